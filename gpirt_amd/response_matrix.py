@@ -1,0 +1,77 @@
+"""Host-side mirror of the reference's `response_matrix` S3 helpers (R/response_matrix.R:51-127).
+
+Pure data preparation that runs once, upstream of the drop-in boundary: recode raw responses to
+{+1, -1, NaN} doubles and drop unanimous items.  In an R deployment this stays in R unchanged
+(INTEGRATION.md); the Python mirror exists so `gpirtMCMC()` here keeps the reference's signature.
+"""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+
+DEFAULT_CODES = dict(yea=(1, 2, 3), nay=(4, 5, 6), missing=(0, 7, 8, 9, None))
+
+
+class ResponseMatrix(np.ndarray):
+    """float64 (n x m) array holding only +1 / -1 / NaN (the reference's class tag)."""
+
+
+def _isin(a, codes):
+    codes = [c for c in np.atleast_1d(np.array(list(codes), dtype=object)) if c is not None]
+    out = np.zeros(a.shape, dtype=bool)
+    for c in codes:
+        if isinstance(c, float) and np.isnan(c):
+            continue
+        out |= (a == c)
+    return out
+
+
+def response_matrix(data, response_codes=None):
+    """R/response_matrix.R:51-99: yea -> +1, nay -> -1, missing/unknown -> NaN, drop unanimous."""
+    if isinstance(data, (list, tuple, dict)):
+        raise TypeError("Conversion from lists to response_matrix objects is currently unsupported.")
+    codes = dict(DEFAULT_CODES if response_codes is None else response_codes)
+    raw = np.asarray(data)
+    if raw.ndim != 2:
+        raise ValueError("data must be a 2-d array (respondents x items)")
+    obj = raw.astype(object)
+    isna = np.array([[v is None or (isinstance(v, float) and np.isnan(v)) for v in row] for row in obj],
+                    dtype=bool).reshape(obj.shape)
+    yea = _isin(obj, np.atleast_1d(codes["yea"])) & ~isna
+    nay = _isin(obj, np.atleast_1d(codes["nay"])) & ~isna
+    mis = _isin(obj, np.atleast_1d(codes["missing"])) | isna
+    unknown = ~(yea | nay | mis)
+    if unknown.any():                                  # :72-77
+        vals = sorted({str(v) for v in obj[unknown]})
+        warnings.warn("Responses with value " + ", ".join(vals) + " were not given a response "
+                      "code and will be treated as missing.")
+    res = np.full(obj.shape, np.nan)
+    res[yea] = 1.0                                     # :79-81
+    res[nay] = -1.0
+    res[mis] = np.nan
+    keep = np.ones(res.shape[1], dtype=bool)           # :87-90
+    for j in range(res.shape[1]):
+        col = res[:, j]
+        u = np.unique(col[~np.isnan(col)])
+        if len(u) == 1:
+            keep[j] = False
+    if (~keep).any():
+        idx = ", ".join(str(i + 1) for i in np.nonzero(~keep)[0])
+        warnings.warn(f"Item(s) {idx} discarded as unanimous.")
+    return np.asfortranarray(res[:, keep]).view(ResponseMatrix)
+
+
+def is_response_matrix(x) -> bool:
+    """R/response_matrix.R:109-115"""
+    if not isinstance(x, ResponseMatrix) or x.ndim != 2:
+        return False
+    a = np.asarray(x)
+    return bool(np.all(np.isnan(a) | (a == 1.0) | (a == -1.0)))
+
+
+def as_response_matrix(x, response_codes=None):
+    """R/response_matrix.R:119-127"""
+    if not is_response_matrix(x):
+        x = response_matrix(x, response_codes)
+    return x
