@@ -1,0 +1,136 @@
+"""ctypes binding of libgpirt_hip.so -- the C ABI declared in include/gpirt_hip.h.
+
+The product path has NO CPU fallback: if the library is missing, or no gfx950 device is visible,
+every compute entry raises.  (The CPU oracle under oracle/ is test infrastructure and is never
+imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgpirt_hip.so")
+
+NGRID = 1001
+RNG_RSTREAM, RNG_ITEM = 0, 1
+ST_INIT_F, ST_INIT_BETA, ST_F_Z, ST_F_ESS, ST_FSTAR, ST_THETA, ST_BETA = 1, 2, 3, 4, 5, 6, 7
+
+E_ARG, E_HIP, E_NODEVICE, E_ALLOC, E_RNG, E_INTERRUPT, E_NUMERIC = -1, -2, -3, -4, -5, -6, -7
+
+
+class GpirtError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[gpirt {code}] {msg}")
+        self.code = code
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("rng_kind", C.c_int),
+        ("seed", C.c_uint64),
+        ("theta_stabilise", C.c_int),
+        ("fstar_fused", C.c_int),
+        ("device", C.c_int),
+        ("use_graph", C.c_int),
+        ("item0", C.c_int64),
+        ("m_total", C.c_int64),
+        ("reserved", C.c_int * 8),
+    ]
+
+
+TICK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)
+
+_vp, _i64, _i32, _u64, _u32, _dbl = C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_uint32, C.c_double
+_dp = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); every symbol include/gpirt_hip.h declares
+SIGNATURES = {
+    "gpirt_version": (_i32, []),
+    "gpirt_last_error": (C.c_char_p, []),
+    "gpirt_device_count": (_i32, [C.POINTER(_i32)]),
+    "gpirt_create": (_i32, [C.POINTER(_vp), _i32, _vp]),
+    "gpirt_create_own_stream": (_i32, [C.POINTER(_vp), _i32]),
+    "gpirt_destroy": (_i32, [_vp]),
+    "gpirt_synchronize": (_i32, [_vp]),
+    "gpirt_set_stream": (_i32, [_vp, _vp]),
+    "gpirt_calibrate_mfma_f64": (_i32, [_vp, _dp]),
+    "gpirt_se_kernel": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _dbl]),
+    "gpirt_potrf_lower": (_i32, [_vp, _vp, _i64, _i64]),
+    "gpirt_factor": (_i32, [_vp, _vp, _i64, _vp, _i64]),
+    "gpirt_trmm_lz": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64]),
+    "gpirt_trsm_lower": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _i32]),
+    "gpirt_gemm": (_i32, [_vp, _i32, _i32, _i64, _i64, _i64, _dbl, _vp, _i64, _vp, _i64, _dbl, _vp, _i64]),
+    "gpirt_ll_bar": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "gpirt_draw_f": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _u64, _u32, _vp]),
+    "gpirt_draw_fstar": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _u64, _u32, _i32, _vp, _vp, _vp]),
+    "gpirt_draw_theta": (_i32, [_vp, _vp, _vp, _i64, _i64, _u64, _u32, _i32, _vp, _vp]),
+    "gpirt_draw_beta": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _u64, _u32]),
+    "gpirt_item_uniforms": (_i32, [_vp, _u64, _u32, _u32, _u32, _i64, _i64, _vp]),
+    "gpirt_item_normals": (_i32, [_vp, _u64, _u32, _u32, _u32, _i64, _i64, _vp]),
+    "gpirt_rstream_create": (_i32, [C.POINTER(_vp), _u32]),
+    "gpirt_rstream_from_state": (_i32, [C.POINTER(_vp), C.POINTER(_u32), _i32]),
+    "gpirt_rstream_get_state": (_i32, [_vp, C.POINTER(_u32), C.POINTER(_i32)]),
+    "gpirt_rstream_destroy": (_i32, [_vp]),
+    "gpirt_rstream_unif": (_i32, [_vp, _dp, _i64]),
+    "gpirt_rstream_norm": (_i32, [_vp, _dp, _i64]),
+    "gpirt_default_options": (None, [C.POINTER(Options)]),
+    "gpirt_mcmc": (_i32, [_dp, _i64, _i64, _dp, _i32, _i32, _dp, _dp, _dp, C.POINTER(Options), _vp,
+                           TICK_FN, _vp, _dp, _dp, _dp, _dp]),
+    "gpirt_sampler_create": (_i32, [C.POINTER(_vp), _vp, _dp, _i64, _i64, _dp, _dp, _dp, _dp,
+                                     C.POINTER(Options), _vp]),
+    "gpirt_sampler_destroy": (_i32, [_vp]),
+    "gpirt_sampler_init": (_i32, [_vp]),
+    "gpirt_sampler_step": (_i32, [_vp]),
+    "gpirt_sampler_draw_f": (_i32, [_vp]),
+    "gpirt_sampler_draw_fstar": (_i32, [_vp]),
+    "gpirt_sampler_theta_partial": (_i32, [_vp]),
+    "gpirt_sampler_theta_finish": (_i32, [_vp]),
+    "gpirt_sampler_draw_beta": (_i32, [_vp]),
+    "gpirt_sampler_factor": (_i32, [_vp]),
+    "gpirt_sampler_accumulate_irf": (_i32, [_vp]),
+    "gpirt_sampler_iteration": (_i32, [_vp, C.POINTER(_i32)]),
+    "gpirt_sampler_check": (_i32, [_vp]),
+    "gpirt_sampler_devptr": (_i32, [_vp, C.c_char_p, C.POINTER(_vp), C.POINTER(_i64)]),
+    "gpirt_sampler_get": (_i32, [_vp, C.c_char_p, _vp, _i64]),
+    "gpirt_sampler_set": (_i32, [_vp, C.c_char_p, _dp, _i64]),
+    "gpirt_sampler_finish_irfs": (_i32, [_vp, _i32, _dp]),
+    "gpirt_sampler_enable_timing": (_i32, [_vp, _i32]),
+    "gpirt_sampler_stage_times": (_i32, [_vp, _dp, _i32, C.POINTER(_i32), C.POINTER(C.c_char_p)]),
+    "gpirt_prof_trailing": (_i32, [_vp, _i32, _dp, C.POINTER(_i64), _dp]),
+    "gpirt_prof_enable": (_i32, [_vp, _i32]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree HIP library and attach the signatures (fails loudly if it is missing)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GpirtError(E_NODEVICE, f"{LIB_PATH} is missing: build it with "
+                                         "`python -m gpirt_amd.build` (hipcc, gfx950). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    return load().gpirt_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        raise GpirtError(rc, last_error())
+    return rc
+
+
+def default_options() -> Options:
+    o = Options()
+    load().gpirt_default_options(C.byref(o))
+    return o

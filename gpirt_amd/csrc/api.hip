@@ -1,0 +1,432 @@
+// api.hip -- handle management, R's RNG on the host, and the operator-level C ABI (include/gpirt_hip.h).
+#include "common.h"
+#include "kernels.h"
+#include "rstream.h"
+
+#include <stdarg.h>
+#include <stdlib.h>
+#include <new>
+
+namespace gpirt {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int ensure_work(gpirt_handle_t h, size_t bytes)
+{
+    if (bytes <= h->work_bytes) return 0;
+    GP_HIP(hipStreamSynchronize(h->stream));
+    if (h->d_work) GP_HIP(hipFree(h->d_work));
+    h->d_work = nullptr;
+    h->work_bytes = 0;
+    hipError_t e = hipMalloc(&h->d_work, bytes);
+    if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return GPIRT_E_ALLOC; }
+    h->work_bytes = bytes;
+    return 0;
+}
+
+static int check_device(int device)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error("no HIP device visible (%s): libgpirt_hip has no CPU fallback",
+                  e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return GPIRT_E_NODEVICE;
+    }
+    if (device >= count) { set_error("device %d out of range (%d visible)", device, count); return GPIRT_E_ARG; }
+    return 0;
+}
+
+// back-to-back v_mfma_f64_16x16x4_f64 with independent accumulators, operands in registers
+__global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double* out, int iters)
+{
+    d4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+    double a = 1.0 + threadIdx.x * 1e-3, b = 1.0 - threadIdx.x * 1e-3;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+}  // namespace gpirt
+
+using namespace gpirt;
+
+extern "C" {
+
+int gpirt_version(void) { return 100; }
+
+const char* gpirt_last_error(void) { return g_err; }
+
+int gpirt_device_count(int* count)
+{
+    GP_ARG(count != nullptr);
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    *count = (e == hipSuccess) ? c : 0;
+    return 0;
+}
+
+int gpirt_create(gpirt_handle_t* out, int device, void* stream)
+{
+    GP_ARG(out != nullptr);
+    *out = nullptr;
+    GP_TRY(check_device(device < 0 ? 0 : device));
+    if (device >= 0) GP_HIP(hipSetDevice(device));
+    int cur = 0;
+    GP_HIP(hipGetDevice(&cur));
+    hipDeviceProp_t prop;
+    GP_HIP(hipGetDeviceProperties(&prop, cur));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; libgpirt_hip is built for gfx950 (MI355X) only", cur, prop.gcnArchName);
+        return GPIRT_E_NODEVICE;
+    }
+    gpirt_handle_s* h = new (std::nothrow) gpirt_handle_s();
+    if (!h) { set_error("out of host memory"); return GPIRT_E_ALLOC; }
+    h->device = cur;
+    // stream == NULL is HIP's default (null) stream, like every hipStream_t argument
+    h->stream = (hipStream_t)stream;
+    h->own_stream = false;
+    GP_HIP(hipMalloc(&h->d_info, 64));
+    GP_HIP(hipMemset(h->d_info, 0, 64));
+    GP_HIP(hipHostMalloc(&h->h_info, 64, hipHostMallocDefault));
+    GP_HIP(hipEventCreate(&h->prof.e0));
+    GP_HIP(hipEventCreate(&h->prof.e1));
+    *out = h;
+    return 0;
+}
+
+int gpirt_destroy(gpirt_handle_t h)
+{
+    if (!h) return 0;
+    hipStreamSynchronize(h->stream);
+    if (h->d_info) hipFree(h->d_info);
+    if (h->h_info) hipHostFree(h->h_info);
+    if (h->d_work) hipFree(h->d_work);
+    if (h->prof.e0) hipEventDestroy(h->prof.e0);
+    if (h->prof.e1) hipEventDestroy(h->prof.e1);
+    if (h->own_stream) hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+int gpirt_synchronize(gpirt_handle_t h)
+{
+    GP_ARG(h != nullptr);
+    GP_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int gpirt_create_own_stream(gpirt_handle_t* out, int device)
+{
+    GP_TRY(gpirt_create(out, device, nullptr));
+    hipStream_t st = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e != hipSuccess) { gpirt_destroy(*out); *out = nullptr; set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); return GPIRT_E_HIP; }
+    (*out)->stream = st;
+    (*out)->own_stream = true;
+    return 0;
+}
+
+int gpirt_set_stream(gpirt_handle_t h, void* stream)
+{
+    GP_ARG(h != nullptr);
+    GP_HIP(hipStreamSynchronize(h->stream));
+    if (h->own_stream) { hipStreamDestroy(h->stream); h->own_stream = false; }
+    h->stream = (hipStream_t)stream;
+    return 0;
+}
+
+int gpirt_calibrate_mfma_f64(gpirt_handle_t h, double* tflops)
+{
+    GP_ARG(h != nullptr && tflops != nullptr);
+    const int blocks = 256 * 8, iters = 4096;
+    GP_TRY(ensure_work(h, (size_t)blocks * 256 * sizeof(double)));
+    hipEvent_t e0, e1;
+    GP_HIP(hipEventCreate(&e0));
+    GP_HIP(hipEventCreate(&e1));
+    double best = 0.0;
+    for (int rep = 0; rep < 4; ++rep) {
+        GP_HIP(hipEventRecord(e0, h->stream));
+        hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, h->stream, h->d_work, iters);
+        GP_HIP(hipEventRecord(e1, h->stream));
+        GP_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        GP_HIP(hipEventElapsedTime(&ms, e0, e1));
+        const double flops = (double)blocks * 4.0 * iters * 8.0 * 2048.0;   // waves * mfma * flop
+        const double tf = flops / (ms * 1e-3) / 1e12;
+        if (tf > best) best = tf;
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *tflops = best;
+    return 0;
+}
+
+static int finish_info(gpirt_handle_t h)
+{
+    GP_HIP(hipMemcpyAsync(h->h_info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    GP_HIP(hipStreamSynchronize(h->stream));
+    const int info = *h->h_info;
+    if (info > 0) set_error("chol(): decomposition failed (leading minor of order %d is not positive definite)", info);
+    return info;
+}
+
+int gpirt_se_kernel(gpirt_handle_t h, const double* d_x1, int64_t n1, const double* d_x2, int64_t n2,
+                    double* d_out, int64_t ld, double jitter)
+{
+    GP_ARG(h && d_x1 && d_x2 && d_out && n1 >= 0 && n2 >= 0 && ld >= n1);
+    return launch_se_kernel(h->stream, d_x1, n1, d_x2, n2, d_out, ld, jitter);
+}
+
+int gpirt_potrf_lower(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda)
+{
+    GP_ARG(h && d_A && n >= 0 && lda >= n);
+    GP_TRY(launch_potrf_lower(h, h->stream, d_A, n, lda, true));
+    return finish_info(h);
+}
+
+int gpirt_factor(gpirt_handle_t h, const double* d_theta, int64_t n, double* d_L, int64_t ldl)
+{
+    GP_ARG(h && d_theta && d_L && n >= 0 && ldl >= n);
+    GP_TRY(launch_se_kernel(h->stream, d_theta, n, d_theta, n, d_L, ldl, GPIRT_JITTER));
+    GP_TRY(launch_potrf_lower(h, h->stream, d_L, n, ldl, true));
+    return finish_info(h);
+}
+
+int gpirt_trmm_lz(gpirt_handle_t h, const double* d_L, int64_t n, int64_t ldl, const double* d_Z,
+                  int64_t m, int64_t ldz, double* d_out, int64_t ldo)
+{
+    GP_ARG(h && d_L && d_Z && d_out && n >= 0 && m >= 0 && ldl >= n && ldz >= n && ldo >= n);
+    return launch_gemm(h, h->stream, false, false, TRI_A_LOWER, n, m, n, 1.0, d_L, ldl, d_Z, ldz, 0.0, d_out, ldo);
+}
+
+int gpirt_trsm_lower(gpirt_handle_t h, const double* d_L, int64_t n, int64_t ldl, double* d_B,
+                     int64_t nrhs, int64_t ldb, int trans)
+{
+    GP_ARG(h && d_L && d_B && n >= 0 && nrhs >= 0 && ldl >= n && ldb >= n);
+    return launch_trsm_lower(h, h->stream, d_L, n, ldl, d_B, nrhs, ldb, trans != 0);
+}
+
+int gpirt_gemm(gpirt_handle_t h, int ta, int tb, int64_t M, int64_t N, int64_t K, double alpha,
+               const double* d_A, int64_t lda, const double* d_B, int64_t ldb, double beta,
+               double* d_C, int64_t ldc)
+{
+    GP_ARG(h && d_A && d_B && d_C && M >= 0 && N >= 0 && K >= 0);
+    GP_ARG(lda >= (ta ? K : M) && ldb >= (tb ? N : K) && ldc >= M);
+    return launch_gemm(h, h->stream, ta != 0, tb != 0, TRI_NONE, M, N, K, alpha, d_A, lda, d_B, ldb, beta, d_C, ldc);
+}
+
+int gpirt_ll_bar(gpirt_handle_t h, const double* d_f, const double* d_y, const double* d_mu,
+                 int64_t n, int64_t m, double* d_out)
+{
+    GP_ARG(h && d_f && d_y && d_out && n >= 0 && m >= 0);
+    return launch_ll_bar(h->stream, d_f, d_y, d_mu, n, m, d_out);
+}
+
+int gpirt_item_uniforms(gpirt_handle_t h, uint64_t seed, uint32_t iter, uint32_t stage,
+                        uint32_t item0, int64_t n_items, int64_t n_index, double* d_out)
+{
+    GP_ARG(h && d_out && n_items >= 0 && n_index >= 0);
+    return launch_item_uniforms(h->stream, seed, iter, stage, item0, n_items, n_index, d_out, false);
+}
+
+int gpirt_item_normals(gpirt_handle_t h, uint64_t seed, uint32_t iter, uint32_t stage,
+                       uint32_t item0, int64_t n_items, int64_t n_index, double* d_out)
+{
+    GP_ARG(h && d_out && n_items >= 0 && n_index >= 0);
+    return launch_item_uniforms(h->stream, seed, iter, stage, item0, n_items, n_index, d_out, true);
+}
+
+int gpirt_draw_f(gpirt_handle_t h, double* d_f, const double* d_y, const double* d_L, int64_t ldl,
+                 const double* d_mu, int64_t n, int64_t m, uint64_t seed, uint32_t iter, int* d_k_out)
+{
+    GP_ARG(h && d_f && d_y && d_L && d_mu && n >= 0 && m >= 0 && ldl >= n);
+    // workspace: Z (n x m) | NU (n x m) | err
+    const size_t nm = (size_t)n * (size_t)m;
+    GP_TRY(ensure_work(h, (2 * nm + 8) * sizeof(double)));
+    double* Z = h->d_work;
+    double* NU = Z + nm;
+    int* err = reinterpret_cast<int*>(NU + nm);
+    GP_HIP(hipMemsetAsync(err, 0, sizeof(int), h->stream));
+    GP_TRY(launch_item_uniforms(h->stream, seed, iter, GPIRT_ST_F_Z, 0, m, n, Z, true));
+    GP_TRY(launch_gemm(h, h->stream, false, false, TRI_A_LOWER, n, m, n, 1.0, d_L, ldl, Z, n, 0.0, NU, n));
+    EssArgs a{};
+    a.f = d_f; a.nu = NU; a.y = d_y; a.mu = d_mu; a.n = n; a.m = m; a.k_out = d_k_out; a.err = err;
+    a.seed = seed; a.iter = iter; a.item0 = 0; a.U = nullptr; a.pos = nullptr; a.cap = 0;
+    GP_TRY(launch_ess(h->stream, a));
+    GP_HIP(hipMemcpyAsync(h->h_info, err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    GP_HIP(hipStreamSynchronize(h->stream));
+    if (*h->h_info != 0) { set_error("draw_f: elliptical slice sampler did not terminate"); return GPIRT_E_NUMERIC; }
+    return 0;
+}
+
+int gpirt_draw_fstar(gpirt_handle_t h, const double* d_f, const double* d_theta, const double* d_L,
+                     int64_t ldl, const double* d_mu_star, int64_t n, int64_t m, uint64_t seed,
+                     uint32_t iter, int fused, double* d_out, double* d_s_out, double* d_mean_out)
+{
+    GP_ARG(h && d_f && d_theta && d_L && d_mu_star && d_out && n >= 0 && m >= 0 && ldl >= n);
+    const int64_t N = GPIRT_NGRID;
+    // workspace: tstar (N) | kstar (n x N) | rhs (n x (N+m)) | mean (N x m) | s (N)
+    const size_t need = (size_t)N + (size_t)n * N + (size_t)n * (N + m) + (size_t)N * m + (size_t)N + 16;
+    GP_TRY(ensure_work(h, need * sizeof(double)));
+    double* tstar = h->d_work;
+    double* kstar = tstar + ((N + 1) & ~1);
+    double* rhs = kstar + (size_t)n * N + ((size_t)n * N & 1);
+    double* mean = rhs + (size_t)n * (N + m) + (((size_t)n * (N + m)) & 1);
+    double* s = mean + (size_t)N * m;
+    double ts[GPIRT_NGRID];
+    for (int i = 0; i < GPIRT_NGRID; ++i) ts[i] = -5.0 + (double)i * 0.01;
+    GP_HIP(hipMemcpyAsync(tstar, ts, sizeof(ts), hipMemcpyHostToDevice, h->stream));
+    GP_HIP(hipStreamSynchronize(h->stream));   // ts is a stack buffer
+    GP_TRY(launch_se_kernel(h->stream, d_theta, n, tstar, N, kstar, n, 0.0));              // :17
+    GP_HIP(hipMemcpyAsync(rhs, kstar, sizeof(double) * (size_t)n * N, hipMemcpyDeviceToDevice, h->stream));
+    GP_HIP(hipMemcpyAsync(rhs + (size_t)n * N, d_f, sizeof(double) * (size_t)n * m, hipMemcpyDeviceToDevice, h->stream));
+    GP_TRY(launch_trsm_lower(h, h->stream, d_L, n, ldl, rhs, N + m, n, false));             // :19 and :7 inner
+    GP_TRY(launch_colnorm_s(h->stream, rhs, n, N, n, s));                                   // :20
+    double* W = rhs + (size_t)n * N;
+    if (fused) {
+        GP_TRY(launch_gemm(h, h->stream, true, false, TRI_NONE, N, m, n, 1.0, rhs, n, W, n, 0.0, mean, N));
+    } else {
+        GP_TRY(launch_trsm_lower(h, h->stream, d_L, n, ldl, W, m, n, true));                // :7 outer
+        GP_TRY(launch_gemm(h, h->stream, true, false, TRI_NONE, N, m, n, 1.0, kstar, n, W, n, 0.0, mean, N)); // :25
+    }
+    FstarEpiArgs a{};
+    a.mean = mean; a.mu_star = d_mu_star; a.s = s; a.out = d_out; a.N = N; a.m = m;
+    a.seed = seed; a.iter = iter; a.item0 = 0; a.U = nullptr; a.mean_out = d_mean_out;
+    GP_TRY(launch_fstar_epilogue(h->stream, a));
+    if (d_s_out) GP_HIP(hipMemcpyAsync(d_s_out, s, sizeof(double) * N, hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+}
+
+int gpirt_draw_theta(gpirt_handle_t h, const double* d_y, const double* d_fstar, int64_t n,
+                     int64_t m, uint64_t seed, uint32_t iter, int stabilise, double* d_theta_out,
+                     int* d_degenerate)
+{
+    GP_ARG(h && d_y && d_fstar && d_theta_out && n >= 0 && m >= 0);
+    const int64_t N = GPIRT_NGRID;
+    // workspace: Ypm (n x 2m) | Gpm (N x 2m, padded) | logpost (N x n)
+    const size_t need = (size_t)n * 2 * m + (size_t)N * 2 * m + 2 + (size_t)N * n + 16;
+    GP_TRY(ensure_work(h, need * sizeof(double)));
+    double* Ypm = h->d_work;
+    double* Gpm = Ypm + (size_t)n * 2 * m;
+    double* lp = Gpm + (size_t)N * 2 * m + (((size_t)N * 2 * m) & 1);
+    GP_TRY(launch_indicators(h->stream, d_y, n, m, Ypm));
+    GP_TRY(launch_loglik_terms(h->stream, d_fstar, N, m, Gpm));
+    GP_TRY(launch_gemm(h, h->stream, false, true, TRI_NONE, N, n, 2 * m, 1.0, Gpm, N, Ypm, n, 0.0, lp, N));
+    if (d_degenerate) GP_HIP(hipMemsetAsync(d_degenerate, 0, sizeof(int), h->stream));
+    ThetaArgs a{};
+    a.logpost = lp; a.N = N; a.n = n; a.stabilise = stabilise; a.seed = seed; a.iter = iter;
+    a.U = nullptr; a.theta_out = d_theta_out; a.degenerate = d_degenerate; a.err = nullptr;
+    return launch_theta_sample(h->stream, a);
+}
+
+int gpirt_draw_beta(gpirt_handle_t h, double* d_beta, const double* d_theta, const double* d_y,
+                    const double* d_f, const double* d_pm, const double* d_ps, const double* d_step,
+                    int64_t n, int64_t m, uint64_t seed, uint32_t iter)
+{
+    GP_ARG(h && d_beta && d_theta && d_y && d_f && d_pm && d_ps && d_step && n >= 0 && m >= 0);
+    BetaArgs a{};
+    a.beta = d_beta; a.theta = d_theta; a.y = d_y; a.f = d_f; a.pm = d_pm; a.ps = d_ps; a.step = d_step;
+    a.n = n; a.m = m; a.N = GPIRT_NGRID; a.mu = nullptr; a.mu_star = nullptr;
+    a.seed = seed; a.iter = iter; a.item0 = 0; a.U = nullptr;
+    return launch_draw_beta(h->stream, a);
+}
+
+int gpirt_prof_enable(gpirt_handle_t h, int on)
+{
+    GP_ARG(h != nullptr);
+    h->prof.enabled = on != 0;
+    return 0;
+}
+
+int gpirt_prof_trailing(gpirt_handle_t h, int reset, double* total_ms, int64_t* launches, double* flops)
+{
+    GP_ARG(h != nullptr);
+    if (total_ms) *total_ms = h->prof.trailing_ms;
+    if (launches) *launches = h->prof.trailing_launches;
+    if (flops) *flops = h->prof.trailing_flops;
+    if (reset) { h->prof.trailing_ms = 0.0; h->prof.trailing_launches = 0; h->prof.trailing_flops = 0.0; }
+    return 0;
+}
+
+// ---------------------------------------------------------------- R stream (host) ----------
+int gpirt_rstream_create(gpirt_rstream_t* out, uint32_t seed)
+{
+    GP_ARG(out != nullptr);
+    gpirt_rstream_s* r = new (std::nothrow) gpirt_rstream_s();
+    if (!r) { set_error("out of host memory"); return GPIRT_E_ALLOC; }
+    // set.seed(): Randomize() -- 50 LCG scrambles, then 625 LCG words; dummy[0] (mti) forced to 624
+    for (int j = 0; j < 50; ++j) seed = 69069u * seed + 1u;
+    uint32_t dummy[625];
+    for (int j = 0; j < 625; ++j) { seed = 69069u * seed + 1u; dummy[j] = seed; }
+    memcpy(r->r.mt, dummy + 1, sizeof(r->r.mt));
+    r->r.mti = 624;
+    *out = r;
+    return 0;
+}
+
+int gpirt_rstream_from_state(gpirt_rstream_t* out, const uint32_t mt[624], int mti)
+{
+    GP_ARG(out != nullptr && mt != nullptr && mti >= 0 && mti <= 624);
+    gpirt_rstream_s* r = new (std::nothrow) gpirt_rstream_s();
+    if (!r) { set_error("out of host memory"); return GPIRT_E_ALLOC; }
+    memcpy(r->r.mt, mt, sizeof(r->r.mt));
+    r->r.mti = mti;
+    *out = r;
+    return 0;
+}
+
+int gpirt_rstream_get_state(gpirt_rstream_t r, uint32_t mt[624], int* mti)
+{
+    GP_ARG(r && mt && mti);
+    memcpy(mt, r->r.mt, sizeof(r->r.mt));
+    *mti = r->r.mti;
+    return 0;
+}
+
+int gpirt_rstream_destroy(gpirt_rstream_t r) { delete r; return 0; }
+
+int gpirt_rstream_unif(gpirt_rstream_t r, double* h_out, int64_t n)
+{
+    GP_ARG(r && (h_out || n == 0) && n >= 0);
+    for (int64_t i = 0; i < n; ++i) h_out[i] = r->r.unif();
+    return 0;
+}
+
+int gpirt_rstream_norm(gpirt_rstream_t r, double* h_out, int64_t n)
+{
+    GP_ARG(r && (h_out || n == 0) && n >= 0);
+    for (int64_t i = 0; i < n; ++i) h_out[i] = r->r.norm();
+    return 0;
+}
+
+void gpirt_default_options(gpirt_options* o)
+{
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->rng_kind = GPIRT_RNG_ITEM;
+    o->seed = 1;
+    o->theta_stabilise = 1;
+    o->fstar_fused = 0;
+    o->device = -1;
+    o->use_graph = 0;
+    o->item0 = 0;
+    o->m_total = 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,169 @@
+// common.h -- shared host/device helpers of libgpirt_hip (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+
+#include "../../include/gpirt_hip.h"
+
+namespace gpirt {
+
+// ---------------------------------------------------------------- errors -------------------
+void set_error(const char* fmt, ...);
+
+#define GP_HIP(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            gpirt::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                             __LINE__);                                                      \
+            return GPIRT_E_HIP;                                                              \
+        }                                                                                    \
+    } while (0)
+
+#define GP_ARG(cond)                                                                         \
+    do {                                                                                     \
+        if (!(cond)) {                                                                       \
+            gpirt::set_error("bad argument: %s (%s:%d)", #cond, __FILE__, __LINE__);         \
+            return GPIRT_E_ARG;                                                              \
+        }                                                                                    \
+    } while (0)
+
+#define GP_TRY(call)                                                                         \
+    do {                                                                                     \
+        int r_ = (call);                                                                     \
+        if (r_ != 0) return r_;                                                              \
+    } while (0)
+
+// ---------------------------------------------------------------- handle -------------------
+struct Prof {
+    bool        enabled = false;
+    double      trailing_ms = 0.0;
+    int64_t     trailing_launches = 0;
+    double      trailing_flops = 0.0;
+    hipEvent_t  e0 = nullptr, e1 = nullptr;
+};
+
+}  // namespace gpirt
+
+struct gpirt_handle_s {
+    int          device = 0;
+    hipStream_t  stream = nullptr;
+    bool         own_stream = false;
+    // small persistent workspace
+    int*         d_info = nullptr;       // potrf info (device)
+    int*         h_info = nullptr;       // pinned mirror
+    double*      d_work = nullptr;       // generic scratch (grown on demand)
+    size_t       work_bytes = 0;
+    gpirt::Prof  prof;
+};
+
+namespace gpirt {
+
+int  ensure_work(gpirt_handle_t h, size_t bytes);   // grows h->d_work (syncs when it reallocates)
+
+// ---------------------------------------------------------------- device math --------------
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+#define GP_2PI 6.283185307179586476925286766559
+
+// Philox4x32-10 (same contract as the oracle; GPIRT_RNG_ITEM)
+__host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+#pragma unroll
+    for (int round = 0; round < 10; ++round) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// one uniform in (0,1) per (seed, iteration, stage, item, index): 52 random bits + half an ulp
+__host__ __device__ inline double item_uniform(uint64_t seed, uint32_t iter, uint32_t stage,
+                                               uint32_t item, uint32_t index)
+{
+    uint32_t o[4];
+    philox4x32_10(index, item, stage, iter, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    uint64_t v = ((uint64_t)(o[0] >> 6) << 26) | (uint64_t)(o[1] >> 6);
+    return ((double)v + 0.5) * 2.220446049250313e-16;
+}
+
+// R's qnorm(p, 0, 1, lower, !log): Wichura AS241 PPND16, evaluated in R's Horner order
+__host__ __device__ inline double qnorm_as241(double p)
+{
+    double q = p - 0.5, r, val;
+    if (fabs(q) <= 0.425) {
+        r = 0.180625 - q * q;
+        val = q * (((((((r * 2509.0809287301226727 + 33430.575583588128105) * r
+                        + 67265.770927008700853) * r + 45921.953931549871457) * r
+                      + 13731.693765509461125) * r + 1971.5909503065514427) * r
+                    + 133.14166789178437745) * r + 3.387132872796366608)
+              / (((((((r * 5226.495278852545925 + 28729.085735721942674) * r
+                      + 39307.89580009271061) * r + 21213.794301586595867) * r
+                    + 5394.1960214247511077) * r + 687.1870074920579083) * r
+                  + 42.313330701600911252) * r + 1.0);
+        return val;
+    }
+    r = (q < 0) ? p : 1.0 - p;
+    r = sqrt(-log(r));
+    if (r <= 5.0) {
+        r += -1.6;
+        val = (((((((r * 7.7454501427834140764e-4 + 0.0227238449892691845833) * r
+                    + 0.24178072517745061177) * r + 1.27045825245236838258) * r
+                  + 3.64784832476320460504) * r + 5.7694972214606914055) * r
+                + 4.6303378461565452959) * r + 1.42343711074968357734)
+              / (((((((r * 1.05075007164441684324e-9 + 5.475938084995344946e-4) * r
+                      + 0.0151986665636164571966) * r + 0.14810397642748007459) * r
+                    + 0.68976733498510000455) * r + 1.6763848301838038494) * r
+                  + 2.05319162663775882187) * r + 1.0);
+    } else {
+        r += -5.0;
+        val = (((((((r * 2.01033439929228813265e-7 + 2.71155556874348757815e-5) * r
+                    + 0.0012426609473880784386) * r + 0.026532189526576123093) * r
+                  + 0.29656057182850489123) * r + 1.7848265399172913358) * r
+                + 5.4637849111641143699) * r + 6.6579046435011037772)
+              / (((((((r * 2.04426310338993978564e-15 + 1.4215117583164458887e-7) * r
+                      + 1.8463183175100546818e-5) * r + 7.868691311456132591e-4) * r
+                    + 0.0148753612908506148525) * r + 0.13692988092273580531) * r
+                  + 0.59983220655588793769) * r + 1.0);
+    }
+    if (q < 0.0) val = -val;
+    return val;
+}
+
+// R's norm_rand() under INVERSION from two consecutive stream uniforms
+__host__ __device__ inline double rnorm_from_two(double u1, double u2)
+{
+    const double BIG = 134217728.0;
+    double u = (double)(int)(BIG * u1) + u2;
+    return qnorm_as241(u / BIG);
+}
+
+// one term of ll()/ll_bar(): log(1 + exp(-a)), verbatim (src/log-likelihood.cpp:20,34)
+__device__ inline double ll_term(double a) { return log(1 + exp(-a)); }
+
+// block-wide sum for 256-thread blocks, fixed reduction tree (deterministic)
+__device__ inline double block_sum_256(double v, double* smem /* >= 4 doubles */)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) smem[w] = v;
+    __syncthreads();
+    double r = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+    return r;
+}
+
+}  // namespace gpirt

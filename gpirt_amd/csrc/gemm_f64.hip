@@ -1,0 +1,247 @@
+// gemm_f64.hip -- the fp64 MFMA GEMM core every stage is built on (gfx950, v_mfma_f64_16x16x4_f64).
+//
+//   C (M x N, column-major) = alpha * op(A) * op(B) + beta * C
+//
+// Work-group = 256 threads = 4 waves (2 x 2), block tile 128 x 128, K-step 16, each wave owns a
+// 64 x 64 sub-tile = 4 x 4 MFMA tiles (16 accumulators x 4 fp64 = 128 VGPRs).  Operands are
+// staged global -> registers -> LDS (double-buffered, one barrier per K-step); an operand whose
+// M/N index is contiguous in memory is kept [k][mn] with a 16-double row pad, one whose K index is
+// contiguous is kept [mn][k] with a 2-double pad -- both read conflict-free by ds_read_b64.
+// The MFMA is issued with the roles swapped (A_mfma <- B fragment, B_mfma <- A fragment) so the
+// accumulator's lane index runs along M, the contiguous dimension of C: every store instruction
+// writes 128-byte row segments.
+//
+// Triangular modes let the callers skip structural zeros without reshaping anything:
+//   TRI_SYRK_LOWER  only blocks on/below the block diagonal (potrf trailing update, C -= P P^T)
+//   TRI_A_LOWER     op(A) is lower triangular: K loop stops at the block's last row  (trmm L Z)
+//   TRI_A_UPPER     op(A) is upper triangular: K loop starts at the block's first row (L^T X)
+//
+// Reference call sites this core serves: cholS * res (src/mvnormal.h:10), the dtrsm/dgemv chain of
+// src/draw-fstar.cpp:7,19,25, arma::chol's trailing update (src/gpirtMCMC.cpp:17,78,97) and the
+// log-likelihood sums of src/draw-theta.cpp:15-19 restated as a GEMM.
+#include "common.h"
+#include "kernels.h"
+
+namespace gpirt {
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LDS_MN = BM + 16;      // [k][mn] row stride (doubles)
+constexpr int LDS_K  = BK + 2;       // [mn][k] row stride (doubles)
+constexpr int TILE_DOUBLES = 2304;   // == BK*LDS_MN == BM*LDS_K
+
+struct GemmParams {
+    const double* A; const double* B; double* C;
+    int64_t lda, ldb, ldc;
+    int M, N, K;
+    double alpha, beta;
+    int tri;
+    int mblocks, nblocks;
+    int fastA, fastB;     // operand base/ld are 16-byte friendly
+};
+
+template <bool KCONTIG>
+__device__ __forceinline__ void load_tile(const double* __restrict__ G, int64_t ld, int mn0,
+                                          int mnmax, int k0, int kmax, bool fast, double2 (&reg)[4])
+{
+    const int t = threadIdx.x;
+    if (!KCONTIG) {
+        const int r2 = (t & 63) * 2;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int c = (t >> 6) + 4 * pass;
+            const double* p = G + (int64_t)(mn0 + r2) + (int64_t)(k0 + c) * ld;
+            if (fast) {
+                reg[pass] = *reinterpret_cast<const double2*>(p);
+            } else {
+                const bool kin = (k0 + c) < kmax;
+                reg[pass].x = (kin && (mn0 + r2) < mnmax) ? p[0] : 0.0;
+                reg[pass].y = (kin && (mn0 + r2 + 1) < mnmax) ? p[1] : 0.0;
+            }
+        }
+    } else {
+        const int k2 = (t & 7) * 2;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int mn = (t >> 3) + 32 * pass;
+            const double* p = G + (int64_t)(k0 + k2) + (int64_t)(mn0 + mn) * ld;
+            if (fast) {
+                reg[pass] = *reinterpret_cast<const double2*>(p);
+            } else {
+                const bool in = (mn0 + mn) < mnmax;
+                reg[pass].x = (in && (k0 + k2) < kmax) ? p[0] : 0.0;
+                reg[pass].y = (in && (k0 + k2 + 1) < kmax) ? p[1] : 0.0;
+            }
+        }
+    }
+}
+
+template <bool KCONTIG>
+__device__ __forceinline__ void store_tile(double* __restrict__ s, const double2 (&reg)[4])
+{
+    const int t = threadIdx.x;
+    if (!KCONTIG) {
+        const int r2 = (t & 63) * 2;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int c = (t >> 6) + 4 * pass;
+            *reinterpret_cast<double2*>(&s[c * LDS_MN + r2]) = reg[pass];
+        }
+    } else {
+        const int k2 = (t & 7) * 2;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int mn = (t >> 3) + 32 * pass;
+            *reinterpret_cast<double2*>(&s[mn * LDS_K + k2]) = reg[pass];
+        }
+    }
+}
+
+// TA: A is stored K x M (op(A) = A^T)  -> K-contiguous.   !TA: stored M x K -> M-contiguous.
+// TB: B is stored N x K (op(B) = B^T)  -> N-contiguous.   !TB: stored K x N -> K-contiguous.
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p)
+{
+    __shared__ __attribute__((aligned(16))) double smem[4 * TILE_DOUBLES];
+    double* sA = smem;                       // [2][TILE]
+    double* sB = smem + 2 * TILE_DOUBLES;    // [2][TILE]
+
+    int bi, bj;
+    if (p.tri == TRI_SYRK_LOWER) {
+        // block columns bj = 0..nblocks-1, each holding block rows bj..mblocks-1 (M >= N trapezoid)
+        const int t = blockIdx.x, mb = p.mblocks;
+        const double q = 2.0 * mb + 1.0;
+        int c = (int)((q - sqrt(q * q - 8.0 * (double)t)) * 0.5);
+        if (c < 0) c = 0;
+        if (c > p.nblocks - 1) c = p.nblocks - 1;
+        while (c > 0 && c * mb - c * (c - 1) / 2 > t) --c;
+        while (c + 1 < p.nblocks && (c + 1) * mb - (c + 1) * c / 2 <= t) ++c;
+        bj = c;
+        bi = c + (t - (c * mb - c * (c - 1) / 2));
+    } else {
+        bi = blockIdx.x % p.mblocks;
+        bj = blockIdx.x / p.mblocks;
+    }
+    const int i0 = bi * BM, j0 = bj * BN;
+
+    int kbeg = 0, kend = p.K;
+    if (p.tri == TRI_A_LOWER) kend = min(p.K, i0 + BM);
+    if (p.tri == TRI_A_UPPER) kbeg = (i0 / BK) * BK;
+
+    constexpr bool A_KC = TA, B_KC = !TB;
+    const bool fullA = p.fastA && (i0 + BM <= p.M);
+    const bool fullB = p.fastB && (j0 + BN <= p.N);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    d4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    double2 ra[4], rb[4];
+    if (nk > 0) {
+        const bool kfull = (kbeg + BK <= p.K);
+        load_tile<A_KC>(p.A, p.lda, i0, p.M, kbeg, p.K, fullA && kfull, ra);
+        load_tile<B_KC>(p.B, p.ldb, j0, p.N, kbeg, p.K, fullB && kfull, rb);
+        store_tile<A_KC>(sA, ra);
+        store_tile<B_KC>(sB, rb);
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        const bool more = (kt + 1 < nk);
+        if (more) {
+            const int k0 = kbeg + (kt + 1) * BK;
+            const bool kfull = (k0 + BK <= p.K);
+            load_tile<A_KC>(p.A, p.lda, i0, p.M, k0, p.K, fullA && kfull, ra);
+            load_tile<B_KC>(p.B, p.ldb, j0, p.N, k0, p.K, fullB && kfull, rb);
+        }
+        const double* cA = sA + buf * TILE_DOUBLES;
+        const double* cB = sB + buf * TILE_DOUBLES;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            double a[4], b[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int mi = wm * 64 + t * 16 + l15;
+                const int ni = wn * 64 + t * 16 + l15;
+                const int kq = kk * 4 + l4;
+                a[t] = A_KC ? cA[mi * LDS_K + kq] : cA[kq * LDS_MN + mi];
+                b[t] = B_KC ? cB[ni * LDS_K + kq] : cB[kq * LDS_MN + ni];
+            }
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[tn], a[tm], acc[tn][tm], 0, 0, 0);
+        }
+        if (more) {
+            store_tile<A_KC>(sA + (buf ^ 1) * TILE_DOUBLES, ra);
+            store_tile<B_KC>(sB + (buf ^ 1) * TILE_DOUBLES, rb);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: acc[tn][tm][r] = C[m = i0+wm*64+tm*16+l15][n = j0+wn*64+tn*16+l4+4r]
+    const double alpha = p.alpha, beta = p.beta;
+    const bool interior = (i0 + BM <= p.M) && (j0 + BN <= p.N);
+    const bool lower_mask = (p.tri == TRI_SYRK_LOWER) && (bi == bj);
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = j0 + wn * 64 + tn * 16 + l4 + 4 * r;
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) {
+                const int m = i0 + wm * 64 + tm * 16 + l15;
+                if ((interior || (m < p.M && n < p.N)) && !(lower_mask && m < n)) {
+                    double* c = p.C + (int64_t)m + (int64_t)n * p.ldc;
+                    double v = alpha * acc[tn][tm][r];
+                    if (beta != 0.0) v += beta * (*c);
+                    *c = v;
+                }
+            }
+        }
+}
+
+}  // namespace
+
+int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri, int64_t M,
+                int64_t N, int64_t K, double alpha, const double* A, int64_t lda, const double* B,
+                int64_t ldb, double beta, double* C, int64_t ldc)
+{
+    (void)h;
+    if (M <= 0 || N <= 0) return 0;
+    GemmParams p;
+    p.A = A; p.B = B; p.C = C;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.M = (int)M; p.N = (int)N; p.K = (int)K;
+    p.alpha = alpha; p.beta = beta; p.tri = tri;
+    p.mblocks = (int)((M + BM - 1) / BM);
+    p.nblocks = (int)((N + BN - 1) / BN);
+    p.fastA = (((uintptr_t)A & 15) == 0) && (lda % 2 == 0);
+    p.fastB = (((uintptr_t)B & 15) == 0) && (ldb % 2 == 0);
+    int64_t grid;
+    if (tri == TRI_SYRK_LOWER) {
+        if (M < N) { set_error("syrk mode needs M >= N"); return GPIRT_E_ARG; }
+        grid = (int64_t)p.nblocks * p.mblocks - (int64_t)p.nblocks * (p.nblocks - 1) / 2;
+    } else {
+        grid = (int64_t)p.mblocks * p.nblocks;
+    }
+    dim3 g((unsigned)grid), b(256);
+    if (!ta && tb)       hipLaunchKernelGGL((gemm_f64_kernel<false, true>),  g, b, 0, stream, p);
+    else if (!ta && !tb) hipLaunchKernelGGL((gemm_f64_kernel<false, false>), g, b, 0, stream, p);
+    else if (ta && !tb)  hipLaunchKernelGGL((gemm_f64_kernel<true, false>),  g, b, 0, stream, p);
+    else                 hipLaunchKernelGGL((gemm_f64_kernel<true, true>),   g, b, 0, stream, p);
+    GP_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace gpirt

@@ -1,0 +1,92 @@
+// kernels.h -- internal launch functions of libgpirt_hip (device pointers, explicit stream).
+#pragma once
+
+#include "common.h"
+
+namespace gpirt {
+
+enum { TRI_NONE = 0, TRI_SYRK_LOWER = 1, TRI_A_LOWER = 2, TRI_A_UPPER = 3 };
+
+// gemm_f64.hip
+int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri, int64_t M,
+                int64_t N, int64_t K, double alpha, const double* A, int64_t lda, const double* B,
+                int64_t ldb, double beta, double* C, int64_t ldc);
+
+// se_kernel.hip
+int launch_se_kernel(hipStream_t stream, const double* x1, int64_t n1, const double* x2, int64_t n2,
+                     double* out, int64_t ld, double jitter);
+// lower-triangular blocks only (upper blocks are left untouched): the potrf input
+int launch_se_kernel_lower(hipStream_t stream, const double* x, int64_t n, double* out, int64_t ld,
+                           double jitter);
+
+// potrf.hip
+int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda,
+                       bool zero_upper);
+
+// trsm.hip
+int launch_trsm_lower(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t n, int64_t ldl,
+                      double* B, int64_t nrhs, int64_t ldb, bool trans);
+
+// rng.hip
+int launch_item_uniforms(hipStream_t stream, uint64_t seed, uint32_t iter, uint32_t stage,
+                         uint32_t item0, int64_t n_items, int64_t n_index, double* out, bool normal);
+// z (n x m) from the R stream: column j, row i <- rnorm from U[pos0 + j*stride + 2i], U[.. + 1]
+int launch_rstream_normals(hipStream_t stream, const double* U, const uint64_t* d_pos,
+                           int64_t col_stride, int64_t n, int64_t m, double* out);
+
+// ess.hip
+struct EssArgs {
+    double* f; const double* nu; const double* y; const double* mu;
+    int64_t n, m;
+    int* k_out;           // rejection counts per column (may be null)
+    int* err;             // device error flag (set when the slice loop hits its cap)
+    // item RNG
+    uint64_t seed; uint32_t iter; uint32_t item0;
+    // R-stream replay (U != null): one column per launch, uniforms from U[*pos + 2n ...]
+    const double* U; uint64_t* pos; uint64_t cap;
+};
+int launch_ess(hipStream_t stream, const EssArgs& a);
+int launch_ll_bar(hipStream_t stream, const double* f, const double* y, const double* mu, int64_t n,
+                  int64_t m, double* out);
+
+// fstar.hip
+int launch_colnorm_s(hipStream_t stream, const double* tmp, int64_t n, int64_t N, int64_t ld, double* s);
+struct FstarEpiArgs {
+    const double* mean; const double* mu_star; const double* s; double* out;
+    int64_t N, m;
+    uint64_t seed; uint32_t iter; uint32_t item0;
+    const double* U; uint64_t* pos; uint64_t cap; int* err;   // R-stream replay when U != null
+    double* mean_out;     // optional copy of mean + mu_star
+};
+int launch_fstar_epilogue(hipStream_t stream, const FstarEpiArgs& a);
+
+// theta.hip
+int launch_indicators(hipStream_t stream, const double* y, int64_t n, int64_t m, double* Ypm /* n x 2m */);
+int launch_loglik_terms(hipStream_t stream, const double* fstar, int64_t N, int64_t m, double* Gpm /* N x 2m */);
+struct ThetaArgs {
+    const double* logpost;   // N x n (column i = respondent i), WITHOUT the prior
+    int64_t N, n;
+    int stabilise;
+    uint64_t seed; uint32_t iter;
+    const double* U; uint64_t* pos; uint64_t cap;  // R-stream replay when U != null
+    double* theta_out; int* degenerate; int* err;
+};
+int launch_theta_sample(hipStream_t stream, const ThetaArgs& a);
+
+// beta.hip
+struct BetaArgs {
+    double* beta; const double* theta; const double* y; const double* f;
+    const double* pm; const double* ps; const double* step;
+    int64_t n, m, N;
+    double* mu; double* mu_star;      // refreshed with the new beta (may be null)
+    uint64_t seed; uint32_t iter; uint32_t item0;
+    const double* U; uint64_t* pos; const uint64_t* item_off; uint64_t cap; int* err;  // R stream
+};
+int launch_draw_beta(hipStream_t stream, const BetaArgs& a);
+int launch_linear_mean(hipStream_t stream, const double* x, int64_t n, const double* beta, int64_t m, double* mu);
+
+// misc
+int launch_axpy_irf(hipStream_t stream, double* acc, const double* fstar, int64_t count);
+int launch_advance_pos(hipStream_t stream, uint64_t* pos, uint64_t delta);
+
+}  // namespace gpirt

@@ -1,0 +1,612 @@
+// sampler.hip -- device-resident state and the per-iteration driver of gpirtMCMC()
+// (src/gpirtMCMC.cpp:5-117): init, draw_f -> draw_fstar -> draw_theta -> draw_beta -> mu, mu_star
+// -> K + jitter -> chol, storage of draws, IRF averaging.  One process drives one GPU; a host that
+// shards item columns over several processes calls the stage entry points and puts its collective
+// (RCCL through torch.distributed) between gpirt_sampler_theta_partial and _theta_finish.
+//
+// Two RNG contracts:
+//   GPIRT_RNG_ITEM     counter-based sub-streams: all m columns of draw_f are ONE trmm + ONE
+//                      elliptical-slice launch;
+//   GPIRT_RNG_RSTREAM  exact replay of R's global Mersenne-Twister stream.  The stream is generated
+//                      on the host one iteration ahead (a fixed, value-independent sequence), copied
+//                      to the device, and consumed through a device-resident cursor, because ess()'s
+//                      consumption is data dependent (k_j rejections) and sequential over items.
+#include "common.h"
+#include "kernels.h"
+#include "rstream.h"
+
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace gpirt;
+
+namespace {
+
+enum { ST_DRAW_F = 0, ST_FSTAR, ST_THETA_GEMM, ST_THETA_SAMPLE, ST_BETA, ST_FACTOR, ST_COUNT };
+const char* const kStageNames[ST_COUNT] = { "draw_f", "draw_fstar", "theta_gemm", "theta_sample",
+                                            "draw_beta", "factor" };
+
+}  // namespace
+
+struct gpirt_sampler_s {
+    gpirt_handle_t h = nullptr;
+    int64_t n = 0, m = 0, N = GPIRT_NGRID;
+    gpirt_options opt{};
+    RStream* rs = nullptr;            // borrowed (R-stream mode)
+    // device state
+    double *y = nullptr, *Ypm = nullptr, *theta = nullptr, *theta_new = nullptr, *f = nullptr,
+           *Z = nullptr, *NU = nullptr, *beta = nullptr, *mu = nullptr, *mu_star = nullptr,
+           *fstar = nullptr, *L = nullptr, *tstar = nullptr, *kstar = nullptr, *rhs = nullptr,
+           *mean = nullptr, *s = nullptr, *Gpm = nullptr, *logpost = nullptr, *irf_sum = nullptr,
+           *pm = nullptr, *ps = nullptr, *step = nullptr;
+    int *ess_k = nullptr, *flags = nullptr;    // flags[0] = err, flags[1] = degenerate theta count
+    int *h_flags = nullptr;                    // pinned
+    // R-stream replay
+    double* U = nullptr; double* hU = nullptr; uint64_t U_cap = 0;
+    uint64_t* pos = nullptr; uint64_t* h_pos = nullptr; uint64_t* beta_off = nullptr;
+    uint64_t beta_total = 0;
+    RStream saved{};
+    bool stream_open = false;
+    // bookkeeping
+    int iter = 0;                     // completed iterations
+    bool initialised = false;
+    bool timing = false;
+    hipEvent_t ev[ST_COUNT + 1] = {};
+    double stage_ms[ST_COUNT] = {};
+    std::vector<void*> allocs;
+    std::vector<double> host_tmp;
+};
+
+namespace {
+
+template <typename T>
+int dalloc(gpirt_sampler_s* s, T** p, size_t count)
+{
+    void* q = nullptr;
+    const size_t bytes = (count ? count : 1) * sizeof(T);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        return GPIRT_E_ALLOC;
+    }
+    s->allocs.push_back(q);
+    *p = reinterpret_cast<T*>(q);
+    return 0;
+}
+
+inline bool stream_mode(const gpirt_sampler_s* s) { return s->opt.rng_kind == GPIRT_RNG_RSTREAM; }
+
+// ---- R-stream window: generate `count` uniforms ahead, upload, reset the device cursor -------
+int stream_begin(gpirt_sampler_s* s, uint64_t count)
+{
+    if (count > s->U_cap) { set_error("R-stream window %llu exceeds capacity %llu", (unsigned long long)count, (unsigned long long)s->U_cap); return GPIRT_E_RNG; }
+    s->saved = *s->rs;
+    for (uint64_t i = 0; i < count; ++i) s->hU[i] = s->rs->unif();
+    hipStream_t st = s->h->stream;
+    GP_HIP(hipMemcpyAsync(s->U, s->hU, count * sizeof(double), hipMemcpyHostToDevice, st));
+    GP_HIP(hipMemsetAsync(s->pos, 0, sizeof(uint64_t), st));
+    s->stream_open = true;
+    return 0;
+}
+
+// read back the cursor, rewind the host generator to exactly the consumed position
+int stream_end(gpirt_sampler_s* s)
+{
+    hipStream_t st = s->h->stream;
+    GP_HIP(hipMemcpyAsync(s->h_pos, s->pos, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    GP_HIP(hipMemcpyAsync(s->h_flags, s->flags, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    GP_HIP(hipStreamSynchronize(st));
+    s->stream_open = false;
+    if (s->h_flags[0] != 0) {
+        set_error(s->h_flags[0] == GPIRT_E_RNG ? "R-stream replay ran out of pre-generated uniforms"
+                                               : "elliptical slice sampler did not terminate");
+        return s->h_flags[0];
+    }
+    const uint64_t used = *s->h_pos;
+    *s->rs = s->saved;
+    for (uint64_t i = 0; i < used; ++i) (void)s->rs->next32();
+    return 0;
+}
+
+uint64_t stream_window(const gpirt_sampler_s* s)
+{
+    const uint64_t n = (uint64_t)s->n, m = (uint64_t)s->m, N = (uint64_t)s->N;
+    return m * (2 * n + 2) + 512 * m + 4096 + 2 * N * m + n + s->beta_total;
+}
+
+// thread-per-row product nu = L z (one right-hand side; R-stream replay path)
+__global__ void trmv_lower_kernel(const double* __restrict__ L, int64_t n, int64_t ldl,
+                                  const double* __restrict__ z, double* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double acc = 0.0;
+    for (int64_t k = 0; k <= i; ++k) acc += L[i + k * ldl] * z[k];
+    out[i] = acc;
+}
+
+int do_draw_f(gpirt_sampler_s* s)
+{
+    gpirt_handle_t h = s->h;
+    hipStream_t st = h->stream;
+    const int64_t n = s->n, m = s->m;
+    const uint32_t iter = (uint32_t)(s->iter + 1);
+    if (!stream_mode(s)) {
+        GP_TRY(launch_item_uniforms(st, s->opt.seed, iter, GPIRT_ST_F_Z, (uint32_t)s->opt.item0, m, n, s->Z, true));
+        GP_TRY(launch_gemm(h, st, false, false, TRI_A_LOWER, n, m, n, 1.0, s->L, n, s->Z, n, 0.0, s->NU, n));
+        EssArgs a{};
+        a.f = s->f; a.nu = s->NU; a.y = s->y; a.mu = s->mu; a.n = n; a.m = m; a.k_out = s->ess_k;
+        a.err = s->flags; a.seed = s->opt.seed; a.iter = iter; a.item0 = (uint32_t)s->opt.item0;
+        return launch_ess(st, a);
+    }
+    // exact R order: item j draws its n normals, then u, eps0 and one uniform per rejection
+    for (int64_t j = 0; j < m; ++j) {
+        GP_TRY(launch_rstream_normals(st, s->U, s->pos, 0, n, 1, s->Z));
+        hipLaunchKernelGGL(trmv_lower_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, s->L, n, n, s->Z, s->NU);
+        EssArgs a{};
+        a.f = s->f + j * n; a.nu = s->NU; a.y = s->y + j * n; a.mu = s->mu + j * n; a.n = n; a.m = 1;
+        a.k_out = s->ess_k + j; a.err = s->flags; a.item0 = (uint32_t)j;
+        a.U = s->U; a.pos = s->pos; a.cap = s->U_cap;
+        GP_TRY(launch_ess(st, a));
+    }
+    return 0;
+}
+
+int do_draw_fstar(gpirt_sampler_s* s, uint32_t iter)
+{
+    gpirt_handle_t h = s->h;
+    hipStream_t st = h->stream;
+    const int64_t n = s->n, m = s->m, N = s->N;
+    double* tmp = s->rhs;                    // n x N : L^-1 kstar
+    double* W = s->rhs + (size_t)n * N;      // n x m : L^-1 f, then L^-T L^-1 f
+    const bool fused = s->opt.fstar_fused != 0;
+    if (fused) {
+        GP_TRY(launch_se_kernel(st, s->theta, n, s->tstar, N, tmp, n, 0.0));                   // :17
+    } else {
+        GP_TRY(launch_se_kernel(st, s->theta, n, s->tstar, N, s->kstar, n, 0.0));
+        GP_HIP(hipMemcpyAsync(tmp, s->kstar, sizeof(double) * (size_t)n * N, hipMemcpyDeviceToDevice, st));
+    }
+    GP_HIP(hipMemcpyAsync(W, s->f, sizeof(double) * (size_t)n * m, hipMemcpyDeviceToDevice, st));
+    GP_TRY(launch_trsm_lower(h, st, s->L, n, n, s->rhs, N + m, n, false));                    // :19, :7 inner
+    GP_TRY(launch_colnorm_s(st, tmp, n, N, n, s->s));                                         // :20
+    if (fused) {
+        GP_TRY(launch_gemm(h, st, true, false, TRI_NONE, N, m, n, 1.0, tmp, n, W, n, 0.0, s->mean, N));
+    } else {
+        GP_TRY(launch_trsm_lower(h, st, s->L, n, n, W, m, n, true));                          // :7 outer
+        GP_TRY(launch_gemm(h, st, true, false, TRI_NONE, N, m, n, 1.0, s->kstar, n, W, n, 0.0, s->mean, N)); // :25
+    }
+    FstarEpiArgs a{};
+    a.mean = s->mean; a.mu_star = s->mu_star; a.s = s->s; a.out = s->fstar; a.N = N; a.m = m;
+    a.seed = s->opt.seed; a.iter = iter; a.item0 = (uint32_t)s->opt.item0; a.err = s->flags;
+    if (stream_mode(s)) { a.U = s->U; a.pos = s->pos; a.cap = s->U_cap; }
+    return launch_fstar_epilogue(st, a);                                                      // :26-28
+}
+
+int do_theta_partial(gpirt_sampler_s* s)
+{
+    hipStream_t st = s->h->stream;
+    const int64_t n = s->n, m = s->m, N = s->N;
+    GP_TRY(launch_loglik_terms(st, s->fstar, N, m, s->Gpm));
+    // logpost (N x n) = G+ Y+^T + G- Y-^T   (draw-theta.cpp:15-19 summed over this rank's items)
+    return launch_gemm(s->h, st, false, true, TRI_NONE, N, n, 2 * m, 1.0, s->Gpm, N, s->Ypm, n, 0.0, s->logpost, N);
+}
+
+int do_theta_finish(gpirt_sampler_s* s)
+{
+    hipStream_t st = s->h->stream;
+    ThetaArgs a{};
+    a.logpost = s->logpost; a.N = s->N; a.n = s->n; a.stabilise = s->opt.theta_stabilise;
+    a.seed = s->opt.seed; a.iter = (uint32_t)(s->iter + 1);
+    a.theta_out = s->theta; a.degenerate = s->flags + 1; a.err = s->flags;
+    if (stream_mode(s)) { a.U = s->U; a.pos = s->pos; a.cap = s->U_cap; }
+    GP_TRY(launch_theta_sample(st, a));
+    if (stream_mode(s)) GP_TRY(launch_advance_pos(st, s->pos, (uint64_t)s->n));
+    return 0;
+}
+
+int do_draw_beta(gpirt_sampler_s* s)
+{
+    hipStream_t st = s->h->stream;
+    BetaArgs a{};
+    a.beta = s->beta; a.theta = s->theta; a.y = s->y; a.f = s->f; a.pm = s->pm; a.ps = s->ps;
+    a.step = s->step; a.n = s->n; a.m = s->m; a.N = s->N; a.mu = s->mu; a.mu_star = s->mu_star;
+    a.seed = s->opt.seed; a.iter = (uint32_t)(s->iter + 1); a.item0 = (uint32_t)s->opt.item0;
+    a.err = s->flags;
+    if (stream_mode(s)) { a.U = s->U; a.pos = s->pos; a.item_off = s->beta_off; a.cap = s->U_cap; }
+    GP_TRY(launch_draw_beta(st, a));
+    if (stream_mode(s)) GP_TRY(launch_advance_pos(st, s->pos, s->beta_total));
+    return 0;
+}
+
+int do_factor(gpirt_sampler_s* s)
+{
+    hipStream_t st = s->h->stream;
+    GP_TRY(launch_se_kernel_lower(st, s->theta, s->n, s->L, s->n, GPIRT_JITTER));   // :76-77
+    return launch_potrf_lower(s->h, st, s->L, s->n, s->n, false);                  // :78
+}
+
+inline void mark(gpirt_sampler_s* s, int idx)
+{
+    if (s->timing) hipEventRecord(s->ev[idx], s->h->stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h_y, int64_t n,
+                         int64_t m, const double* h_theta0, const double* h_pm, const double* h_ps,
+                         const double* h_step, const gpirt_options* opts, gpirt_rstream_t rs)
+{
+    GP_ARG(out && h && h_y && h_theta0 && h_pm && h_ps && h_step && n > 0 && m > 0);
+    *out = nullptr;
+    gpirt_sampler_s* s = new (std::nothrow) gpirt_sampler_s();
+    if (!s) { set_error("out of host memory"); return GPIRT_E_ALLOC; }
+    s->h = h; s->n = n; s->m = m; s->N = GPIRT_NGRID;
+    if (opts) s->opt = *opts; else gpirt_default_options(&s->opt);
+    if (s->opt.m_total <= 0) s->opt.m_total = m;
+    if (stream_mode(s)) {
+        if (!rs) { set_error("GPIRT_RNG_RSTREAM needs an R stream state"); delete s; return GPIRT_E_ARG; }
+        if (s->opt.item0 != 0 || s->opt.m_total != m) {
+            set_error("R-stream replay is sequential over items and cannot be sharded"); delete s; return GPIRT_E_ARG;
+        }
+        s->rs = &rs->r;
+    }
+    const int64_t N = s->N;
+    hipStream_t st = h->stream;
+    int rc = 0;
+#define GP_A(p, cnt) do { rc = dalloc(s, &(p), (size_t)(cnt)); if (rc) { gpirt_sampler_destroy(s); return rc; } } while (0)
+    GP_A(s->y, n * m);       GP_A(s->Ypm, n * 2 * m);  GP_A(s->theta, n);       GP_A(s->theta_new, n);
+    GP_A(s->f, n * m);       GP_A(s->Z, n * m);        GP_A(s->NU, n * m);      GP_A(s->beta, 2 * m);
+    GP_A(s->mu, n * m);      GP_A(s->mu_star, N * m + 1); GP_A(s->fstar, N * m + 1); GP_A(s->L, n * n);
+    GP_A(s->tstar, N + 1);   GP_A(s->rhs, n * (N + m) + 2); GP_A(s->mean, N * m + 1); GP_A(s->s, N + 1);
+    GP_A(s->Gpm, N * 2 * m + 2); GP_A(s->logpost, N * n + 2); GP_A(s->irf_sum, N * m + 1);
+    GP_A(s->pm, 2 * m);      GP_A(s->ps, 2 * m);       GP_A(s->step, 2 * m);
+    GP_A(s->ess_k, m);       GP_A(s->flags, 4);
+    if (!s->opt.fstar_fused) GP_A(s->kstar, n * N + 2);
+    if (stream_mode(s)) {
+        // consumption of draw_beta per item: rnorm (2 unless step == 0) + runif (1), twice
+        std::vector<uint64_t> off((size_t)m);
+        uint64_t acc = 0;
+        for (int64_t j = 0; j < m; ++j) {
+            off[(size_t)j] = acc;
+            for (int k = 0; k < 2; ++k) {
+                const double sd = h_step[k + 2 * j];
+                acc += ((sd > 0.0 && std::isfinite(sd)) ? 2 : 0) + 1;
+            }
+        }
+        s->beta_total = acc;
+        s->U_cap = stream_window(s);
+        const uint64_t init_need = (uint64_t)m * 2 * (uint64_t)n + 4 * (uint64_t)m + 2 * (uint64_t)N * m + 64;
+        if (init_need > s->U_cap) s->U_cap = init_need;
+        GP_A(s->U, s->U_cap);
+        GP_A(s->pos, 2);
+        GP_A(s->beta_off, m);
+        if (hipHostMalloc(&s->hU, s->U_cap * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc(&s->h_pos, 2 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
+            set_error("pinned allocation for the R-stream window failed");
+            gpirt_sampler_destroy(s);
+            return GPIRT_E_ALLOC;
+        }
+        hipMemcpyAsync(s->beta_off, off.data(), sizeof(uint64_t) * (size_t)m, hipMemcpyHostToDevice, st);
+        hipStreamSynchronize(st);
+    }
+#undef GP_A
+    if (hipHostMalloc(&s->h_flags, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+        set_error("pinned allocation failed"); gpirt_sampler_destroy(s); return GPIRT_E_ALLOC;
+    }
+    for (int i = 0; i <= ST_COUNT; ++i) hipEventCreate(&s->ev[i]);
+    // uploads (host buffers are caller-owned and never modified: R semantics)
+    std::vector<double> ts((size_t)N);
+    for (int64_t i = 0; i < N; ++i) ts[(size_t)i] = -5.0 + (double)i * 0.01;   // src/gpirtMCMC.cpp:35
+    hipMemcpyAsync(s->y, h_y, sizeof(double) * (size_t)(n * m), hipMemcpyHostToDevice, st);
+    hipMemcpyAsync(s->theta, h_theta0, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st);
+    hipMemcpyAsync(s->pm, h_pm, sizeof(double) * (size_t)(2 * m), hipMemcpyHostToDevice, st);
+    hipMemcpyAsync(s->ps, h_ps, sizeof(double) * (size_t)(2 * m), hipMemcpyHostToDevice, st);
+    hipMemcpyAsync(s->step, h_step, sizeof(double) * (size_t)(2 * m), hipMemcpyHostToDevice, st);
+    hipMemcpyAsync(s->tstar, ts.data(), sizeof(double) * (size_t)N, hipMemcpyHostToDevice, st);
+    hipMemsetAsync(s->L, 0, sizeof(double) * (size_t)(n * n), st);         // strict upper stays zero
+    hipMemsetAsync(s->irf_sum, 0, sizeof(double) * (size_t)(N * m), st);   // :42
+    hipMemsetAsync(s->flags, 0, 4 * sizeof(int), st);
+    hipMemsetAsync(s->ess_k, 0, sizeof(int) * (size_t)m, st);
+    launch_indicators(st, s->y, n, m, s->Ypm);
+    if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) {
+        set_error("sampler upload failed"); gpirt_sampler_destroy(s); return GPIRT_E_HIP;
+    }
+    // keep pm/ps on the host for the R-stream init of beta
+    s->host_tmp.assign(h_pm, h_pm + 2 * m);
+    s->host_tmp.insert(s->host_tmp.end(), h_ps, h_ps + 2 * m);
+    *out = s;
+    return 0;
+}
+
+int gpirt_sampler_destroy(gpirt_sampler_t s)
+{
+    if (!s) return 0;
+    if (s->h) hipStreamSynchronize(s->h->stream);
+    for (void* p : s->allocs) hipFree(p);
+    if (s->hU) hipHostFree(s->hU);
+    if (s->h_pos) hipHostFree(s->h_pos);
+    if (s->h_flags) hipHostFree(s->h_flags);
+    for (int i = 0; i <= ST_COUNT; ++i) if (s->ev[i]) hipEventDestroy(s->ev[i]);
+    delete s;
+    return 0;
+}
+
+// src/gpirtMCMC.cpp:13-47
+int gpirt_sampler_init(gpirt_sampler_t s)
+{
+    GP_ARG(s != nullptr);
+    gpirt_handle_t h = s->h;
+    hipStream_t st = h->stream;
+    const int64_t n = s->n, m = s->m, N = s->N;
+    GP_TRY(do_factor(s));                                                         // :15-17
+    if (!stream_mode(s)) {
+        GP_TRY(launch_item_uniforms(st, s->opt.seed, 0, GPIRT_ST_INIT_F, (uint32_t)s->opt.item0, m, n, s->Z, true));
+        GP_TRY(launch_gemm(h, st, false, false, TRI_A_LOWER, n, m, n, 1.0, s->L, n, s->Z, n, 0.0, s->f, n)); // :18-21
+        // beta(p, j) = R::rnorm(prior_mean, prior_sd), index = p                    :22-27
+        std::vector<double> b((size_t)(2 * m));
+        const double* pm = s->host_tmp.data();
+        const double* ps = pm + 2 * m;
+        for (int64_t j = 0; j < m; ++j)
+            for (int p = 0; p < 2; ++p) {
+                const double mu = pm[p + 2 * j], sd = ps[p + 2 * j];
+                double v;
+                if (mu != mu || !std::isfinite(sd) || sd < 0.0) v = NAN;
+                else if (sd == 0.0 || !std::isfinite(mu)) v = mu;
+                else v = mu + sd * qnorm_as241(item_uniform(s->opt.seed, 0, GPIRT_ST_INIT_BETA,
+                                                            (uint32_t)(s->opt.item0 + j), (uint32_t)p));
+                b[(size_t)(p + 2 * j)] = v;
+            }
+        GP_HIP(hipMemcpyAsync(s->beta, b.data(), sizeof(double) * b.size(), hipMemcpyHostToDevice, st));
+        GP_HIP(hipStreamSynchronize(st));
+    } else {
+        // window layout: [f init: m x 2n][beta init: <= 4m][fstar: 2 N m]
+        const uint64_t nf = (uint64_t)m * 2 * (uint64_t)n;
+        // beta consumes on the host, directly behind the f-init block
+        s->saved = *s->rs;
+        for (uint64_t i = 0; i < nf; ++i) s->hU[i] = s->rs->unif();
+        std::vector<double> b((size_t)(2 * m));
+        const double* pm = s->host_tmp.data();
+        const double* ps = pm + 2 * m;
+        uint64_t nb = 0;
+        for (int64_t j = 0; j < m; ++j)
+            for (int p = 0; p < 2; ++p) {
+                const double mu = pm[p + 2 * j], sd = ps[p + 2 * j];
+                double v;
+                if (mu != mu || !std::isfinite(sd) || sd < 0.0) v = NAN;
+                else if (sd == 0.0 || !std::isfinite(mu)) v = mu;
+                else { v = mu + sd * s->rs->norm(); nb += 2; }
+                b[(size_t)(p + 2 * j)] = v;
+            }
+        const uint64_t nfs = 2 * (uint64_t)N * (uint64_t)m;
+        for (uint64_t i = 0; i < nfs; ++i) s->hU[nf + i] = s->rs->unif();
+        (void)nb;
+        GP_HIP(hipMemcpyAsync(s->U, s->hU, (nf + nfs) * sizeof(double), hipMemcpyHostToDevice, st));
+        GP_HIP(hipMemsetAsync(s->pos, 0, sizeof(uint64_t), st));
+        GP_TRY(launch_rstream_normals(st, s->U, s->pos, 2 * n, n, m, s->Z));
+        GP_TRY(launch_gemm(h, st, false, false, TRI_A_LOWER, n, m, n, 1.0, s->L, n, s->Z, n, 0.0, s->f, n));
+        GP_TRY(launch_advance_pos(st, s->pos, nf));
+        GP_HIP(hipMemcpyAsync(s->beta, b.data(), sizeof(double) * b.size(), hipMemcpyHostToDevice, st));
+        GP_HIP(hipStreamSynchronize(st));
+    }
+    GP_TRY(launch_linear_mean(st, s->theta, n, s->beta, m, s->mu));               // :30-33
+    GP_TRY(launch_linear_mean(st, s->tstar, N, s->beta, m, s->mu_star));          // :37-40
+    GP_TRY(do_draw_fstar(s, 0));                                                  // :41
+    if (stream_mode(s)) {
+        // the fstar block may have consumed fewer than 2 N m uniforms (s_i <= 0): rewind exactly
+        GP_HIP(hipMemcpyAsync(s->h_pos, s->pos, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        GP_HIP(hipStreamSynchronize(st));
+        const uint64_t nf = (uint64_t)m * 2 * (uint64_t)n;
+        const uint64_t used_fstar = *s->h_pos - nf;
+        // host state currently sits after [f][beta][2Nm]; recompute: after [f][beta] + used_fstar
+        RStream r = s->saved;
+        for (uint64_t i = 0; i < nf; ++i) (void)r.next32();
+        const double* pm = s->host_tmp.data();
+        const double* ps = pm + 2 * m;
+        for (int64_t j = 0; j < m; ++j)
+            for (int p = 0; p < 2; ++p) {
+                const double mu = pm[p + 2 * j], sd = ps[p + 2 * j];
+                if (!(mu != mu || !std::isfinite(sd) || sd < 0.0) && !(sd == 0.0 || !std::isfinite(mu))) {
+                    (void)r.next32(); (void)r.next32();
+                }
+            }
+        for (uint64_t i = 0; i < used_fstar; ++i) (void)r.next32();
+        *s->rs = r;
+    }
+    s->iter = 0;
+    s->initialised = true;
+    return 0;
+}
+
+int gpirt_sampler_draw_f(gpirt_sampler_t s) { GP_ARG(s && s->initialised); return do_draw_f(s); }
+int gpirt_sampler_draw_fstar(gpirt_sampler_t s) { GP_ARG(s && s->initialised); return do_draw_fstar(s, (uint32_t)(s->iter + 1)); }
+int gpirt_sampler_theta_partial(gpirt_sampler_t s) { GP_ARG(s && s->initialised); return do_theta_partial(s); }
+int gpirt_sampler_theta_finish(gpirt_sampler_t s) { GP_ARG(s && s->initialised); return do_theta_finish(s); }
+int gpirt_sampler_draw_beta(gpirt_sampler_t s) { GP_ARG(s && s->initialised); return do_draw_beta(s); }
+int gpirt_sampler_factor(gpirt_sampler_t s)
+{
+    GP_ARG(s && s->initialised);
+    GP_TRY(do_factor(s));
+    s->iter += 1;            // the factorisation closes an iteration (src/gpirtMCMC.cpp:78,97)
+    return 0;
+}
+
+int gpirt_sampler_step(gpirt_sampler_t s)
+{
+    GP_ARG(s && s->initialised);
+    if (stream_mode(s)) GP_TRY(stream_begin(s, stream_window(s)));
+    mark(s, 0);
+    GP_TRY(do_draw_f(s));            mark(s, 1);
+    GP_TRY(do_draw_fstar(s, (uint32_t)(s->iter + 1))); mark(s, 2);
+    GP_TRY(do_theta_partial(s));     mark(s, 3);
+    GP_TRY(do_theta_finish(s));      mark(s, 4);
+    GP_TRY(do_draw_beta(s));         mark(s, 5);
+    GP_TRY(do_factor(s));            mark(s, 6);
+    s->iter += 1;
+    if (stream_mode(s)) GP_TRY(stream_end(s));
+    if (s->timing) {
+        GP_HIP(hipEventSynchronize(s->ev[ST_COUNT]));
+        for (int i = 0; i < ST_COUNT; ++i) {
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, s->ev[i], s->ev[i + 1]);
+            s->stage_ms[i] = ms;
+        }
+    }
+    return 0;
+}
+
+int gpirt_sampler_accumulate_irf(gpirt_sampler_t s)
+{
+    GP_ARG(s && s->initialised);
+    return launch_axpy_irf(s->h->stream, s->irf_sum, s->fstar, s->N * s->m);     // :103
+}
+
+int gpirt_sampler_iteration(gpirt_sampler_t s, int* iter)
+{
+    GP_ARG(s && iter);
+    *iter = s->iter;
+    return 0;
+}
+
+int gpirt_sampler_check(gpirt_sampler_t s)
+{
+    GP_ARG(s != nullptr);
+    gpirt_handle_t h = s->h;
+    hipStream_t st = h->stream;
+    GP_HIP(hipMemcpyAsync(h->h_info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, st));
+    GP_HIP(hipMemcpyAsync(s->h_flags, s->flags, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    GP_HIP(hipStreamSynchronize(st));
+    if (*h->h_info > 0) {
+        set_error("chol(): decomposition failed (leading minor of order %d is not positive definite)", *h->h_info);
+        return *h->h_info;
+    }
+    if (s->h_flags[0] != 0) {
+        set_error("sampler state is not finite (flag %d): elliptical slice sampler did not terminate or the R stream window overflowed", s->h_flags[0]);
+        return s->h_flags[0];
+    }
+    return 0;
+}
+
+static int lookup(gpirt_sampler_t s, const char* name, void** p, int64_t* count)
+{
+    const int64_t n = s->n, m = s->m, N = s->N;
+    struct E { const char* k; void* p; int64_t c; } tab[] = {
+        { "theta", s->theta, n }, { "f", s->f, n * m }, { "beta", s->beta, 2 * m }, { "mu", s->mu, n * m },
+        { "mu_star", s->mu_star, N * m }, { "fstar", s->fstar, N * m }, { "L", s->L, n * n },
+        { "logpost", s->logpost, N * n }, { "irf_sum", s->irf_sum, N * m }, { "ess_k", s->ess_k, m },
+        { "s", s->s, N }, { "mean", s->mean, N * m }, { "nu", s->NU, n * m }, { "z", s->Z, n * m },
+        { "y", s->y, n * m },
+    };
+    for (auto& e : tab)
+        if (strcmp(e.k, name) == 0) { *p = e.p; *count = e.c; return 0; }
+    set_error("unknown sampler array '%s'", name);
+    return GPIRT_E_ARG;
+}
+
+int gpirt_sampler_devptr(gpirt_sampler_t s, const char* name, void** d_ptr, int64_t* count)
+{
+    GP_ARG(s && name && d_ptr && count);
+    return lookup(s, name, d_ptr, count);
+}
+
+int gpirt_sampler_get(gpirt_sampler_t s, const char* name, double* h_out, int64_t count)
+{
+    GP_ARG(s && name && h_out);
+    void* p; int64_t c;
+    GP_TRY(lookup(s, name, &p, &c));
+    GP_ARG(count <= c);
+    const size_t esz = strcmp(name, "ess_k") == 0 ? sizeof(int) : sizeof(double);
+    GP_HIP(hipMemcpyAsync(h_out, p, esz * (size_t)count, hipMemcpyDeviceToHost, s->h->stream));
+    GP_HIP(hipStreamSynchronize(s->h->stream));
+    return 0;
+}
+
+int gpirt_sampler_set(gpirt_sampler_t s, const char* name, const double* h_in, int64_t count)
+{
+    GP_ARG(s && name && h_in);
+    void* p; int64_t c;
+    GP_TRY(lookup(s, name, &p, &c));
+    GP_ARG(count <= c && strcmp(name, "ess_k") != 0);
+    GP_HIP(hipMemcpyAsync(p, h_in, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, s->h->stream));
+    GP_HIP(hipStreamSynchronize(s->h->stream));
+    return 0;
+}
+
+// IRFs *= 1/S ; plogis : src/gpirtMCMC.cpp:106-111 (Q7: S = 0 gives NaN, as in the reference)
+int gpirt_sampler_finish_irfs(gpirt_sampler_t s, int sample_iterations, double* h_irfs)
+{
+    GP_ARG(s && h_irfs);
+    const int64_t cnt = s->N * s->m;
+    GP_HIP(hipMemcpyAsync(h_irfs, s->irf_sum, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost, s->h->stream));
+    GP_HIP(hipStreamSynchronize(s->h->stream));
+    const double inv = 1.0 / (double)sample_iterations;
+    for (int64_t i = 0; i < cnt; ++i) h_irfs[i] = 1.0 / (1.0 + exp(-(h_irfs[i] * inv)));
+    return 0;
+}
+
+int gpirt_sampler_enable_timing(gpirt_sampler_t s, int on)
+{
+    GP_ARG(s != nullptr);
+    s->timing = on != 0;
+    return 0;
+}
+
+int gpirt_sampler_stage_times(gpirt_sampler_t s, double* ms_out, int max_stages, int* n_stages,
+                              const char** names_out)
+{
+    GP_ARG(s && ms_out && n_stages);
+    static const char names[] = "draw_f\0draw_fstar\0theta_gemm\0theta_sample\0draw_beta\0factor\0";
+    const int k = max_stages < ST_COUNT ? max_stages : ST_COUNT;
+    for (int i = 0; i < k; ++i) ms_out[i] = s->stage_ms[i];
+    *n_stages = k;
+    if (names_out) *names_out = names;
+    (void)kStageNames;
+    return 0;
+}
+
+// Whole-call drop-in: src/gpirtMCMC.cpp:5-117 behind src/RcppExports.cpp:16-30.
+int gpirt_mcmc(const double* h_y, int64_t n, int64_t m, const double* h_theta0, int S_it, int B_it,
+               const double* h_pm, const double* h_ps, const double* h_step, const gpirt_options* opts,
+               gpirt_rstream_t rs, gpirt_tick_fn tick, void* tick_ctx, double* h_theta_draws,
+               double* h_beta_draws, double* h_f_draws, double* h_irfs)
+{
+    GP_ARG(h_y && h_theta0 && h_pm && h_ps && h_step && h_theta_draws && h_beta_draws && h_f_draws && h_irfs);
+    GP_ARG(n > 0 && m > 0 && S_it >= 0 && B_it >= 0);
+    gpirt_options o;
+    if (opts) o = *opts; else gpirt_default_options(&o);
+    gpirt_handle_t h = nullptr;
+    GP_TRY(gpirt_create_own_stream(&h, o.device));
+    gpirt_sampler_t s = nullptr;
+    int rc = gpirt_sampler_create(&s, h, h_y, n, m, h_theta0, h_pm, h_ps, h_step, &o, rs);
+    if (rc) { gpirt_destroy(h); return rc; }
+    std::vector<double> th((size_t)n);
+    auto store = [&](int slot) -> int {
+        // theta_draws.row(slot), beta_draws.slice(slot), f_draws.slice(slot): :53-55, :99-101
+        GP_TRY(gpirt_sampler_get(s, "theta", th.data(), n));
+        for (int64_t i = 0; i < n; ++i) h_theta_draws[slot + i * (int64_t)(S_it + 1)] = th[(size_t)i];
+        GP_TRY(gpirt_sampler_get(s, "beta", h_beta_draws + (int64_t)slot * 2 * m, 2 * m));
+        GP_TRY(gpirt_sampler_get(s, "f", h_f_draws + (int64_t)slot * n * m, n * m));
+        return 0;
+    };
+    const int total = S_it + B_it;
+    rc = gpirt_sampler_init(s);
+    if (!rc) rc = gpirt_sampler_check(s);
+    if (!rc) rc = store(0);
+    for (int it = 0; it < total && !rc; ++it) {
+        if (tick && tick(tick_ctx, it, total)) { set_error("interrupted"); rc = GPIRT_E_INTERRUPT; break; }
+        rc = gpirt_sampler_step(s);
+        if (!rc) rc = gpirt_sampler_check(s);
+        if (!rc && it >= B_it) {
+            rc = store(it - B_it + 1);
+            if (!rc) rc = gpirt_sampler_accumulate_irf(s);
+        }
+    }
+    if (!rc) rc = gpirt_sampler_finish_irfs(s, S_it, h_irfs);
+    gpirt_sampler_destroy(s);
+    gpirt_destroy(h);
+    return rc;
+}
+
+}  // extern "C"

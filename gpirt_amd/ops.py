@@ -1,0 +1,255 @@
+"""Operator-level host API over the C ABI (device tensors in, device tensors out).
+
+Mirrors the reference's internal operator interface, src/gpirt.h:4-28 -- K(), draw_f(),
+draw_fstar(), draw_theta(), draw_beta(), ll_bar() -- plus the LAPACK/BLAS-level pieces the
+reference reaches through Armadillo (chol, solve(trimatl/trimatu), cholS * z).  torch is used only
+for device memory and the stream; all arithmetic happens in libgpirt_hip.so.
+
+Matrices are COLUMN-MAJOR fp64 (Armadillo / R layout): an n x m matrix is a torch tensor of shape
+(n, m) with strides (1, ld).  Use `colmajor()` / `to_device()` to make them.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import NGRID, check
+
+
+def colmajor(n: int, m: int, device="cuda", fill=None) -> torch.Tensor:
+    """Uninitialised (or filled) column-major n x m fp64 device matrix."""
+    base = torch.empty((m, n), dtype=torch.float64, device=device)
+    if fill is not None:
+        base.fill_(fill)
+    return base.T
+
+
+def to_device(a, device="cuda") -> torch.Tensor:
+    """Host array -> column-major device tensor (vectors stay 1-d)."""
+    a = np.asarray(a, dtype=np.float64)
+    if a.ndim == 1:
+        return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    if a.ndim != 2:
+        raise ValueError("expected a vector or a matrix")
+    return torch.from_numpy(np.ascontiguousarray(a.T)).to(device).T
+
+
+def to_host(t: torch.Tensor) -> np.ndarray:
+    """Device tensor -> Fortran-ordered numpy array."""
+    if t.dim() == 2:
+        return np.asfortranarray(t.T.contiguous().cpu().numpy().T)
+    return t.cpu().numpy()
+
+
+def _ld(t: torch.Tensor) -> int:
+    if t.dtype != torch.float64 or not t.is_cuda:
+        raise TypeError("expected a float64 device tensor")
+    if t.dim() == 1:
+        if t.stride(0) != 1:
+            raise ValueError("vector must be contiguous")
+        return t.shape[0]
+    if t.dim() != 2 or (t.shape[0] > 1 and t.stride(0) != 1):
+        raise ValueError("matrix must be column-major (stride(0) == 1)")
+    ld = t.stride(1) if t.shape[1] > 1 else max(t.shape[0], 1)
+    if ld < t.shape[0]:
+        raise ValueError("bad leading dimension")
+    return ld
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Handle:
+    """gpirt_handle_t bound to a device and (by default) torch's current stream."""
+
+    def __init__(self, device: int | None = None, stream: torch.cuda.Stream | None = None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.GpirtError(_lib.E_NODEVICE, "no GPU visible: the HIP path has no CPU fallback")
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = device
+        with torch.cuda.device(device):
+            self.stream = stream if stream is not None else torch.cuda.current_stream()
+            h = C.c_void_p()
+            check(self.lib.gpirt_create(C.byref(h), device, C.c_void_p(self.stream.cuda_stream)))
+        self._h = h
+
+    @property
+    def ptr(self):
+        return self._h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.gpirt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(self.lib.gpirt_synchronize(self._h))
+
+    def calibrate_mfma_f64(self) -> float:
+        v = C.c_double()
+        check(self.lib.gpirt_calibrate_mfma_f64(self._h, C.byref(v)))
+        return v.value
+
+    # ---------------------------------------------------------------- operators
+    def se_kernel(self, x1: torch.Tensor, x2: torch.Tensor, jitter: float = 0.0) -> torch.Tensor:
+        """K(x1, x2): src/covariance-function.cpp:3-14 (+ jitter on i == j)."""
+        out = colmajor(x1.shape[0], x2.shape[0], x1.device)
+        check(self.lib.gpirt_se_kernel(self._h, _p(x1), x1.shape[0], _p(x2), x2.shape[0], _p(out), _ld(out), jitter))
+        return out
+
+    def potrf_lower(self, S: torch.Tensor) -> torch.Tensor:
+        """arma::chol(S, "lower") in place; raises like the reference when S is not PD."""
+        n = S.shape[0]
+        info = self.lib.gpirt_potrf_lower(self._h, _p(S), n, _ld(S))
+        if info > 0:
+            raise RuntimeError("chol(): decomposition failed (leading minor %d)" % info)
+        check(info)
+        return S
+
+    def factor(self, theta: torch.Tensor) -> torch.Tensor:
+        """K(theta,theta) + 0.001 I -> lower Cholesky factor (src/gpirtMCMC.cpp:15-17)."""
+        n = theta.shape[0]
+        L = colmajor(n, n, theta.device)
+        info = self.lib.gpirt_factor(self._h, _p(theta), n, _p(L), _ld(L))
+        if info > 0:
+            raise RuntimeError("chol(): decomposition failed (leading minor %d)" % info)
+        check(info)
+        return L
+
+    def trmm_lz(self, L: torch.Tensor, Z: torch.Tensor) -> torch.Tensor:
+        """rmvnorm()'s cholS * res for all columns (src/mvnormal.h:10)."""
+        n, m = Z.shape
+        out = colmajor(n, m, Z.device)
+        check(self.lib.gpirt_trmm_lz(self._h, _p(L), n, _ld(L), _p(Z), m, _ld(Z), _p(out), _ld(out)))
+        return out
+
+    def trsm_lower(self, L: torch.Tensor, B: torch.Tensor, trans: bool = False) -> torch.Tensor:
+        """solve(trimatl(L), B) / solve(trimatu(L.t()), B) in place (src/draw-fstar.cpp:7,19)."""
+        n, nrhs = B.shape
+        check(self.lib.gpirt_trsm_lower(self._h, _p(L), n, _ld(L), _p(B), nrhs, _ld(B), int(trans)))
+        return B
+
+    def gemm(self, A, B, ta=False, tb=False, alpha=1.0, beta=0.0, C_out=None):
+        M = A.shape[1] if ta else A.shape[0]
+        K = A.shape[0] if ta else A.shape[1]
+        N = B.shape[0] if tb else B.shape[1]
+        if C_out is None:
+            C_out = colmajor(M, N, A.device, fill=0.0 if beta != 0.0 else None)
+        check(self.lib.gpirt_gemm(self._h, int(ta), int(tb), M, N, K, alpha, _p(A), _ld(A), _p(B), _ld(B),
+                                  beta, _p(C_out), _ld(C_out)))
+        return C_out
+
+    def ll_bar(self, f, y, mu=None) -> torch.Tensor:
+        """ll_bar() / ll() per column: src/log-likelihood.cpp:12-37."""
+        n, m = f.shape
+        out = torch.empty(m, dtype=torch.float64, device=f.device)
+        check(self.lib.gpirt_ll_bar(self._h, _p(f), _p(y), _p(mu), n, m, _p(out)))
+        return out
+
+    def item_normals(self, seed, it, stage, item0, n_items, n_index) -> torch.Tensor:
+        out = colmajor(n_index, n_items)
+        check(self.lib.gpirt_item_normals(self._h, seed, it, stage, item0, n_items, n_index, _p(out)))
+        return out
+
+    def item_uniforms(self, seed, it, stage, item0, n_items, n_index) -> torch.Tensor:
+        out = colmajor(n_index, n_items)
+        check(self.lib.gpirt_item_uniforms(self._h, seed, it, stage, item0, n_items, n_index, _p(out)))
+        return out
+
+    def draw_f(self, f, y, L, mu, seed: int, it: int):
+        """draw_f(): src/draw-f.cpp:64-73 (item RNG).  In place on f; returns (f, rejections)."""
+        n, m = f.shape
+        k = torch.zeros(m, dtype=torch.int32, device=f.device)
+        check(self.lib.gpirt_draw_f(self._h, _p(f), _p(y), _p(L), _ld(L), _p(mu), n, m, seed, it, _p(k)))
+        return f, k
+
+    def draw_fstar(self, f, theta, L, mu_star, seed: int, it: int, fused: bool = False):
+        """draw_fstar(): src/draw-fstar.cpp:10-31 (item RNG).  Returns (fstar, s, mean)."""
+        n, m = f.shape
+        out = colmajor(NGRID, m, f.device)
+        s = torch.empty(NGRID, dtype=torch.float64, device=f.device)
+        mean = colmajor(NGRID, m, f.device)
+        check(self.lib.gpirt_draw_fstar(self._h, _p(f), _p(theta), _p(L), _ld(L), _p(mu_star), n, m, seed, it,
+                                        int(fused), _p(out), _p(s), _p(mean)))
+        return out, s, mean
+
+    def draw_theta(self, y, fstar, seed: int, it: int, stabilise: bool = True):
+        """draw_theta(): src/draw-theta.cpp:3-37 (item RNG).  Returns (theta, n_degenerate)."""
+        n, m = y.shape
+        out = torch.empty(n, dtype=torch.float64, device=y.device)
+        deg = torch.zeros(1, dtype=torch.int32, device=y.device)
+        check(self.lib.gpirt_draw_theta(self._h, _p(y), _p(fstar), n, m, seed, it, int(stabilise), _p(out), _p(deg)))
+        return out, int(deg.item())
+
+    def draw_beta(self, beta, theta, y, f, pm, ps, step, seed: int, it: int):
+        """draw_beta(): src/draw-beta.cpp:3-41 (item RNG).  In place on beta (2 x m)."""
+        n, m = y.shape
+        check(self.lib.gpirt_draw_beta(self._h, _p(beta), _p(theta), _p(y), _p(f), _p(pm), _p(ps), _p(step),
+                                       n, m, seed, it))
+        return beta
+
+    # ---------------------------------------------------------------- profiling
+    def prof_enable(self, on: bool):
+        check(self.lib.gpirt_prof_enable(self._h, int(on)))
+
+    def prof_trailing(self, reset: bool = False):
+        ms = C.c_double()
+        n = C.c_int64()
+        fl = C.c_double()
+        check(self.lib.gpirt_prof_trailing(self._h, int(reset), C.byref(ms), C.byref(n), C.byref(fl)))
+        return ms.value, n.value, fl.value
+
+
+class RStream:
+    """R's default RNG on the host: RStream(seed) == set.seed(seed); .rnorm(n) == rnorm(n)."""
+
+    def __init__(self, seed: int | None = None, state=None):
+        self.lib = _lib.load()
+        r = C.c_void_p()
+        if state is not None:
+            mt, mti = state
+            arr = (C.c_uint32 * 624)(*[int(x) for x in mt])
+            check(self.lib.gpirt_rstream_from_state(C.byref(r), arr, int(mti)))
+        else:
+            check(self.lib.gpirt_rstream_create(C.byref(r), C.c_uint32(int(seed) & 0xFFFFFFFF)))
+        self._r = r
+
+    @property
+    def ptr(self):
+        return self._r
+
+    def runif(self, n: int) -> np.ndarray:
+        out = np.empty(n)
+        check(self.lib.gpirt_rstream_unif(self._r, out.ctypes.data_as(C.POINTER(C.c_double)), n))
+        return out
+
+    def rnorm(self, n: int) -> np.ndarray:
+        out = np.empty(n)
+        check(self.lib.gpirt_rstream_norm(self._r, out.ctypes.data_as(C.POINTER(C.c_double)), n))
+        return out
+
+    def state(self):
+        mt = (C.c_uint32 * 624)()
+        mti = C.c_int()
+        check(self.lib.gpirt_rstream_get_state(self._r, mt, C.byref(mti)))
+        return np.array(mt, dtype=np.uint32), mti.value
+
+    def __del__(self):
+        try:
+            if self._r:
+                self.lib.gpirt_rstream_destroy(self._r)
+                self._r = None
+        except Exception:
+            pass

@@ -1,0 +1,210 @@
+"""Sampler-level host API: the gpirtMCMC() mirror and the stage-driven Sampler.
+
+`gpirtMCMC()` keeps the reference's R signature and returned list (R/gpirtMCMC.R:85-105,
+src/gpirtMCMC.cpp:112-116); it prepares the data exactly like the R wrapper and then crosses the
+same boundary the R shim would (.Call -> extern "C" gpirt_mcmc, include/gpirt_hip.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import NGRID, RNG_ITEM, RNG_RSTREAM, Options, check
+from .response_matrix import as_response_matrix
+
+_dp = C.POINTER(C.c_double)
+
+
+def _f64(a):
+    return np.asfortranarray(np.array(a, dtype=np.float64))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _options(rng, seed, theta_stabilise, fstar_fused, device, item0=0, m_total=0) -> Options:
+    o = _lib.default_options()
+    o.rng_kind = RNG_RSTREAM if rng == "reference" else RNG_ITEM
+    o.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    o.theta_stabilise = int(bool(theta_stabilise))
+    o.fstar_fused = int(bool(fstar_fused))
+    o.device = -1 if device is None else int(device)
+    o.item0 = int(item0)
+    o.m_total = int(m_total)
+    return o
+
+
+def gpirtMCMC(data, sample_iterations, burn_iterations, vote_codes=None, beta_prior_means=None,
+              beta_prior_sds=None, beta_proposal_sds=None, theta_init=None, *, rng="reference",
+              seed=1, rstream=None, theta_stabilise=False, fstar_fused=False, device=None, progress=False):
+    """Drop-in for the reference's gpirtMCMC() (R/gpirtMCMC.R:85-105) on one MI355X.
+
+    Positional arguments, defaults and the returned dict (theta (S+1) x n, beta 2 x m x (S+1),
+    f n x m x (S+1), IRFs 1001 x m) follow the reference.  Keyword-only extras select the RNG
+    contract instead of new required arguments:
+      rng="reference": replay R's Mersenne-Twister stream (`rstream`, or RStream(seed), stands in
+                       for R's .Random.seed); draw-for-draw comparable with the reference;
+      rng="item":      counter-based per-item sub-streams keyed by `seed` (batched, shardable).
+    """
+    from .ops import RStream
+
+    lib = _lib.load()
+    data = as_response_matrix(data, vote_codes)                      # R/gpirtMCMC.R:93
+    y = _f64(np.asarray(data))
+    n, m = y.shape
+    # defaults are evaluated AFTER the unanimous items were dropped (R lazy evaluation, quirk Q8)
+    pm = _f64(np.zeros((2, m)) if beta_prior_means is None else beta_prior_means)
+    ps = _f64(np.full((2, m), 3.0) if beta_prior_sds is None else beta_prior_sds)
+    st = _f64(np.full((2, m), 0.1) if beta_proposal_sds is None else beta_proposal_sds)
+    for a in (pm, ps, st):
+        if a.shape != (2, m):
+            raise ValueError("beta prior / proposal matrices must be 2 x ncol(data)")
+    rs = None
+    if rng == "reference":
+        rs = rstream if rstream is not None else RStream(seed)
+    if theta_init is None:                                           # R/gpirtMCMC.R:95-97
+        if rs is not None:
+            theta_init = rs.rnorm(n)
+        else:
+            theta_init = RStream(seed).rnorm(n)
+    theta0 = np.ascontiguousarray(theta_init, dtype=np.float64)
+    if theta0.shape != (n,):
+        raise ValueError("theta_init must have one value per respondent")
+    S, B = int(sample_iterations), int(burn_iterations)
+    th = np.empty((S + 1, n), order="F")
+    be = np.empty((2, m, S + 1), order="F")
+    ff = np.empty((n, m, S + 1), order="F")
+    irf = np.empty((NGRID, m), order="F")
+    o = _options(rng, seed, theta_stabilise, fstar_fused, device)
+
+    def _tick(ctx, it, total):                                       # src/gpirtMCMC.cpp:64-66
+        if progress:
+            print("\r%6.3f %% complete" % (100.0 * it / max(total, 1)), end="", flush=True)
+        return 0
+
+    cb = _lib.TICK_FN(_tick)
+    rc = lib.gpirt_mcmc(_ptr(y), n, m, _ptr(theta0), S, B, _ptr(pm), _ptr(ps), _ptr(st), C.byref(o),
+                        rs.ptr if rs is not None else None, cb, None, _ptr(th), _ptr(be), _ptr(ff), _ptr(irf))
+    if progress:
+        print("\r100.000 % complete")
+    if rc > 0:
+        raise RuntimeError("chol(): decomposition failed")           # what arma::chol throws
+    check(rc)
+    return dict(theta=th, beta=be, f=ff, IRFs=irf)
+
+
+class Sampler:
+    """Stage-driven sampler (gpirt_sampler_*): device-resident state, one iteration per step()."""
+
+    def __init__(self, handle, y, theta_init, beta_prior_means=None, beta_prior_sds=None,
+                 beta_proposal_sds=None, *, rng="item", seed=1, rstream=None, theta_stabilise=True,
+                 fstar_fused=False, item0=0, m_total=0):
+        self.lib = _lib.load()
+        self.handle = handle
+        y = _f64(y)
+        self.n, self.m = y.shape
+        m = self.m
+        pm = _f64(np.zeros((2, m)) if beta_prior_means is None else beta_prior_means)
+        ps = _f64(np.full((2, m), 3.0) if beta_prior_sds is None else beta_prior_sds)
+        st = _f64(np.full((2, m), 0.1) if beta_proposal_sds is None else beta_proposal_sds)
+        theta0 = np.ascontiguousarray(theta_init, dtype=np.float64)
+        self.rs = rstream
+        o = _options(rng, seed, theta_stabilise, fstar_fused, handle.device, item0, m_total)
+        s = C.c_void_p()
+        check(self.lib.gpirt_sampler_create(C.byref(s), handle.ptr, _ptr(y), self.n, m, _ptr(theta0), _ptr(pm),
+                                            _ptr(ps), _ptr(st), C.byref(o),
+                                            rstream.ptr if rstream is not None else None))
+        self._s = s
+
+    def close(self):
+        if getattr(self, "_s", None):
+            self.lib.gpirt_sampler_destroy(self._s)
+            self._s = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _call(self, name):
+        rc = getattr(self.lib, name)(self._s)
+        if rc > 0:
+            raise RuntimeError("chol(): decomposition failed (leading minor %d)" % rc)
+        check(rc)
+
+    def init(self): self._call("gpirt_sampler_init")
+    def step(self): self._call("gpirt_sampler_step")
+    def draw_f(self): self._call("gpirt_sampler_draw_f")
+    def draw_fstar(self): self._call("gpirt_sampler_draw_fstar")
+    def theta_partial(self): self._call("gpirt_sampler_theta_partial")
+    def theta_finish(self): self._call("gpirt_sampler_theta_finish")
+    def draw_beta(self): self._call("gpirt_sampler_draw_beta")
+    def factor(self): self._call("gpirt_sampler_factor")
+    def accumulate_irf(self): self._call("gpirt_sampler_accumulate_irf")
+    def check(self): self._call("gpirt_sampler_check")
+
+    @property
+    def iteration(self) -> int:
+        it = C.c_int()
+        check(self.lib.gpirt_sampler_iteration(self._s, C.byref(it)))
+        return it.value
+
+    _SHAPES = {"theta": "n", "f": "nm", "beta": "2m", "mu": "nm", "mu_star": "Nm", "fstar": "Nm", "L": "nn",
+               "logpost": "Nn", "irf_sum": "Nm", "s": "N", "mean": "Nm", "nu": "nm", "z": "nm", "y": "nm"}
+
+    def _shape(self, name):
+        n, m, N = self.n, self.m, NGRID
+        return {"n": (n,), "nm": (n, m), "2m": (2, m), "Nm": (N, m), "nn": (n, n), "Nn": (N, n), "N": (N,)}[
+            self._SHAPES[name]]
+
+    def get(self, name: str) -> np.ndarray:
+        if name == "ess_k":
+            out = np.empty(self.m, dtype=np.int32)
+            check(self.lib.gpirt_sampler_get(self._s, b"ess_k", C.c_void_p(out.ctypes.data), self.m))
+            return out
+        shape = self._shape(name)
+        out = np.empty(shape, order="F")
+        check(self.lib.gpirt_sampler_get(self._s, name.encode(), C.c_void_p(out.ctypes.data), out.size))
+        return out
+
+    def set(self, name: str, value):
+        v = _f64(value)
+        check(self.lib.gpirt_sampler_set(self._s, name.encode(), _ptr(v), v.size))
+
+    def devptr(self, name: str):
+        p = C.c_void_p()
+        cnt = C.c_int64()
+        check(self.lib.gpirt_sampler_devptr(self._s, name.encode(), C.byref(p), C.byref(cnt)))
+        return p.value, cnt.value
+
+    def device_tensor(self, name: str):
+        """Zero-copy torch view of a state array (used to hand buffers to torch.distributed)."""
+        import torch
+
+        ptr, cnt = self.devptr(name)
+
+        class _Wrap:
+            pass
+
+        w = _Wrap()
+        w.__cuda_array_interface__ = {"shape": (cnt,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+        return torch.as_tensor(w, device=f"cuda:{self.handle.device}")
+
+    def finish_irfs(self, sample_iterations: int) -> np.ndarray:
+        out = np.empty((NGRID, self.m), order="F")
+        check(self.lib.gpirt_sampler_finish_irfs(self._s, int(sample_iterations), _ptr(out)))
+        return out
+
+    def enable_timing(self, on=True):
+        check(self.lib.gpirt_sampler_enable_timing(self._s, int(on)))
+
+    def stage_times(self) -> dict:
+        ms = (C.c_double * 16)()
+        k = C.c_int()
+        check(self.lib.gpirt_sampler_stage_times(self._s, ms, 16, C.byref(k), None))
+        names = ["draw_f", "draw_fstar", "theta_gemm", "theta_sample", "draw_beta", "factor"]
+        return {names[i]: ms[i] for i in range(k.value)}

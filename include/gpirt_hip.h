@@ -1,0 +1,230 @@
+/*
+ * gpirt_hip.h -- C ABI of libgpirt_hip.so: the MI355X (gfx950) implementation of the per-iteration
+ * GP linear algebra of duckmayr/gpirt's gpirtMCMC(), behind the reference's own boundary.
+ *
+ * Boundary being replaced (paths relative to the upstream repository):
+ *   R/RcppExports.R:4-6      .Call(`_gpirt_gpirtMCMC`, y, theta, S, B, prior_means, prior_sds, steps)
+ *   src/RcppExports.cpp:16-30  SEXP _gpirt_gpirtMCMC(SEXP x 7)  (Rcpp glue, RNGScope, BEGIN/END_RCPP)
+ *   src/gpirtMCMC.cpp:5-9    Rcpp::List gpirtMCMC(const arma::mat& y, arma::vec theta, int, int, ...)
+ *   src/gpirt.h:4-28         internal prototypes K / draw_f / draw_fstar / draw_theta / draw_beta / ll_bar
+ *
+ * Conventions: plain pointers and sizes only; every matrix is column-major fp64 (Armadillo / R
+ * layout); y holds -1 / +1 / NaN; int64_t sizes; `void* stream` is a hipStream_t (NULL = the
+ * handle's stream).  Pointers named d_* are DEVICE pointers, h_* are HOST pointers.
+ * Every function returns 0 on success; >0 = LAPACK-style potrf info (order of the leading minor
+ * that is not positive definite -- what makes arma::chol throw "decomposition failed",
+ * src/gpirtMCMC.cpp:17); <0 = GPIRT_E_* .  gpirt_last_error() describes the last failure of the
+ * calling thread.  No function throws across the boundary.
+ *
+ * The library has NO CPU fallback: without a usable gfx950 device every compute entry fails with
+ * GPIRT_E_NODEVICE.
+ */
+#ifndef GPIRT_HIP_H
+#define GPIRT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPIRT_NGRID 1001           /* theta_star = regspace(-5, 0.01, 5): src/gpirtMCMC.cpp:35 */
+#define GPIRT_JITTER 0.001         /* S.diag() += 0.001: src/gpirtMCMC.cpp:16,77,96 */
+
+enum {
+    GPIRT_OK          = 0,
+    GPIRT_E_ARG       = -1,   /* bad argument (NULL pointer, negative size, ...) */
+    GPIRT_E_HIP       = -2,   /* a HIP runtime call failed */
+    GPIRT_E_NODEVICE  = -3,   /* no gfx950 device visible */
+    GPIRT_E_ALLOC     = -4,   /* device or host allocation failed */
+    GPIRT_E_RNG       = -5,   /* R-stream replay ran out of pre-generated uniforms */
+    GPIRT_E_INTERRUPT = -6,   /* the tick callback asked to stop */
+    GPIRT_E_NUMERIC   = -7    /* non-finite state (e.g. ESS did not terminate) */
+};
+
+/* RNG contracts:
+ *  GPIRT_RNG_RSTREAM  exact replay of R's Mersenne-Twister/inversion stream in the reference's
+ *                     consumption order (item-sequential draw_f);
+ *  GPIRT_RNG_ITEM     counter-based Philox4x32-10 sub-streams keyed by (seed, iteration, stage,
+ *                     item): same algorithm, items independent, batched trmm legal. */
+enum { GPIRT_RNG_RSTREAM = 0, GPIRT_RNG_ITEM = 1 };
+
+/* stage ids of the GPIRT_RNG_ITEM contract */
+enum {
+    GPIRT_ST_INIT_F = 1, GPIRT_ST_INIT_BETA = 2, GPIRT_ST_F_Z = 3, GPIRT_ST_F_ESS = 4,
+    GPIRT_ST_FSTAR = 5, GPIRT_ST_THETA = 6, GPIRT_ST_BETA = 7
+};
+
+typedef struct gpirt_handle_s*  gpirt_handle_t;
+typedef struct gpirt_sampler_s* gpirt_sampler_t;
+
+/* ---------------------------------------------------------------- library / handle ------ */
+int         gpirt_version(void);
+const char* gpirt_last_error(void);
+int         gpirt_device_count(int* count);
+/* device < 0: current device.  stream is a hipStream_t; NULL is HIP's default (null) stream. */
+int         gpirt_create(gpirt_handle_t* h, int device, void* stream);
+/* same, but the handle creates and owns a non-blocking stream of its own */
+int         gpirt_create_own_stream(gpirt_handle_t* h, int device);
+int         gpirt_destroy(gpirt_handle_t h);
+int         gpirt_synchronize(gpirt_handle_t h);
+int         gpirt_set_stream(gpirt_handle_t h, void* stream);
+/* Peak fp64 MFMA rate of this device measured by a back-to-back v_mfma_f64_16x16x4_f64 loop
+ * (TFLOP/s); used to calibrate the roofline. */
+int         gpirt_calibrate_mfma_f64(gpirt_handle_t h, double* tflops);
+
+/* ---------------------------------------------------------------- operators ------------- */
+/* K(): src/covariance-function.cpp:3-14.  d_out (n1 x n2, leading dimension ld) =
+ * exp(-0.5 (x1_i - x2_j)^2); `jitter` is added where i == j (src/gpirtMCMC.cpp:16; pass 0 for
+ * K(theta, theta_star), src/draw-fstar.cpp:17). */
+int gpirt_se_kernel(gpirt_handle_t h, const double* d_x1, int64_t n1, const double* d_x2,
+                    int64_t n2, double* d_out, int64_t ld, double jitter);
+
+/* arma::chol(S, "lower"): src/gpirtMCMC.cpp:17,78,97.  In place on d_A (n x n, lda): on exit the
+ * lower triangle holds L and the strict upper triangle is zero.  Blocked right-looking
+ * factorisation, trailing update on fp64 MFMA.  Returns info (>0) if S is not positive definite. */
+int gpirt_potrf_lower(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda);
+
+/* Fused K(theta,theta) + jitter + chol: src/gpirtMCMC.cpp:15-17,76-78,95-97.  d_L n x n. */
+int gpirt_factor(gpirt_handle_t h, const double* d_theta, int64_t n, double* d_L, int64_t ldl);
+
+/* rmvnorm()'s product `cholS * res` (src/mvnormal.h:10) for all item columns at once:
+ * d_out (n x m) = L * Z with L lower triangular; the strict upper triangle of d_L must hold zeros
+ * (as gpirt_potrf_lower / arma::chol leave it). */
+int gpirt_trmm_lz(gpirt_handle_t h, const double* d_L, int64_t n, int64_t ldl, const double* d_Z,
+                  int64_t m, int64_t ldz, double* d_out, int64_t ldo);
+
+/* solve(trimatl(L), B) (trans = 0) and solve(trimatu(L.t()), B) (trans = 1):
+ * src/draw-fstar.cpp:7,19.  In place on d_B (n x nrhs, ldb). */
+int gpirt_trsm_lower(gpirt_handle_t h, const double* d_L, int64_t n, int64_t ldl, double* d_B,
+                     int64_t nrhs, int64_t ldb, int trans);
+
+/* General fp64 MFMA GEMM used by every stage: C = alpha * op(A) op(B) + beta * C.
+ * ta/tb: 0 = as stored, 1 = transposed.  C is M x N. */
+int gpirt_gemm(gpirt_handle_t h, int ta, int tb, int64_t M, int64_t N, int64_t K, double alpha,
+               const double* d_A, int64_t lda, const double* d_B, int64_t ldb, double beta,
+               double* d_C, int64_t ldc);
+
+/* ll_bar() for every column: src/log-likelihood.cpp:25-37.  d_out[j] = ll_bar(f_j, y_j, mu_j).
+ * d_mu may be NULL (then this is ll(), :12-23). */
+int gpirt_ll_bar(gpirt_handle_t h, const double* d_f, const double* d_y, const double* d_mu,
+                 int64_t n, int64_t m, double* d_out);
+
+/* draw_f(): src/draw-f.cpp:64-73 under GPIRT_RNG_ITEM: Z ~ N(0,1) from (seed, iter) sub-streams,
+ * nu = L Z as one trmm, then one elliptical-slice update per column (ess(), :21-60).
+ * In place on d_f (n x m).  d_k_out (m ints, may be NULL) receives the rejection counts. */
+int gpirt_draw_f(gpirt_handle_t h, double* d_f, const double* d_y, const double* d_L, int64_t ldl,
+                 const double* d_mu, int64_t n, int64_t m, uint64_t seed, uint32_t iter,
+                 int* d_k_out);
+
+/* draw_fstar(): src/draw-fstar.cpp:10-31 under GPIRT_RNG_ITEM.  d_out (N x m), N = GPIRT_NGRID.
+ * fused = 0: alpha = L^-T L^-1 f as in the reference (double_solve, :3-8);
+ * fused = 1: mean = (L^-1 kstar)^T (L^-1 f), algebraically identical, one trsm fewer.
+ * d_s_out (N) and d_mean_out (N x m) may be NULL. */
+int gpirt_draw_fstar(gpirt_handle_t h, const double* d_f, const double* d_theta, const double* d_L,
+                     int64_t ldl, const double* d_mu_star, int64_t n, int64_t m, uint64_t seed,
+                     uint32_t iter, int fused, double* d_out, double* d_s_out, double* d_mean_out);
+
+/* draw_theta(): src/draw-theta.cpp:3-37 under GPIRT_RNG_ITEM, as one fp64 MFMA GEMM over the
+ * +1 / -1 indicator matrices of y.  stabilise = 1 subtracts the column maximum before exp. */
+int gpirt_draw_theta(gpirt_handle_t h, const double* d_y, const double* d_fstar, int64_t n,
+                     int64_t m, uint64_t seed, uint32_t iter, int stabilise, double* d_theta_out,
+                     int* d_degenerate);
+
+/* draw_beta(): src/draw-beta.cpp:3-41 under GPIRT_RNG_ITEM.  In place on d_beta (2 x m). */
+int gpirt_draw_beta(gpirt_handle_t h, double* d_beta, const double* d_theta, const double* d_y,
+                    const double* d_f, const double* d_prior_means, const double* d_prior_sds,
+                    const double* d_step_sizes, int64_t n, int64_t m, uint64_t seed, uint32_t iter);
+
+/* The item-RNG primitives, exported so hosts and tests can address the same sub-streams. */
+int gpirt_item_uniforms(gpirt_handle_t h, uint64_t seed, uint32_t iter, uint32_t stage,
+                        uint32_t item0, int64_t n_items, int64_t n_index, double* d_out);
+int gpirt_item_normals(gpirt_handle_t h, uint64_t seed, uint32_t iter, uint32_t stage,
+                       uint32_t item0, int64_t n_items, int64_t n_index, double* d_out);
+
+/* ---------------------------------------------------------------- R's RNG on the host --- */
+/* set.seed(seed) + unif_rand()/norm_rand() of R's default Mersenne-Twister/inversion generator.
+ * Host code (R does this itself before the call: theta_init <- rnorm(n), R/gpirtMCMC.R:95-97). */
+typedef struct gpirt_rstream_s* gpirt_rstream_t;
+int gpirt_rstream_create(gpirt_rstream_t* r, uint32_t seed);
+int gpirt_rstream_from_state(gpirt_rstream_t* r, const uint32_t mt[624], int mti);
+int gpirt_rstream_get_state(gpirt_rstream_t r, uint32_t mt[624], int* mti);
+int gpirt_rstream_destroy(gpirt_rstream_t r);
+int gpirt_rstream_unif(gpirt_rstream_t r, double* h_out, int64_t n);
+int gpirt_rstream_norm(gpirt_rstream_t r, double* h_out, int64_t n);
+
+/* ---------------------------------------------------------------- sampler --------------- */
+typedef int (*gpirt_tick_fn)(void* ctx, int iter, int total);  /* nonzero return = stop */
+
+typedef struct gpirt_options {
+    int      rng_kind;        /* GPIRT_RNG_RSTREAM or GPIRT_RNG_ITEM */
+    uint64_t seed;            /* GPIRT_RNG_ITEM key */
+    int      theta_stabilise; /* 1 = subtract the row maximum before exp in draw_theta */
+    int      fstar_fused;     /* see gpirt_draw_fstar */
+    int      device;          /* < 0: current device */
+    int      use_graph;       /* 1 = replay one captured hipGraph per iteration (item RNG only) */
+    /* item sharding (one process per GPU): this rank owns item columns [item0, item0 + m) of a
+     * global problem with m_total items; y / priors / outputs passed in are the LOCAL columns. */
+    int64_t  item0;
+    int64_t  m_total;
+    int      reserved[8];
+} gpirt_options;
+
+void gpirt_default_options(gpirt_options* o);
+
+/* Whole-call drop-in for .gpirtMCMC (src/gpirtMCMC.cpp:5-117), all pointers HOST:
+ *   h_y            n x m   responses (never modified)
+ *   h_theta0       n       initial theta (copied, R semantics)
+ *   h_prior_means / h_prior_sds / h_step_sizes   2 x m
+ *   h_theta_draws  (S+1) x n, h_beta_draws 2 x m x (S+1), h_f_draws n x m x (S+1), h_irfs 1001 x m
+ * R-stream mode: rs carries R's Mersenne-Twister state in and out (GetRNGstate/PutRNGstate of
+ * Rcpp::RNGScope, src/RcppExports.cpp:19); ignored for GPIRT_RNG_ITEM.
+ * tick may be NULL; it is called once per iteration before the draws (Rprintf +
+ * checkUserInterrupt, src/gpirtMCMC.cpp:64-66,83-85). */
+int gpirt_mcmc(const double* h_y, int64_t n, int64_t m, const double* h_theta0,
+               int sample_iterations, int burn_iterations, const double* h_prior_means,
+               const double* h_prior_sds, const double* h_step_sizes, const gpirt_options* opts,
+               gpirt_rstream_t rs, gpirt_tick_fn tick, void* tick_ctx, double* h_theta_draws,
+               double* h_beta_draws, double* h_f_draws, double* h_irfs);
+
+/* Stage-level sampler for hosts that drive the loop themselves (bench.py, multi-GPU hosts that
+ * put a collective between stages).  State lives on the device. */
+int gpirt_sampler_create(gpirt_sampler_t* s, gpirt_handle_t h, const double* h_y, int64_t n,
+                         int64_t m, const double* h_theta0, const double* h_prior_means,
+                         const double* h_prior_sds, const double* h_step_sizes,
+                         const gpirt_options* opts, gpirt_rstream_t rs);
+int gpirt_sampler_destroy(gpirt_sampler_t s);
+int gpirt_sampler_init(gpirt_sampler_t s);               /* src/gpirtMCMC.cpp:13-47 */
+int gpirt_sampler_step(gpirt_sampler_t s);               /* one full iteration, :68-78 / :87-97 */
+/* the stages of one iteration, in the reference's order */
+int gpirt_sampler_draw_f(gpirt_sampler_t s);             /* :68 / :87 */
+int gpirt_sampler_draw_fstar(gpirt_sampler_t s);         /* :69 / :88 */
+int gpirt_sampler_theta_partial(gpirt_sampler_t s);      /* local-item part of draw_theta's log-posterior */
+int gpirt_sampler_theta_finish(gpirt_sampler_t s);       /* :70 / :89 (after any cross-rank reduction) */
+int gpirt_sampler_draw_beta(gpirt_sampler_t s);          /* :71-75 / :90-94 (beta, mu, mu_star) */
+int gpirt_sampler_factor(gpirt_sampler_t s);             /* :76-78 / :95-97 */
+int gpirt_sampler_accumulate_irf(gpirt_sampler_t s);     /* :103 */
+int gpirt_sampler_iteration(gpirt_sampler_t s, int* iter);
+int gpirt_sampler_check(gpirt_sampler_t s);              /* syncs; returns potrf info / GPIRT_E_* */
+/* Device pointer of a named state array ("theta","f","beta","mu","mu_star","fstar","L","logpost",
+ * "irf_sum","ess_k") and its element count; the pointer stays valid until destroy. */
+int gpirt_sampler_devptr(gpirt_sampler_t s, const char* name, void** d_ptr, int64_t* count);
+int gpirt_sampler_get(gpirt_sampler_t s, const char* name, double* h_out, int64_t count);
+int gpirt_sampler_set(gpirt_sampler_t s, const char* name, const double* h_in, int64_t count);
+int gpirt_sampler_finish_irfs(gpirt_sampler_t s, int sample_iterations, double* h_irfs); /* :106-111 */
+/* Per-stage device time of the last gpirt_sampler_step (ms, hipEvents); names_out is a
+ * NUL-separated list terminated by an empty string. */
+int gpirt_sampler_enable_timing(gpirt_sampler_t s, int on);
+int gpirt_sampler_stage_times(gpirt_sampler_t s, double* ms_out, int max_stages, int* n_stages,
+                              const char** names_out);
+/* Device time and launch count of the potrf trailing-update kernel accumulated since the last
+ * reset (hipEvents on the launch stream); the roofline figure of bench.py. */
+int gpirt_prof_trailing(gpirt_handle_t h, int reset, double* total_ms, int64_t* launches,
+                        double* flops);
+int gpirt_prof_enable(gpirt_handle_t h, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPIRT_HIP_H */

@@ -1,0 +1,205 @@
+"""GPU parity tests, operator level: every C-ABI operator against the CPU oracle on seeded inputs.
+
+Tolerances (fp64): element-wise kernels 1e-14 relative (libm exp/log may differ by an ulp between
+glibc and the ROCm device library); Cholesky factor max|L - L_ref| <= 1e-11 and relative residual
+<= 1e-14 * n; solves / products 1e-10 absolute.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _theta_grid(n, seed):
+    rng = np.random.default_rng(seed)
+    k = np.clip(np.rint((rng.standard_normal(n) + 5.0) / 0.01), 0, 1000)
+    return -5.0 + k * 0.01
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("shape", [(128, 128, 64), (257, 131, 77), (1001, 300, 513), (64, 1, 200), (5, 7, 3)])
+def test_gemm_matches_numpy(handle, ta, tb, shape):
+    from gpirt_amd.ops import to_device, to_host
+    M, N, K = shape
+    rng = np.random.default_rng(M * 7 + N)
+    A = rng.standard_normal((K, M) if ta else (M, K))
+    B = rng.standard_normal((N, K) if tb else (K, N))
+    C0 = rng.standard_normal((M, N))
+    Cd = to_device(C0)
+    out = handle.gemm(to_device(A), to_device(B), ta=ta, tb=tb, alpha=-1.5, beta=0.5, C_out=Cd)
+    ref = -1.5 * (A.T if ta else A) @ (B.T if tb else B) + 0.5 * C0
+    assert np.abs(to_host(out) - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+
+
+def test_gemm_mfma_layout_asymmetric(handle):
+    """A = I with an asymmetric B catches a transposed C/D lane map (guide section 3)."""
+    from gpirt_amd.ops import to_device, to_host
+    n = 256
+    B = np.arange(n * n, dtype=np.float64).reshape(n, n) / 7.0
+    out = handle.gemm(to_device(np.eye(n)), to_device(B))
+    assert np.array_equal(to_host(out), B)
+
+
+@pytest.mark.parametrize("n1,n2", [(100, 100), (1024, 1001), (513, 77)])
+def test_se_kernel(handle, oracle, n1, n2):
+    from gpirt_amd.ops import to_device, to_host
+    rng = np.random.default_rng(n1 + n2)
+    x1, x2 = rng.standard_normal(n1) * 2, rng.standard_normal(n2) * 2
+    K = to_host(handle.se_kernel(to_device(x1), to_device(x2), jitter=0.001 if n1 == n2 else 0.0))
+    ref = oracle.se_kernel(x1, x2)
+    if n1 == n2:
+        ref[np.diag_indices(n1)] += 0.001
+    assert np.abs(K - ref).max() <= 4e-16
+
+
+@pytest.mark.parametrize("n", [8, 64, 100, 200, 256, 300, 1000, 1024])
+def test_potrf_matches_oracle(handle, oracle, n):
+    from gpirt_amd.ops import to_device, to_host
+    theta = _theta_grid(n, n)
+    Lref, info = oracle.factor(theta)
+    assert info == 0
+    L = to_host(handle.factor(to_device(theta)))
+    assert np.array_equal(np.triu(L, 1), np.zeros_like(L))
+    S = oracle.se_kernel(theta, theta)
+    S[np.diag_indices(n)] += 0.001
+    resid = np.linalg.norm(L @ L.T - S) / np.linalg.norm(S)
+    assert resid <= 1e-14 * n
+    assert np.abs(L - Lref).max() <= 1e-11
+
+
+def test_potrf_operator_on_user_matrix(handle, oracle):
+    from gpirt_amd.ops import to_device, to_host
+    n = 200
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((n, n))
+    S = A @ A.T + n * np.eye(n)
+    L = to_host(handle.potrf_lower(to_device(S)))
+    assert np.abs(L - np.linalg.cholesky(S)).max() <= 1e-11
+
+
+def test_potrf_not_positive_definite_raises(handle):
+    from gpirt_amd.ops import to_device
+    S = np.eye(70)
+    S[40, 40] = -1.0
+    with pytest.raises(RuntimeError, match="decomposition failed"):
+        handle.potrf_lower(to_device(S))
+
+
+@pytest.mark.parametrize("n,m", [(100, 7), (300, 130), (1024, 256)])
+def test_trmm_trsm(handle, oracle, n, m):
+    from gpirt_amd.ops import to_device, to_host
+    theta = _theta_grid(n, 5)
+    Lref, _ = oracle.factor(theta)
+    Ld = to_device(Lref)
+    rng = np.random.default_rng(n)
+    Z = rng.standard_normal((n, m))
+    out = to_host(handle.trmm_lz(Ld, to_device(Z)))
+    assert np.abs(out - Lref @ Z).max() <= 1e-11
+    for trans in (False, True):
+        X = to_host(handle.trsm_lower(Ld, to_device(Z), trans=trans))
+        ref = oracle.trsm_lower(Lref, Z, trans=trans)
+        scale = np.abs(ref).max()
+        assert np.abs(X - ref).max() <= 1e-10 * scale
+        back = (Lref.T if trans else Lref) @ X
+        assert np.abs(back - Z).max() <= 1e-9
+
+
+def test_item_rng_matches_oracle(handle, oracle):
+    from gpirt_amd.ops import to_host
+    seed, it, stage = 0x1234567890ABCDEF, 3, oracle.ST_F_Z
+    U = to_host(handle.item_uniforms(seed, it, stage, 5, 4, 33))
+    Z = to_host(handle.item_normals(seed, it, stage, 5, 4, 33))
+    for j in range(4):
+        for i in range(33):
+            u = oracle.item_uniform(seed, it, stage, 5 + j, i)
+            assert U[i, j] == u
+            assert abs(Z[i, j] - oracle.qnorm(u)) <= 4e-15 * max(1.0, abs(Z[i, j]))
+
+
+def test_ll_bar(handle, oracle):
+    from gpirt_amd.ops import to_device
+    from gpirt_amd.synthetic import make_responses
+    n, m = 300, 9
+    y, _ = make_responses(n, m, seed=11)
+    rng = np.random.default_rng(0)
+    f, mu = rng.standard_normal((n, m)), rng.standard_normal((n, m))
+    got = handle.ll_bar(to_device(f), to_device(y), to_device(mu)).cpu().numpy()
+    for j in range(m):
+        ref = oracle.ll_bar(f[:, j], y[:, j], mu[:, j])
+        assert abs(got[j] - ref) <= 1e-12 * abs(ref)
+    got = handle.ll_bar(to_device(f), to_device(y)).cpu().numpy()
+    assert abs(got[0] - oracle.ll(f[:, 0], y[:, 0])) <= 1e-12 * abs(got[0])
+
+
+def _problem(n, m, seed):
+    from gpirt_amd.synthetic import make_responses
+    y, theta = make_responses(n, m, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    f = rng.standard_normal((n, m))
+    beta = np.vstack([rng.uniform(-1, 1, m), rng.uniform(0.5, 2, m)])
+    mu = beta[0][None, :] + theta[:, None] * beta[1][None, :]
+    return y, theta, f, beta, mu
+
+
+@pytest.mark.parametrize("n,m", [(100, 5), (520, 33)])
+def test_draw_f_item_rng(handle, oracle, n, m):
+    from gpirt_amd.ops import to_device, to_host
+    y, theta, f, beta, mu = _problem(n, m, 21)
+    L, _ = oracle.factor(theta)
+    seed, it = 77, 4
+    rng = oracle.ItemStream(seed)
+    ref, kref = oracle.draw_f(rng, f, y, L, mu, it=it)
+    fd = to_device(f)
+    out, k = handle.draw_f(fd, to_device(y), to_device(L), to_device(mu), seed, it)
+    assert np.array_equal(k.cpu().numpy(), kref)
+    assert np.abs(to_host(out) - ref).max() <= 1e-9
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_draw_fstar_item_rng(handle, oracle, fused):
+    from gpirt_amd.ops import to_device, to_host
+    n, m = 300, 6
+    y, theta, f, beta, mu = _problem(n, m, 5)
+    L, _ = oracle.factor(theta)
+    f = L @ np.random.default_rng(1).standard_normal((n, m))      # a GP-plausible f
+    ts = oracle.theta_star()
+    mu_star = beta[0][None, :] + ts[:, None] * beta[1][None, :]
+    seed, it = 99, 2
+    ref, sref, meanref = oracle.draw_fstar(oracle.ItemStream(seed), f, theta, L, mu_star, it=it)
+    out, s, mean = handle.draw_fstar(to_device(f), to_device(theta), to_device(L), to_device(mu_star), seed, it, fused=fused)
+    assert np.abs(s.cpu().numpy() - sref).max() <= 1e-9
+    assert np.abs(to_host(mean) - meanref).max() <= 1e-9
+    assert np.abs(to_host(out) - ref).max() <= 1e-9
+
+
+@pytest.mark.parametrize("stabilise", [False, True])
+def test_draw_theta_item_rng(handle, oracle, stabilise):
+    from gpirt_amd.ops import to_device
+    n, m = 200, 12
+    y, theta, f, beta, mu = _problem(n, m, 8)
+    ts = oracle.theta_star()
+    fstar = beta[0][None, :] + ts[:, None] * beta[1][None, :] + 0.1 * np.sin(ts)[:, None]
+    seed, it = 5, 9
+    ref, deg = oracle.draw_theta(oracle.ItemStream(seed), y, fstar, it=it, stabilise=stabilise)
+    out, degd = handle.draw_theta(to_device(y), to_device(fstar), seed, it, stabilise=stabilise)
+    assert deg == 0 and degd == 0
+    assert np.array_equal(out.cpu().numpy(), ref)       # theta is a grid value: exact
+
+
+def test_draw_beta_item_rng(handle, oracle):
+    from gpirt_amd.ops import to_device, to_host
+    n, m = 257, 10
+    y, theta, f, beta, mu = _problem(n, m, 13)
+    pm, ps, st = np.zeros((2, m)), np.full((2, m), 3.0), np.full((2, m), 0.1)
+    st[0, 3] = 0.0                                       # rnorm(mu, 0) consumes nothing
+    seed, it = 31, 6
+    ref = oracle.draw_beta(oracle.ItemStream(seed), beta, theta, y, f, pm, ps, st, it=it)
+    bd = to_device(beta)
+    handle.draw_beta(bd, to_device(theta), to_device(y), to_device(f), to_device(pm), to_device(ps), to_device(st), seed, it)
+    assert np.abs(to_host(bd) - ref).max() <= 1e-12
+
+
+def test_calibrate_mfma(handle):
+    tf = handle.calibrate_mfma_f64()
+    print("fp64 MFMA peak (measured):", tf, "TFLOP/s")
+    assert 20.0 < tf < 200.0
