@@ -88,6 +88,7 @@ SIGNATURES = {
     "gpirt_sampler_theta_finish": (_i32, [_vp]),
     "gpirt_sampler_draw_beta": (_i32, [_vp]),
     "gpirt_sampler_factor": (_i32, [_vp]),
+    "gpirt_sampler_skip_factor": (_i32, [_vp]),
     "gpirt_sampler_accumulate_irf": (_i32, [_vp]),
     "gpirt_sampler_iteration": (_i32, [_vp, C.POINTER(_i32)]),
     "gpirt_sampler_check": (_i32, [_vp]),

@@ -104,8 +104,6 @@ int gpirt_create(gpirt_handle_t* out, int device, void* stream)
     GP_HIP(hipMalloc(&h->d_info, 64));
     GP_HIP(hipMemset(h->d_info, 0, 64));
     GP_HIP(hipHostMalloc(&h->h_info, 64, hipHostMallocDefault));
-    GP_HIP(hipEventCreate(&h->prof.e0));
-    GP_HIP(hipEventCreate(&h->prof.e1));
     *out = h;
     return 0;
 }
@@ -117,8 +115,8 @@ int gpirt_destroy(gpirt_handle_t h)
     if (h->d_info) hipFree(h->d_info);
     if (h->h_info) hipHostFree(h->h_info);
     if (h->d_work) hipFree(h->d_work);
-    if (h->prof.e0) hipEventDestroy(h->prof.e0);
-    if (h->prof.e1) hipEventDestroy(h->prof.e1);
+    for (auto& pp : h->prof.pending) { hipEventDestroy(pp.e0); hipEventDestroy(pp.e1); }
+    for (auto& pp : h->prof.free_pairs) { hipEventDestroy(pp.e0); hipEventDestroy(pp.e1); }
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -357,6 +355,18 @@ int gpirt_prof_enable(gpirt_handle_t h, int on)
 int gpirt_prof_trailing(gpirt_handle_t h, int reset, double* total_ms, int64_t* launches, double* flops)
 {
     GP_ARG(h != nullptr);
+    if (!h->prof.pending.empty()) {
+        GP_HIP(hipStreamSynchronize(h->stream));
+        for (auto& pp : h->prof.pending) {
+            float ms = 0.f;
+            GP_HIP(hipEventElapsedTime(&ms, pp.e0, pp.e1));
+            h->prof.trailing_ms += ms;
+            h->prof.trailing_launches += 1;
+            h->prof.trailing_flops += pp.flops;
+            h->prof.free_pairs.push_back(pp);
+        }
+        h->prof.pending.clear();
+    }
     if (total_ms) *total_ms = h->prof.trailing_ms;
     if (launches) *launches = h->prof.trailing_launches;
     if (flops) *flops = h->prof.trailing_flops;

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
+#include <vector>
 
 #include "../../include/gpirt_hip.h"
 
@@ -39,12 +40,16 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 // ---------------------------------------------------------------- handle -------------------
+// Event-pair profiler for the potrf trailing-update launches: pairs are recorded on the launch
+// stream without synchronising and resolved later by gpirt_prof_trailing().
+struct ProfPair { hipEvent_t e0, e1; double flops; };
 struct Prof {
     bool        enabled = false;
     double      trailing_ms = 0.0;
     int64_t     trailing_launches = 0;
     double      trailing_flops = 0.0;
-    hipEvent_t  e0 = nullptr, e1 = nullptr;
+    std::vector<ProfPair> pending;
+    std::vector<ProfPair> free_pairs;
 };
 
 }  // namespace gpirt

@@ -159,18 +159,19 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
         }
         if (c1 < n) {
             const int64_t rows = n - c1;
-            if (prof) GP_HIP(hipEventRecord(h->prof.e0, stream));
+            ProfPair pp{nullptr, nullptr, 0.0};
+            if (prof) {
+                if (!h->prof.free_pairs.empty()) { pp = h->prof.free_pairs.back(); h->prof.free_pairs.pop_back(); }
+                else { GP_HIP(hipEventCreate(&pp.e0)); GP_HIP(hipEventCreate(&pp.e1)); }
+                GP_HIP(hipEventRecord(pp.e0, stream));
+            }
             GP_TRY(launch_gemm(h, stream, false, true, TRI_SYRK_LOWER, rows, rows, c1 - K0, -1.0,
                                A + c1 + K0 * lda, lda, A + c1 + K0 * lda, lda, 1.0,
                                A + c1 + c1 * lda, lda));
             if (prof) {
-                GP_HIP(hipEventRecord(h->prof.e1, stream));
-                GP_HIP(hipEventSynchronize(h->prof.e1));
-                float ms = 0.f;
-                GP_HIP(hipEventElapsedTime(&ms, h->prof.e0, h->prof.e1));
-                h->prof.trailing_ms += ms;
-                h->prof.trailing_launches += 1;
-                h->prof.trailing_flops += (double)rows * (double)rows * (double)(c1 - K0);
+                GP_HIP(hipEventRecord(pp.e1, stream));
+                pp.flops = (double)rows * (double)rows * (double)(c1 - K0);   // n^2 k (lower half, 2 flop/fma)
+                h->prof.pending.push_back(pp);
             }
         }
     }

@@ -433,6 +433,13 @@ int gpirt_sampler_factor(gpirt_sampler_t s)
     return 0;
 }
 
+int gpirt_sampler_skip_factor(gpirt_sampler_t s)
+{
+    GP_ARG(s && s->initialised);
+    s->iter += 1;
+    return 0;
+}
+
 int gpirt_sampler_step(gpirt_sampler_t s)
 {
     GP_ARG(s && s->initialised);

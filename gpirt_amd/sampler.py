@@ -144,6 +144,7 @@ class Sampler:
     def theta_finish(self): self._call("gpirt_sampler_theta_finish")
     def draw_beta(self): self._call("gpirt_sampler_draw_beta")
     def factor(self): self._call("gpirt_sampler_factor")
+    def skip_factor(self): self._call("gpirt_sampler_skip_factor")
     def accumulate_irf(self): self._call("gpirt_sampler_accumulate_irf")
     def check(self): self._call("gpirt_sampler_check")
 

@@ -204,6 +204,8 @@ int gpirt_sampler_theta_partial(gpirt_sampler_t s);      /* local-item part of d
 int gpirt_sampler_theta_finish(gpirt_sampler_t s);       /* :70 / :89 (after any cross-rank reduction) */
 int gpirt_sampler_draw_beta(gpirt_sampler_t s);          /* :71-75 / :90-94 (beta, mu, mu_star) */
 int gpirt_sampler_factor(gpirt_sampler_t s);             /* :76-78 / :95-97 */
+/* closes the iteration WITHOUT factoring: for ranks that receive L by broadcast ("L" devptr) */
+int gpirt_sampler_skip_factor(gpirt_sampler_t s);
 int gpirt_sampler_accumulate_irf(gpirt_sampler_t s);     /* :103 */
 int gpirt_sampler_iteration(gpirt_sampler_t s, int* iter);
 int gpirt_sampler_check(gpirt_sampler_t s);              /* syncs; returns potrf info / GPIRT_E_* */
