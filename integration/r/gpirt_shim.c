@@ -1,0 +1,122 @@
+/*
+ * gpirt_shim.c -- the plain-C `.Call` routine a maintainer of duckmayr/gpirt adds to swap the
+ * RcppArmadillo sampler for libgpirt_hip.so.  It replaces src/RcppExports.cpp:16-40 (the generated
+ * Rcpp glue `_gpirt_gpirtMCMC` + R_init_gpirt) one for one: same symbol, same 7 arguments, same
+ * returned list (src/gpirtMCMC.cpp:112-116), same RNG bracketing (Rcpp::RNGScope,
+ * src/RcppExports.cpp:19), same progress text and interrupt polling (src/gpirtMCMC.cpp:64-66,105).
+ *
+ * NOT compiled in the build container (R.h / Rinternals.h are absent there);
+ * every behaviour it relies on is exercised through the same C ABI by the Python harness
+ * (gpirt_amd/sampler.py).  Build inside the R package with:
+ *     PKG_CPPFLAGS = -I<repo>/include      PKG_LIBS = -L<repo>/gpirt_amd -lgpirt_hip
+ */
+#include <R.h>
+#include <Rinternals.h>
+#include <R_ext/Random.h>
+#include <R_ext/Rdynload.h>
+#include <R_ext/Utils.h>
+
+#include "gpirt_hip.h"
+
+static void chk_interrupt(void* dummy) { (void)dummy; R_CheckUserInterrupt(); }
+
+/* Rprintf("\r%6.3f %% complete") + Rcpp::checkUserInterrupt(), src/gpirtMCMC.cpp:64-66 */
+static int tick(void* ctx, int iter, int total)
+{
+    (void)ctx;
+    Rprintf("\r%6.3f %% complete", 100.0 * (double)iter / (double)(total > 0 ? total : 1));
+    /* R_ToplevelExec returns FALSE when the user interrupted: ask the core to stop cleanly so
+     * device memory is released before the R condition is raised */
+    return R_ToplevelExec(chk_interrupt, NULL) ? 0 : 1;
+}
+
+/* R's Mersenne-Twister state lives in .Random.seed: [kind, mti, mt[0..623]].  The reference reads
+ * and writes it through GetRNGstate()/PutRNGstate(); the HIP core replays the same stream, so the
+ * state is handed over explicitly and written back. */
+static int rng_is_default_mt(SEXP seedvec)
+{
+    return TYPEOF(seedvec) == INTSXP && LENGTH(seedvec) == 626 && (INTEGER(seedvec)[0] % 100) == 3;
+}
+
+SEXP _gpirt_gpirtMCMC(SEXP ySEXP, SEXP thetaSEXP, SEXP sample_iterationsSEXP, SEXP burn_iterationsSEXP,
+                      SEXP beta_prior_meansSEXP, SEXP beta_prior_sdsSEXP, SEXP beta_step_sizesSEXP)
+{
+    SEXP dim = getAttrib(ySEXP, R_DimSymbol);
+    const int64_t n = INTEGER(dim)[0], m = INTEGER(dim)[1];
+    const int S = asInteger(sample_iterationsSEXP), B = asInteger(burn_iterationsSEXP);
+    const int64_t N = GPIRT_NGRID;
+
+    SEXP theta = PROTECT(allocMatrix(REALSXP, S + 1, (int)n));
+    SEXP beta = PROTECT(alloc3DArray(REALSXP, 2, (int)m, S + 1));
+    SEXP f = PROTECT(alloc3DArray(REALSXP, (int)n, (int)m, S + 1));
+    SEXP irfs = PROTECT(allocMatrix(REALSXP, (int)N, (int)m));
+
+    gpirt_options opt;
+    gpirt_default_options(&opt);
+    opt.theta_stabilise = asLogical(GetOption1(install("gpirt.hip.theta_stabilise"))) == TRUE;
+    opt.fstar_fused = asLogical(GetOption1(install("gpirt.hip.fstar_fused"))) == TRUE;
+
+    /* options(gpirt.hip.rng = "item") selects the batched counter-based contract; the default
+     * replays R's own stream so results are draw-for-draw those of the RcppArmadillo build */
+    SEXP rngopt = GetOption1(install("gpirt.hip.rng"));
+    const int item_rng = isString(rngopt) && strcmp(CHAR(STRING_ELT(rngopt, 0)), "item") == 0;
+
+    gpirt_rstream_t rs = NULL;
+    SEXP seedvec = R_NilValue;
+    GetRNGstate();                                           /* Rcpp::RNGScope, entry */
+    if (item_rng) {
+        opt.rng_kind = GPIRT_RNG_ITEM;
+        opt.seed = (uint64_t)(unif_rand() * 4294967296.0) << 32 | (uint64_t)(unif_rand() * 4294967296.0);
+    } else {
+        opt.rng_kind = GPIRT_RNG_RSTREAM;
+        PutRNGstate();                                       /* make .Random.seed current */
+        seedvec = findVarInFrame(R_GlobalEnv, install(".Random.seed"));
+        if (!rng_is_default_mt(seedvec)) {
+            UNPROTECT(4);
+            error("gpirt-hip: rng = \"reference\" needs RNGkind(\"Mersenne-Twister\", \"Inversion\")");
+        }
+        gpirt_rstream_from_state(&rs, (const uint32_t*)(INTEGER(seedvec) + 2), INTEGER(seedvec)[1]);
+        GetRNGstate();
+    }
+
+    int rc = gpirt_mcmc(REAL(ySEXP), n, m, REAL(thetaSEXP), S, B, REAL(beta_prior_meansSEXP),
+                        REAL(beta_prior_sdsSEXP), REAL(beta_step_sizesSEXP), &opt, rs, tick, NULL,
+                        REAL(theta), REAL(beta), REAL(f), REAL(irfs));
+
+    if (rs) {                                                /* hand the advanced stream back to R */
+        int mti = 0;
+        gpirt_rstream_get_state(rs, (uint32_t*)(INTEGER(seedvec) + 2), &mti);
+        INTEGER(seedvec)[1] = mti;
+        gpirt_rstream_destroy(rs);
+        GetRNGstate();                                       /* re-read the modified .Random.seed */
+    }
+    PutRNGstate();                                           /* Rcpp::RNGScope, exit */
+
+    if (rc != 0) {                                           /* device resources are already released */
+        UNPROTECT(4);
+        if (rc == GPIRT_E_INTERRUPT) { Rprintf("\n"); Rf_onintr(); }
+        error("%s", rc > 0 ? "chol(): decomposition failed" : gpirt_last_error());
+    }
+    Rprintf("\r100.000 %% complete\n");                      /* src/gpirtMCMC.cpp:105 */
+
+    SEXP res = PROTECT(allocVector(VECSXP, 4));
+    SEXP names = PROTECT(allocVector(STRSXP, 4));
+    SET_VECTOR_ELT(res, 0, theta); SET_STRING_ELT(names, 0, mkChar("theta"));
+    SET_VECTOR_ELT(res, 1, beta);  SET_STRING_ELT(names, 1, mkChar("beta"));
+    SET_VECTOR_ELT(res, 2, f);     SET_STRING_ELT(names, 2, mkChar("f"));
+    SET_VECTOR_ELT(res, 3, irfs);  SET_STRING_ELT(names, 3, mkChar("IRFs"));
+    setAttrib(res, R_NamesSymbol, names);
+    UNPROTECT(6);
+    return res;
+}
+
+static const R_CallMethodDef CallEntries[] = {
+    {"_gpirt_gpirtMCMC", (DL_FUNC)&_gpirt_gpirtMCMC, 7},      /* src/RcppExports.cpp:32-35 */
+    {NULL, NULL, 0}
+};
+
+void R_init_gpirt(DllInfo* dll)                               /* src/RcppExports.cpp:37-40 */
+{
+    R_registerRoutines(dll, NULL, CallEntries, NULL, NULL);
+    R_useDynamicSymbols(dll, FALSE);
+}

@@ -115,7 +115,9 @@ void orc_rng_init_item(orc_rng* r, uint64_t seed)
 void orc_rng_substream(orc_rng* r, uint32_t iter, uint32_t stage, uint32_t item)
 {
     if (r->kind != ORC_RNG_ITEM) return; /* the R stream is one global sequence */
-    r->iter = iter; r->stage = stage; r->item = item; r->index = 0;
+    /* item-keyed stages use the GLOBAL item index; draw_theta is keyed by respondent */
+    r->iter = iter; r->stage = stage; r->index = 0;
+    r->item = item + (stage != ORC_ST_THETA ? r->item_base : 0u);
 }
 
 double orc_unif_rand(orc_rng* r)
@@ -293,7 +295,7 @@ int orc_ess(orc_rng* r, const double* f, const double* y, const double* L, const
 {
     double* z  = (double*)malloc(sizeof(double) * (size_t)n);
     double* nu = nu_out ? nu_out : (double*)malloc(sizeof(double) * (size_t)n);
-    uint32_t iter = r->iter, item = r->item;
+    uint32_t iter = r->iter, item = r->item_local;
     orc_rng_substream(r, iter, ORC_ST_F_Z, item);
     orc_rmvnorm(r, L, n, z, nu);                                   /* :26 */
     orc_rng_substream(r, iter, ORC_ST_F_ESS, item);
@@ -323,7 +325,7 @@ void orc_draw_f(orc_rng* r, uint32_t iter, const double* f, const double* y, con
                 const double* mu, int64_t n, int64_t m, double* f_out, int* k_out)
 {
     for (int64_t j = 0; j < m; ++j) {
-        r->iter = iter; r->item = (uint32_t)j;
+        r->iter = iter; r->item_local = (uint32_t)j;
         int k = orc_ess(r, f + j * n, y + j * n, L, mu + j * n, n, f_out + j * n, NULL, NULL);
         if (k_out) k_out[j] = k;
     }

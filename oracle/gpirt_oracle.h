@@ -52,6 +52,8 @@ typedef struct orc_rng {
     uint32_t stage;
     uint32_t item;
     uint32_t index;       /* next index inside the current sub-stream                        */
+    uint32_t item_base;   /* global index of local item 0 (item-sharded runs; 0 otherwise)   */
+    uint32_t item_local;  /* local item whose ess() is running                               */
 } orc_rng;
 
 void   orc_rng_init_rstream(orc_rng* r, uint32_t seed);          /* == set.seed(seed)        */

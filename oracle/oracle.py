@@ -37,6 +37,8 @@ class Rng(C.Structure):
         ("stage", C.c_uint32),
         ("item", C.c_uint32),
         ("index", C.c_uint32),
+        ("item_base", C.c_uint32),
+        ("item_local", C.c_uint32),
     ]
 
 
@@ -125,9 +127,10 @@ class RStream:
 class ItemStream:
     """Counter-based (Philox4x32-10) per-(iteration, stage, item) sub-streams."""
 
-    def __init__(self, seed: int):
+    def __init__(self, seed: int, item_base: int = 0):
         self.s = Rng()
         lib().orc_rng_init_item(C.byref(self.s), C.c_uint64(seed))
+        self.s.item_base = item_base
 
     @property
     def ref(self):
@@ -216,7 +219,7 @@ def ess(rng, f, y, L, mu, it=0, item=0):
     out = np.empty(n)
     nu = np.empty(n)
     tr = EssTrace()
-    rng.s.iter, rng.s.item = it, item
+    rng.s.iter, rng.s.item_local = it, item
     lib().orc_ess(rng.ref, _p(f), _p(y), _p(L), _p(mu), C.c_int64(n), _p(out), _p(nu), C.byref(tr))
     return out, nu, dict(u=tr.u, log_y=tr.log_y, eps0=tr.eps0, eps_final=tr.eps_final, k=tr.k)
 

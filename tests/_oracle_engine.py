@@ -1,0 +1,100 @@
+"""A CPU stand-in for gpirt_amd.Sampler built on the oracle -- tests only.
+
+It exists so the multi-process host logic of gpirt_amd/distributed.py (item partition, all-reduce of
+the partial log-posterior, broadcast of L, gathers) can be exercised under gloo on a machine without
+a GPU.  The HIP path itself is covered by the -m gpu tests.
+"""
+import numpy as np
+import torch
+
+from oracle import oracle as O
+
+
+class OracleEngine:
+    def __init__(self, y, theta0, pm, ps, step, item0, m_total, seed=11):
+        self.y = np.asfortranarray(y)
+        self.n, self.m = self.y.shape
+        self.pm, self.ps, self.step = (np.asfortranarray(a) for a in (pm, ps, step))
+        self.theta = np.array(theta0, dtype=np.float64)
+        self.rng = O.ItemStream(seed, item_base=item0)
+        self.it = 0
+        self.ts = O.theta_star()
+        self.N = len(self.ts)
+        self._logpost = torch.zeros(self.N * self.n, dtype=torch.float64)
+        self._L = torch.zeros(self.n * self.n, dtype=torch.float64)
+
+    # state views shared with torch (what the collectives operate on)
+    def device_tensor(self, name):
+        return {"logpost": self._logpost, "L": self._L}[name]
+
+    @property
+    def L(self):
+        return self._L.numpy().reshape(self.n, self.n, order="F")
+
+    def _factor_into_L(self):
+        L, info = O.factor(self.theta)
+        assert info == 0
+        self.L[:, :] = L
+
+    def init(self):
+        self._factor_into_L()
+        f = np.empty((self.n, self.m), order="F")
+        for j in range(self.m):
+            self.rng.substream(0, O.ST_INIT_F, j)
+            f[:, j], _ = O.rmvnorm(self.rng, self.L)
+        self.f = f
+        beta = np.empty((2, self.m), order="F")
+        for j in range(self.m):
+            self.rng.substream(0, O.ST_INIT_BETA, j)
+            for p in range(2):
+                self.rng.s.index = p
+                beta[p, j] = O.lib().orc_rnorm(self.rng.ref, self.pm[p, j], self.ps[p, j])
+        self.beta = beta
+        self._means()
+        self.fstar, _, _ = O.draw_fstar(self.rng, self.f, self.theta, self.L, self.mu_star, it=0)
+
+    def _means(self):
+        self.mu = self.beta[0][None, :] + self.theta[:, None] * self.beta[1][None, :]
+        self.mu_star = self.beta[0][None, :] + self.ts[:, None] * self.beta[1][None, :]
+
+    def draw_f(self):
+        self.f, self.k = O.draw_f(self.rng, self.f, self.y, self.L, self.mu, it=self.it + 1)
+
+    def draw_fstar(self):
+        self.fstar, _, _ = O.draw_fstar(self.rng, self.f, self.theta, self.L, self.mu_star, it=self.it + 1)
+
+    def theta_partial(self):
+        # partial log-likelihood sums over this rank's items: N x n, column i = respondent i
+        lp = np.zeros((self.N, self.n), order="F")
+        for i in range(self.n):
+            ok = ~np.isnan(self.y[i])
+            a = self.fstar[:, ok] * self.y[i, ok][None, :]
+            lp[:, i] = -np.sum(np.log(1 + np.exp(-a)), axis=1)
+        self._logpost.numpy()[:] = lp.reshape(-1, order="F")
+
+    def theta_finish(self):
+        lp = self._logpost.numpy().reshape(self.N, self.n, order="F")
+        prior = np.array([O.lib().orc_dnorm_log(t, 0.0, 1.0) for t in self.ts])
+        out = np.empty(self.n)
+        for i in range(self.n):
+            P = prior + lp[:, i]
+            P = np.cumsum(np.exp(P - P.max()))
+            P = (P - P.min()) / (P.max() - P.min())
+            u = O.item_uniform(self.rng.s.seed, self.it + 1, O.ST_THETA, i, 0)
+            out[i] = self.ts[np.nonzero(P > u)[0][0]]
+        self.theta = out
+
+    def draw_beta(self):
+        self.beta = O.draw_beta(self.rng, self.beta, self.theta, self.y, self.f, self.pm, self.ps, self.step,
+                                it=self.it + 1)
+        self._means()
+
+    def factor(self):
+        self._factor_into_L()
+        self.it += 1
+
+    def skip_factor(self):
+        self.it += 1
+
+    def get(self, name):
+        return np.asfortranarray(getattr(self, name) if name != "L" else self.L)
