@@ -190,11 +190,26 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p)
     }
 
     // epilogue: acc[tn][tm][r] = C[m = i0+wm*64+tm*16+l15][n = j0+wn*64+tn*16+l4+4r]
+    // C is read in batches of 16 independent loads before anything is stored: a store followed by
+    // a load of the same array would otherwise serialise 64 L2 round trips per thread.
     const double alpha = p.alpha, beta = p.beta;
     const bool interior = (i0 + BM <= p.M) && (j0 + BN <= p.N);
     const bool lower_mask = (p.tri == TRI_SYRK_LOWER) && (bi == bj);
+    const bool use_c = (beta != 0.0);
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn)
+    for (int tn = 0; tn < 4; ++tn) {
+        double cv[4][4];
+        if (use_c) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = j0 + wn * 64 + tn * 16 + l4 + 4 * r;
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm) {
+                    const int m = i0 + wm * 64 + tm * 16 + l15;
+                    cv[r][tm] = (interior || (m < p.M && n < p.N)) ? p.C[(int64_t)m + (int64_t)n * p.ldc] : 0.0;
+                }
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = j0 + wn * 64 + tn * 16 + l4 + 4 * r;
@@ -202,13 +217,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p)
             for (int tm = 0; tm < 4; ++tm) {
                 const int m = i0 + wm * 64 + tm * 16 + l15;
                 if ((interior || (m < p.M && n < p.N)) && !(lower_mask && m < n)) {
-                    double* c = p.C + (int64_t)m + (int64_t)n * p.ldc;
                     double v = alpha * acc[tn][tm][r];
-                    if (beta != 0.0) v += beta * (*c);
-                    *c = v;
+                    if (use_c) v += beta * cv[r][tm];
+                    p.C[(int64_t)m + (int64_t)n * p.ldc] = v;
                 }
             }
         }
+    }
 }
 
 }  // namespace

@@ -16,6 +16,7 @@
 // leading minor) in h->d_info and lets NaNs propagate; the host checks it after the stream drains.
 #include "common.h"
 #include "kernels.h"
+#include "solve64.h"
 
 namespace gpirt {
 
@@ -23,101 +24,143 @@ namespace {
 
 constexpr int NBI = 64;
 constexpr int NBO = 256;
-constexpr int LDD = NBI + 1;
 
 // ------------------------------------------------------------------ diagonal block ---------
+// 64 x 64 Cholesky in one work-group, register tiled: thread (tr, tc) = (t & 15, t >> 4) owns the
+// 4 x 4 tile rows 4tr.., columns 4tc.. .  Per 4-column panel jb: the 16 lanes that own it (one
+// contiguous 16-lane group of one wavefront) factor it with v_readlane broadcasts of the pivot
+// row -- no barrier inside the panel --, publish it to LDS, and after ONE barrier every trailing
+// tile applies the rank-4 update from registers.  16 barriers in total (the unblocked version
+// this replaces needed 192 and ran 83 us; see profiles/).
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(256) void potf2_64_kernel(double* __restrict__ A, int64_t lda, int nb,
                                                        int k0, int* __restrict__ info)
 {
-    __shared__ double sd[NBI * LDD];
+    __shared__ __attribute__((aligned(16))) double sP[2][4 * NBI];   // sP[buf][k * 64 + row]
     __shared__ int sfail;
     const int t = threadIdx.x;
-    if (t == 0) sfail = 0;
-    for (int idx = t; idx < NBI * NBI; idx += 256) {
-        const int r = idx & (NBI - 1), c = idx >> 6;
-        double v = 0.0;
-        if (r < nb && c < nb && r >= c) v = A[(int64_t)r + (int64_t)c * lda];
-        else if (r == c) v = 1.0;                       // identity padding for nb < 64
-        sd[r + c * LDD] = v;
-    }
+    const int tr = t & 15, tc = t >> 4;
+    double a[4][4];                                                   // a[i][k]: row 4tr+i, col 4tc+k
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 4 * tr + i, col = 4 * tc + k;
+            double v = (row == col) ? 1.0 : 0.0;                      // identity padding for nb < 64
+            if (row >= col && row < nb && col < nb) v = A[(int64_t)row + (int64_t)col * lda];
+            a[i][k] = v;
+        }
+    if (t == 0) sfail = 0x7fffffff;
     __syncthreads();
-    for (int j = 0; j < nb; ++j) {
-        const double d = sd[j + j * LDD];
-        if (!(d > 0.0) && t == 0 && sfail == 0) sfail = j + 1;
-        const double piv = sqrt(d);                     // NaN when d < 0: propagates
-        __syncthreads();
-        if (t > j && t < NBI) sd[t + j * LDD] /= piv;
-        if (t == j) sd[j + j * LDD] = piv;
-        __syncthreads();
-        const int w = nb - j - 1;
-        for (int idx = t; idx < w * w; idx += 256) {
-            const int r = j + 1 + idx % w, c = j + 1 + idx / w;
-            if (r >= c) sd[r + c * LDD] -= sd[r + j * LDD] * sd[c + j * LDD];
+    int fail = 0x7fffffff;
+#pragma unroll
+    for (int jb = 0; jb < 16; ++jb) {
+        const int buf = jb & 1;
+        if (tc == jb) {
+            const int src = jb + 16 * (jb & 3);                       // lane of thread (tr = jb, tc = jb)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = 4 * jb + jj;
+                const double d = readlane_f64(a[jj][jj], src);
+                if (!(d > 0.0) && j < nb && fail == 0x7fffffff) fail = j + 1;
+                // pivot column scaled by 1/sqrt(d) (LAPACK dpotf2 scales by the reciprocal too);
+                // rsqrt keeps the 64-step dependent chain short.  d <= 0 gives NaN: propagates.
+                const double rinv = (d > 0.0) ? rsqrt(d) : __builtin_nan("");
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = 4 * tr + i;
+                    if (row > j) a[i][jj] *= rinv;
+                    else if (row == j) a[i][jj] = d * rinv;
+                }
+#pragma unroll
+                for (int jj2 = jj + 1; jj2 < 4; ++jj2) {
+                    const double lc = readlane_f64(a[jj2][jj], src);  // L[4jb+jj2][j]
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (4 * tr + i >= 4 * jb + jj2) a[i][jj2] = fma(-a[i][jj], lc, a[i][jj2]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    sP[buf][k * NBI + 4 * tr + i] = (4 * tr + i >= 4 * jb + k) ? a[i][k] : 0.0;
         }
         __syncthreads();
+        if (tc > jb && tr >= tc) {
+            double lr[4][4], lcn[4][4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    lr[i][k] = sP[buf][k * NBI + 4 * tr + i];
+                    lcn[i][k] = sP[buf][k * NBI + 4 * tc + i];
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) a[i][kk] = fma(-lr[i][k], lcn[kk][k], a[i][kk]);
+        }
     }
-    for (int idx = t; idx < NBI * NBI; idx += 256) {
-        const int r = idx & (NBI - 1), c = idx >> 6;
-        if (r < nb && c < nb && r >= c) A[(int64_t)r + (int64_t)c * lda] = sd[r + c * LDD];
-    }
-    if (t == 0 && sfail != 0) atomicCAS(info, 0, k0 + sfail);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 4 * tr + i, col = 4 * tc + k;
+            if (row >= col && row < nb && col < nb) A[(int64_t)row + (int64_t)col * lda] = a[i][k];
+        }
+    if (fail != 0x7fffffff) atomicMin(&sfail, fail);
+    __syncthreads();
+    if (t == 0 && sfail != 0x7fffffff) atomicCAS(info, 0, k0 + sfail);
 }
 
 // ------------------------------------------------------------------ panel solve ------------
 // X * Lkk^T = Apanel.  Lkk: nb x nb lower at A[k0,k0]; panel rows r0..n-1, columns k0..k0+nb-1.
-// Full 64-column panels: one lane per row, the row lives in 64 fp64 registers, Lkk is broadcast
-// from LDS.  (Predicating the loads/stores on a run-time nb makes hipcc spill ~3800 registers, so
-// the ragged last panel goes through the generic kernel below instead.)
+// Each wavefront solves 16 rows with the MFMA-layout substitution core (solve64.h); a work-group
+// of 4 waves covers 64 rows, so even the last panels keep >= 1 wave per 16 rows in flight.
 __global__ __launch_bounds__(256) void panel_trsm_64_kernel(double* __restrict__ A, int64_t lda,
-                                                            int64_t n, int64_t k0, int64_t r0)
+                                                            int64_t n, int64_t k0, int nb, int64_t r0)
 {
-    // sLt[c][c2] = L[c2][c]  (column c of Lkk contiguous over c2)
-    __shared__ __attribute__((aligned(16))) double sLt[NBI * NBI];
+    __shared__ __attribute__((aligned(16))) double sM[NBI * S64_LS];
     const int t = threadIdx.x;
     for (int idx = t; idx < NBI * NBI; idx += 256) {
-        const int c2 = idx & (NBI - 1), c = idx >> 6;   // element L[c2][c], c2 >= c
-        sLt[c * NBI + c2] = (c2 >= c) ? A[(k0 + c2) + (k0 + c) * lda] : 0.0;
+        const int r = idx & (NBI - 1), c = idx >> 6;
+        double v = 0.0;
+        if (r < nb && c < nb && r >= c) v = A[(k0 + r) + (k0 + c) * lda];
+        else if (r == c) v = 1.0;
+        sM[c * S64_LS + r] = v;
     }
     __syncthreads();
-    const int64_t r = r0 + (int64_t)blockIdx.x * 256 + t;
-    if (r >= n) return;
-    double* row = A + r + k0 * lda;
-    double x[NBI];
+    const int lane = t & 63, wave = t >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int64_t row = r0 + (int64_t)blockIdx.x * 64 + wave * 16 + i;
+    const bool live = row < n;
+    d4 X[4];
 #pragma unroll
-    for (int c = 0; c < NBI; ++c) x[c] = row[c * lda];
+    for (int J = 0; J < 4; ++J)
 #pragma unroll
-    for (int c = 0; c < NBI; ++c) {
-        const double xc = x[c] / sLt[c * NBI + c];
-        x[c] = xc;
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * J + 4 * g + r;
+            X[J][r] = (live && c < nb) ? A[row + (k0 + c) * lda] : 0.0;
+        }
+    solve64_lower(X, sM);
+    if (live) {
 #pragma unroll
-        for (int c2 = c + 1; c2 < NBI; ++c2) x[c2] -= xc * sLt[c * NBI + c2];
+        for (int J = 0; J < 4; ++J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * J + 4 * g + r;
+                if (c < nb) A[row + (k0 + c) * lda] = X[J][r];
+            }
     }
-#pragma unroll
-    for (int c = 0; c < NBI; ++c) row[c * lda] = x[c];
-}
-
-// ragged panel (nb < 64): same substitution with the row kept in LDS; 64 rows per work-group
-__global__ __launch_bounds__(64) void panel_trsm_ragged_kernel(double* __restrict__ A, int64_t lda,
-                                                               int64_t n, int64_t k0, int nb,
-                                                               int64_t r0)
-{
-    __shared__ double sL[NBI * NBI];      // sL[c * 64 + c2] = L[c2][c]
-    __shared__ double sx[NBI * 64];       // sx[c * 64 + t]
-    const int t = threadIdx.x;
-    for (int idx = t; idx < nb * NBI; idx += 64) {
-        const int c2 = idx & (NBI - 1), c = idx >> 6;
-        sL[c * NBI + c2] = (c2 < nb && c2 >= c) ? A[(k0 + c2) + (k0 + c) * lda] : 0.0;
-    }
-    __syncthreads();
-    const int64_t r = r0 + (int64_t)blockIdx.x * 64 + t;
-    if (r >= n) return;
-    for (int c = 0; c < nb; ++c) sx[c * 64 + t] = A[r + (k0 + c) * lda];
-    for (int c = 0; c < nb; ++c) {
-        const double xc = sx[c * 64 + t] / sL[c * NBI + c];
-        sx[c * 64 + t] = xc;
-        for (int c2 = c + 1; c2 < nb; ++c2) sx[c2 * 64 + t] -= xc * sL[c * NBI + c2];
-    }
-    for (int c = 0; c < nb; ++c) A[r + (k0 + c) * lda] = sx[c * 64 + t];
 }
 
 __global__ void zero_upper_kernel(double* __restrict__ A, int64_t n, int64_t lda)
@@ -144,12 +187,8 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
             const int64_t r0 = k0 + nb;
             if (r0 >= n) break;
             const int64_t rows = n - r0;
-            if (nb == NBI)
-                hipLaunchKernelGGL(panel_trsm_64_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256),
-                                   0, stream, A, lda, n, k0, r0);
-            else
-                hipLaunchKernelGGL(panel_trsm_ragged_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64),
-                                   0, stream, A, lda, n, k0, nb, r0);
+            hipLaunchKernelGGL(panel_trsm_64_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, stream,
+                               A, lda, n, k0, nb, r0);
             if (r0 < c1) {
                 // rest of the outer panel: A[r0:n, r0:c1] -= A[r0:n, k0:r0] A[r0:c1, k0:r0]^T
                 GP_TRY(launch_gemm(h, stream, false, true, TRI_SYRK_LOWER, rows, c1 - r0, nb, -1.0,

@@ -11,6 +11,7 @@
 //   global traffic stays coalesced.
 #include "common.h"
 #include "kernels.h"
+#include "solve64.h"
 
 namespace gpirt {
 
@@ -18,63 +19,51 @@ namespace {
 
 constexpr int NL = 64;          // leaf rows
 constexpr int CB = 64;          // right-hand-side columns per work-group
-constexpr int LDT = NL + 1;
 
-// Solves the nb x nb system for 64 columns.  BACK = false: L x = b ; BACK = true: L^T x = b.
+// Solves the nb x nb system for 64 right-hand sides per work-group (16 per wavefront) with the
+// MFMA-layout substitution core.  BACK = false: L x = b.  BACK = true: L^T x = b, run as the same
+// forward substitution on the flipped transpose M'[a][b] = L[nb-1-b][nb-1-a] with the vector
+// entries visited in reverse order.
 template <bool BACK>
 __global__ __launch_bounds__(256) void trsm_leaf_kernel(const double* __restrict__ L, int64_t ldl,
                                                         int nb, double* __restrict__ B, int64_t ldb,
                                                         int64_t nrhs)
 {
-    // sL[c][c2]: for !BACK element L[c2][c] (column c of L, rows c2 >= c);
-    //            for  BACK element L[c][c2] (row c of L, columns c2 <= c).  Identity padded.
-    __shared__ __attribute__((aligned(16))) double sL[NL * NL];
-    __shared__ double sT[CB * LDT];     // sT[col][row]
+    __shared__ __attribute__((aligned(16))) double sM[NL * S64_LS];
     const int t = threadIdx.x;
     for (int idx = t; idx < NL * NL; idx += 256) {
-        const int r = idx & (NL - 1), c = idx >> 6;      // L[r][c] with r >= c is stored data
+        const int r = idx & (NL - 1), c = idx >> 6;       // M[r][c], r >= c
         double v = 0.0;
-        if (r < nb && c < nb && r >= c) v = L[(int64_t)r + (int64_t)c * ldl];
+        if (r < nb && c < nb && r >= c)
+            v = BACK ? L[(int64_t)(nb - 1 - c) + (int64_t)(nb - 1 - r) * ldl] : L[(int64_t)r + (int64_t)c * ldl];
         else if (r == c) v = 1.0;
-        if (!BACK) sL[c * NL + r] = v; else sL[r * NL + c] = v;
-    }
-    const int64_t col0 = (int64_t)blockIdx.x * CB;
-    // coalesced tile load: 64 rows x 64 columns
-    for (int idx = t; idx < NL * CB; idx += 256) {
-        const int r = idx & (NL - 1), c = idx >> 6;
-        double v = 0.0;
-        if (r < nb && col0 + c < nrhs) v = B[(int64_t)r + (col0 + c) * ldb];
-        sT[c * LDT + r] = v;
+        sM[c * S64_LS + r] = v;
     }
     __syncthreads();
-    if (t < CB) {
-        double x[NL];
+    const int lane = t & 63, wave = t >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int64_t col = (int64_t)blockIdx.x * CB + wave * 16 + i;
+    const bool live = col < nrhs;
+    double* b = B + col * ldb;
+    d4 X[4];
 #pragma unroll
-        for (int i = 0; i < NL; ++i) x[i] = sT[t * LDT + i];
-        if (!BACK) {
+    for (int J = 0; J < 4; ++J)
 #pragma unroll
-            for (int c = 0; c < NL; ++c) {
-                const double xc = x[c] / sL[c * NL + c];
-                x[c] = xc;
-#pragma unroll
-                for (int c2 = c + 1; c2 < NL; ++c2) x[c2] -= xc * sL[c * NL + c2];
-            }
-        } else {
-#pragma unroll
-            for (int c = NL - 1; c >= 0; --c) {
-                const double xc = x[c] / sL[c * NL + c];
-                x[c] = xc;
-#pragma unroll
-                for (int c2 = 0; c2 < c; ++c2) x[c2] -= xc * sL[c * NL + c2];
-            }
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * J + 4 * g + r;
+            const int p = BACK ? (nb - 1 - c) : c;
+            X[J][r] = (live && c < nb) ? b[p] : 0.0;
         }
+    solve64_lower(X, sM);
+    if (live) {
 #pragma unroll
-        for (int i = 0; i < NL; ++i) sT[t * LDT + i] = x[i];
-    }
-    __syncthreads();
-    for (int idx = t; idx < NL * CB; idx += 256) {
-        const int r = idx & (NL - 1), c = idx >> 6;
-        if (r < nb && col0 + c < nrhs) B[(int64_t)r + (col0 + c) * ldb] = sT[c * LDT + r];
+        for (int J = 0; J < 4; ++J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * J + 4 * g + r;
+                const int p = BACK ? (nb - 1 - c) : c;
+                if (c < nb) b[p] = X[J][r];
+            }
     }
 }
 
