@@ -26,10 +26,17 @@ namespace gpirt {
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16;
-constexpr int LDS_MN = BM + 16;      // [k][mn] row stride (doubles)
-constexpr int LDS_K  = BK + 2;       // [mn][k] row stride (doubles)
-constexpr int TILE_DOUBLES = 2304;   // == BK*LDS_MN == BM*LDS_K
+constexpr int BK = 16;
+constexpr int LDS_K = BK + 2;        // [mn][k] row stride (doubles)
+// Block tile T x T (T = 128: 4 x 4 MFMA tiles per wave, the throughput configuration;
+// T = 64: 2 x 2 tiles per wave, 4x as many work-groups and ~4x shorter k-steps -- used when the
+// 128-tile grid would leave most of the 256 CUs idle: panel updates, trsm levels, potrf tail).
+template <int T> struct Cfg {
+    static constexpr int LDS_MN = T + 16;                 // [k][mn] row stride (doubles)
+    static constexpr int TILE = (BK * (T + 16) > T * LDS_K) ? BK * (T + 16) : T * LDS_K;
+    static constexpr int NT = T / 32;                     // MFMA tiles per wave per dimension
+    static constexpr int PASSES = T / 32;                 // double2 loads per thread per operand tile
+};
 
 struct GemmParams {
     const double* A; const double* B; double* C;
@@ -41,16 +48,20 @@ struct GemmParams {
     int fastA, fastB;     // operand base/ld are 16-byte friendly
 };
 
-template <bool KCONTIG>
+template <bool KCONTIG, int T>
 __device__ __forceinline__ void load_tile(const double* __restrict__ G, int64_t ld, int mn0,
-                                          int mnmax, int k0, int kmax, bool fast, double2 (&reg)[4])
+                                          int mnmax, int k0, int kmax, bool fast,
+                                          double2 (&reg)[Cfg<T>::PASSES])
 {
     const int t = threadIdx.x;
+    constexpr int P = Cfg<T>::PASSES;
+    constexpr int TPC = T / 2;              // threads per column of the [k][mn] image
+    constexpr int CPP = 256 / TPC;          // columns per pass
     if (!KCONTIG) {
-        const int r2 = (t & 63) * 2;
+        const int r2 = (t % TPC) * 2;
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            const int c = (t >> 6) + 4 * pass;
+        for (int pass = 0; pass < P; ++pass) {
+            const int c = (t / TPC) + CPP * pass;
             const double* p = G + (int64_t)(mn0 + r2) + (int64_t)(k0 + c) * ld;
             if (fast) {
                 reg[pass] = *reinterpret_cast<const double2*>(p);
@@ -63,7 +74,7 @@ __device__ __forceinline__ void load_tile(const double* __restrict__ G, int64_t 
     } else {
         const int k2 = (t & 7) * 2;
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
+        for (int pass = 0; pass < P; ++pass) {
             const int mn = (t >> 3) + 32 * pass;
             const double* p = G + (int64_t)(k0 + k2) + (int64_t)(mn0 + mn) * ld;
             if (fast) {
@@ -77,21 +88,23 @@ __device__ __forceinline__ void load_tile(const double* __restrict__ G, int64_t 
     }
 }
 
-template <bool KCONTIG>
-__device__ __forceinline__ void store_tile(double* __restrict__ s, const double2 (&reg)[4])
+template <bool KCONTIG, int T>
+__device__ __forceinline__ void store_tile(double* __restrict__ s, const double2 (&reg)[Cfg<T>::PASSES])
 {
     const int t = threadIdx.x;
+    constexpr int P = Cfg<T>::PASSES;
+    constexpr int TPC = T / 2, CPP = 256 / TPC, LDS_MN = Cfg<T>::LDS_MN;
     if (!KCONTIG) {
-        const int r2 = (t & 63) * 2;
+        const int r2 = (t % TPC) * 2;
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            const int c = (t >> 6) + 4 * pass;
+        for (int pass = 0; pass < P; ++pass) {
+            const int c = (t / TPC) + CPP * pass;
             *reinterpret_cast<double2*>(&s[c * LDS_MN + r2]) = reg[pass];
         }
     } else {
         const int k2 = (t & 7) * 2;
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
+        for (int pass = 0; pass < P; ++pass) {
             const int mn = (t >> 3) + 32 * pass;
             *reinterpret_cast<double2*>(&s[mn * LDS_K + k2]) = reg[pass];
         }
@@ -100,9 +113,11 @@ __device__ __forceinline__ void store_tile(double* __restrict__ s, const double2
 
 // TA: A is stored K x M (op(A) = A^T)  -> K-contiguous.   !TA: stored M x K -> M-contiguous.
 // TB: B is stored N x K (op(B) = B^T)  -> N-contiguous.   !TB: stored K x N -> K-contiguous.
-template <bool TA, bool TB>
+template <bool TA, bool TB, int T>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p)
 {
+    constexpr int BM = T, BN = T, LDS_MN = Cfg<T>::LDS_MN, TILE_DOUBLES = Cfg<T>::TILE, NT = Cfg<T>::NT;
+    constexpr int WT = T / 2;                // wave tile edge
     __shared__ __attribute__((aligned(16))) double smem[4 * TILE_DOUBLES];
     double* sA = smem;                       // [2][TILE]
     double* sB = smem + 2 * TILE_DOUBLES;    // [2][TILE]
@@ -137,20 +152,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p)
     const int wm = wave & 1, wn = wave >> 1;
     const int l15 = lane & 15, l4 = lane >> 4;
 
-    d4 acc[4][4];
+    d4 acc[NT][NT];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+        for (int b = 0; b < NT; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
 
     const int nk = (kend - kbeg + BK - 1) / BK;
-    double2 ra[4], rb[4];
+    double2 ra[Cfg<T>::PASSES], rb[Cfg<T>::PASSES];
     if (nk > 0) {
         const bool kfull = (kbeg + BK <= p.K);
-        load_tile<A_KC>(p.A, p.lda, i0, p.M, kbeg, p.K, fullA && kfull, ra);
-        load_tile<B_KC>(p.B, p.ldb, j0, p.N, kbeg, p.K, fullB && kfull, rb);
-        store_tile<A_KC>(sA, ra);
-        store_tile<B_KC>(sB, rb);
+        load_tile<A_KC, T>(p.A, p.lda, i0, p.M, kbeg, p.K, fullA && kfull, ra);
+        load_tile<B_KC, T>(p.B, p.ldb, j0, p.N, kbeg, p.K, fullB && kfull, rb);
+        store_tile<A_KC, T>(sA, ra);
+        store_tile<B_KC, T>(sB, rb);
     }
     __syncthreads();
 
@@ -160,31 +175,31 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p)
         if (more) {
             const int k0 = kbeg + (kt + 1) * BK;
             const bool kfull = (k0 + BK <= p.K);
-            load_tile<A_KC>(p.A, p.lda, i0, p.M, k0, p.K, fullA && kfull, ra);
-            load_tile<B_KC>(p.B, p.ldb, j0, p.N, k0, p.K, fullB && kfull, rb);
+            load_tile<A_KC, T>(p.A, p.lda, i0, p.M, k0, p.K, fullA && kfull, ra);
+            load_tile<B_KC, T>(p.B, p.ldb, j0, p.N, k0, p.K, fullB && kfull, rb);
         }
         const double* cA = sA + buf * TILE_DOUBLES;
         const double* cB = sB + buf * TILE_DOUBLES;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            double a[4], b[4];
+            double a[NT], b[NT];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int mi = wm * 64 + t * 16 + l15;
-                const int ni = wn * 64 + t * 16 + l15;
+            for (int t = 0; t < NT; ++t) {
+                const int mi = wm * WT + t * 16 + l15;
+                const int ni = wn * WT + t * 16 + l15;
                 const int kq = kk * 4 + l4;
                 a[t] = A_KC ? cA[mi * LDS_K + kq] : cA[kq * LDS_MN + mi];
                 b[t] = B_KC ? cB[ni * LDS_K + kq] : cB[kq * LDS_MN + ni];
             }
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
+            for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
-                for (int tm = 0; tm < 4; ++tm)
+                for (int tm = 0; tm < NT; ++tm)
                     acc[tn][tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[tn], a[tm], acc[tn][tm], 0, 0, 0);
         }
         if (more) {
-            store_tile<A_KC>(sA + (buf ^ 1) * TILE_DOUBLES, ra);
-            store_tile<B_KC>(sB + (buf ^ 1) * TILE_DOUBLES, rb);
+            store_tile<A_KC, T>(sA + (buf ^ 1) * TILE_DOUBLES, ra);
+            store_tile<B_KC, T>(sB + (buf ^ 1) * TILE_DOUBLES, rb);
         }
         __syncthreads();
     }
@@ -197,25 +212,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p)
     const bool lower_mask = (p.tri == TRI_SYRK_LOWER) && (bi == bj);
     const bool use_c = (beta != 0.0);
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn) {
-        double cv[4][4];
+    for (int tn = 0; tn < NT; ++tn) {
+        double cv[4][NT];
         if (use_c) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int n = j0 + wn * 64 + tn * 16 + l4 + 4 * r;
+                const int n = j0 + wn * WT + tn * 16 + l4 + 4 * r;
 #pragma unroll
-                for (int tm = 0; tm < 4; ++tm) {
-                    const int m = i0 + wm * 64 + tm * 16 + l15;
+                for (int tm = 0; tm < NT; ++tm) {
+                    const int m = i0 + wm * WT + tm * 16 + l15;
                     cv[r][tm] = (interior || (m < p.M && n < p.N)) ? p.C[(int64_t)m + (int64_t)n * p.ldc] : 0.0;
                 }
             }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int n = j0 + wn * 64 + tn * 16 + l4 + 4 * r;
+            const int n = j0 + wn * WT + tn * 16 + l4 + 4 * r;
 #pragma unroll
-            for (int tm = 0; tm < 4; ++tm) {
-                const int m = i0 + wm * 64 + tm * 16 + l15;
+            for (int tm = 0; tm < NT; ++tm) {
+                const int m = i0 + wm * WT + tm * 16 + l15;
                 if ((interior || (m < p.M && n < p.N)) && !(lower_mask && m < n)) {
                     double v = alpha * acc[tn][tm][r];
                     if (use_c) v += beta * cv[r][tm];
@@ -228,6 +243,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p)
 
 }  // namespace
 
+template <int T>
+static int launch_gemm_t(hipStream_t stream, bool ta, bool tb, GemmParams p)
+{
+    p.mblocks = (p.M + T - 1) / T;
+    p.nblocks = (p.N + T - 1) / T;
+    int64_t grid;
+    if (p.tri == TRI_SYRK_LOWER) grid = (int64_t)p.nblocks * p.mblocks - (int64_t)p.nblocks * (p.nblocks - 1) / 2;
+    else grid = (int64_t)p.mblocks * p.nblocks;
+    dim3 g((unsigned)grid), b(256);
+    if (!ta && tb)       hipLaunchKernelGGL((gemm_f64_kernel<false, true, T>),  g, b, 0, stream, p);
+    else if (!ta && !tb) hipLaunchKernelGGL((gemm_f64_kernel<false, false, T>), g, b, 0, stream, p);
+    else if (ta && !tb)  hipLaunchKernelGGL((gemm_f64_kernel<true, false, T>),  g, b, 0, stream, p);
+    else                 hipLaunchKernelGGL((gemm_f64_kernel<true, true, T>),   g, b, 0, stream, p);
+    GP_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri, int64_t M,
                 int64_t N, int64_t K, double alpha, const double* A, int64_t lda, const double* B,
                 int64_t ldb, double beta, double* C, int64_t ldc)
@@ -239,24 +271,15 @@ int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri,
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.M = (int)M; p.N = (int)N; p.K = (int)K;
     p.alpha = alpha; p.beta = beta; p.tri = tri;
-    p.mblocks = (int)((M + BM - 1) / BM);
-    p.nblocks = (int)((N + BN - 1) / BN);
+    p.mblocks = p.nblocks = 0;
     p.fastA = (((uintptr_t)A & 15) == 0) && (lda % 2 == 0);
     p.fastB = (((uintptr_t)B & 15) == 0) && (ldb % 2 == 0);
-    int64_t grid;
-    if (tri == TRI_SYRK_LOWER) {
-        if (M < N) { set_error("syrk mode needs M >= N"); return GPIRT_E_ARG; }
-        grid = (int64_t)p.nblocks * p.mblocks - (int64_t)p.nblocks * (p.nblocks - 1) / 2;
-    } else {
-        grid = (int64_t)p.mblocks * p.nblocks;
-    }
-    dim3 g((unsigned)grid), b(256);
-    if (!ta && tb)       hipLaunchKernelGGL((gemm_f64_kernel<false, true>),  g, b, 0, stream, p);
-    else if (!ta && !tb) hipLaunchKernelGGL((gemm_f64_kernel<false, false>), g, b, 0, stream, p);
-    else if (ta && !tb)  hipLaunchKernelGGL((gemm_f64_kernel<true, false>),  g, b, 0, stream, p);
-    else                 hipLaunchKernelGGL((gemm_f64_kernel<true, true>),   g, b, 0, stream, p);
-    GP_HIP(hipGetLastError());
-    return 0;
+    if (tri == TRI_SYRK_LOWER && M < N) { set_error("syrk mode needs M >= N"); return GPIRT_E_ARG; }
+    // 128-tiles when they already give every CU >= 2 work-groups, 64-tiles otherwise
+    const int64_t mb = (M + 127) / 128, nb = (N + 127) / 128;
+    const int64_t blocks128 = (tri == TRI_SYRK_LOWER) ? nb * mb - nb * (nb - 1) / 2 : mb * nb;
+    if (blocks128 >= 448) return launch_gemm_t<128>(stream, ta, tb, p);
+    return launch_gemm_t<64>(stream, ta, tb, p);
 }
 
 }  // namespace gpirt
