@@ -117,6 +117,9 @@ int gpirt_destroy(gpirt_handle_t h)
     if (h->d_work) hipFree(h->d_work);
     for (auto& pp : h->prof.pending) { hipEventDestroy(pp.e0); hipEventDestroy(pp.e1); }
     for (auto& pp : h->prof.free_pairs) { hipEventDestroy(pp.e0); hipEventDestroy(pp.e1); }
+    if (h->side) hipStreamDestroy(h->side);
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
     return 0;

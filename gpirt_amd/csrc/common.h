@@ -64,6 +64,9 @@ struct gpirt_handle_s {
     double*      d_work = nullptr;       // generic scratch (grown on demand)
     size_t       work_bytes = 0;
     gpirt::Prof  prof;
+    // look-ahead Cholesky: high-priority side stream for the panel chain + fork/join events
+    hipStream_t  side = nullptr;
+    hipEvent_t   ev_fork = nullptr, ev_join = nullptr;
 };
 
 namespace gpirt {

@@ -114,30 +114,12 @@ __device__ __forceinline__ void store_tile(double* __restrict__ s, const double2
 // TA: A is stored K x M (op(A) = A^T)  -> K-contiguous.   !TA: stored M x K -> M-contiguous.
 // TB: B is stored N x K (op(B) = B^T)  -> N-contiguous.   !TB: stored K x N -> K-contiguous.
 template <bool TA, bool TB, int T>
-__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p)
+__device__ __forceinline__ void gemm_tile(const GemmParams& p, const int bi, const int bj, double* smem)
 {
     constexpr int BM = T, BN = T, LDS_MN = Cfg<T>::LDS_MN, TILE_DOUBLES = Cfg<T>::TILE, NT = Cfg<T>::NT;
     constexpr int WT = T / 2;                // wave tile edge
-    __shared__ __attribute__((aligned(16))) double smem[4 * TILE_DOUBLES];
     double* sA = smem;                       // [2][TILE]
     double* sB = smem + 2 * TILE_DOUBLES;    // [2][TILE]
-
-    int bi, bj;
-    if (p.tri == TRI_SYRK_LOWER) {
-        // block columns bj = 0..nblocks-1, each holding block rows bj..mblocks-1 (M >= N trapezoid)
-        const int t = blockIdx.x, mb = p.mblocks;
-        const double q = 2.0 * mb + 1.0;
-        int c = (int)((q - sqrt(q * q - 8.0 * (double)t)) * 0.5);
-        if (c < 0) c = 0;
-        if (c > p.nblocks - 1) c = p.nblocks - 1;
-        while (c > 0 && c * mb - c * (c - 1) / 2 > t) --c;
-        while (c + 1 < p.nblocks && (c + 1) * mb - (c + 1) * c / 2 <= t) ++c;
-        bj = c;
-        bi = c + (t - (c * mb - c * (c - 1) / 2));
-    } else {
-        bi = blockIdx.x % p.mblocks;
-        bj = blockIdx.x / p.mblocks;
-    }
     const int i0 = bi * BM, j0 = bj * BN;
 
     int kbeg = 0, kend = p.K;
@@ -241,7 +223,55 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p)
     }
 }
 
+// PAD > 0 inflates the static LDS footprint past half a CU so only ONE work-group is resident per
+// CU: ~7 % less MFMA throughput, but every CU keeps LDS, registers and wave slots free for the
+// latency-bound Cholesky panel kernels that run concurrently on the side stream (look-ahead).
+template <bool TA, bool TB, int T, int PAD = 0>
+__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p)
+{
+    __shared__ __attribute__((aligned(16))) double smem[4 * Cfg<T>::TILE + PAD];
+    int bi, bj;
+    if (p.tri == TRI_SYRK_LOWER) {
+        // block columns bj = 0..nblocks-1, each holding block rows bj..mblocks-1 (M >= N trapezoid)
+        const int t = blockIdx.x, mb = p.mblocks;
+        const double q = 2.0 * mb + 1.0;
+        int c = (int)((q - sqrt(q * q - 8.0 * (double)t)) * 0.5);
+        if (c < 0) c = 0;
+        if (c > p.nblocks - 1) c = p.nblocks - 1;
+        while (c > 0 && c * mb - c * (c - 1) / 2 > t) --c;
+        while (c + 1 < p.nblocks && (c + 1) * mb - (c + 1) * c / 2 <= t) ++c;
+        bj = c;
+        bi = c + (t - (c * mb - c * (c - 1) / 2));
+    } else if (p.tri == TRI_A_LOWER || p.tri == TRI_A_UPPER) {
+        // triangular A: the K range of block row bi grows (or shrinks) linearly with bi, so each
+        // work-group takes the pair (mblocks-1-q, q): every work-group then carries the same
+        // number of k-steps instead of the last block rows setting the kernel's duration.
+        const int half = (p.mblocks + 1) / 2;
+        const int q = blockIdx.x % half;
+        bj = blockIdx.x / half;
+        bi = p.mblocks - 1 - q;
+        gemm_tile<TA, TB, T>(p, bi, bj, smem);
+        if (q == bi) return;
+        bi = q;
+    } else {
+        bi = blockIdx.x % p.mblocks;
+        bj = blockIdx.x / p.mblocks;
+    }
+    gemm_tile<TA, TB, T>(p, bi, bj, smem);
+}
+
 }  // namespace
+
+static int launch_gemm_shared(hipStream_t stream, GemmParams p)
+{
+    constexpr int T = 128;
+    p.mblocks = (p.M + T - 1) / T;
+    p.nblocks = (p.N + T - 1) / T;
+    const int64_t grid = (int64_t)p.nblocks * p.mblocks - (int64_t)p.nblocks * (p.nblocks - 1) / 2;
+    hipLaunchKernelGGL((gemm_f64_kernel<false, true, 128, 1100>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    GP_HIP(hipGetLastError());
+    return 0;
+}
 
 template <int T>
 static int launch_gemm_t(hipStream_t stream, bool ta, bool tb, GemmParams p)
@@ -250,6 +280,7 @@ static int launch_gemm_t(hipStream_t stream, bool ta, bool tb, GemmParams p)
     p.nblocks = (p.N + T - 1) / T;
     int64_t grid;
     if (p.tri == TRI_SYRK_LOWER) grid = (int64_t)p.nblocks * p.mblocks - (int64_t)p.nblocks * (p.nblocks - 1) / 2;
+    else if (p.tri == TRI_A_LOWER || p.tri == TRI_A_UPPER) grid = (int64_t)((p.mblocks + 1) / 2) * p.nblocks;
     else grid = (int64_t)p.mblocks * p.nblocks;
     dim3 g((unsigned)grid), b(256);
     if (!ta && tb)       hipLaunchKernelGGL((gemm_f64_kernel<false, true, T>),  g, b, 0, stream, p);
@@ -274,10 +305,16 @@ int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri,
     p.mblocks = p.nblocks = 0;
     p.fastA = (((uintptr_t)A & 15) == 0) && (lda % 2 == 0);
     p.fastB = (((uintptr_t)B & 15) == 0) && (ldb % 2 == 0);
+    if (tri == TRI_SYRK_LOWER_SHARED) {
+        p.tri = TRI_SYRK_LOWER;
+        if (M < N || ta || !tb) { set_error("shared syrk mode needs the NT form and M >= N"); return GPIRT_E_ARG; }
+        return launch_gemm_shared(stream, p);
+    }
     if (tri == TRI_SYRK_LOWER && M < N) { set_error("syrk mode needs M >= N"); return GPIRT_E_ARG; }
     // 128-tiles when they already give every CU >= 2 work-groups, 64-tiles otherwise
     const int64_t mb = (M + 127) / 128, nb = (N + 127) / 128;
-    const int64_t blocks128 = (tri == TRI_SYRK_LOWER) ? nb * mb - nb * (nb - 1) / 2 : mb * nb;
+    int64_t blocks128 = (tri == TRI_SYRK_LOWER) ? nb * mb - nb * (nb - 1) / 2 : mb * nb;
+    if (tri == TRI_A_LOWER || tri == TRI_A_UPPER) blocks128 *= 2;     // paired: one work-group per CU suffices
     if (blocks128 >= 448) return launch_gemm_t<128>(stream, ta, tb, p);
     return launch_gemm_t<64>(stream, ta, tb, p);
 }

@@ -5,7 +5,7 @@
 
 namespace gpirt {
 
-enum { TRI_NONE = 0, TRI_SYRK_LOWER = 1, TRI_A_LOWER = 2, TRI_A_UPPER = 3 };
+enum { TRI_NONE = 0, TRI_SYRK_LOWER = 1, TRI_A_LOWER = 2, TRI_A_UPPER = 3, TRI_SYRK_LOWER_SHARED = 4 };
 
 // gemm_f64.hip
 int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri, int64_t M,

@@ -18,6 +18,8 @@
 #include "kernels.h"
 #include "solve64.h"
 
+#include <stdlib.h>
+
 namespace gpirt {
 
 namespace {
@@ -44,6 +46,7 @@ __global__ __launch_bounds__(256) void potf2_64_kernel(double* __restrict__ A, i
 {
     __shared__ __attribute__((aligned(16))) double sP[2][4 * NBI];   // sP[buf][k * 64 + row]
     __shared__ int sfail;
+    __builtin_amdgcn_s_setprio(3);   // latency-bound chain: win issue arbitration against co-resident GEMM waves
     const int t = threadIdx.x;
     const int tr = t & 15, tc = t >> 4;
     double a[4][4];                                                   // a[i][k]: row 4tr+i, col 4tc+k
@@ -130,13 +133,24 @@ __global__ __launch_bounds__(256) void panel_trsm_64_kernel(double* __restrict__
                                                             int64_t n, int64_t k0, int nb, int64_t r0)
 {
     __shared__ __attribute__((aligned(16))) double sM[NBI * S64_LS];
+    __builtin_amdgcn_s_setprio(3);
     const int t = threadIdx.x;
-    for (int idx = t; idx < NBI * NBI; idx += 256) {
-        const int r = idx & (NBI - 1), c = idx >> 6;
-        double v = 0.0;
-        if (r < nb && c < nb && r >= c) v = A[(k0 + r) + (k0 + c) * lda];
-        else if (r == c) v = 1.0;
-        sM[c * S64_LS + r] = v;
+    {
+        double v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {                // 16 loads in flight, then 16 LDS stores
+            const int idx = t + 256 * k;
+            const int r = idx & (NBI - 1), c = idx >> 6;
+            double x = 0.0;
+            if (r < nb && c < nb && r >= c) x = A[(k0 + r) + (k0 + c) * lda];
+            else if (r == c) x = 1.0;
+            v[k] = x;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int idx = t + 256 * k;
+            sM[(idx >> 6) * S64_LS + (idx & (NBI - 1))] = v[k];
+        }
     }
     __syncthreads();
     const int lane = t & 63, wave = t >> 6;
@@ -172,46 +186,101 @@ __global__ void zero_upper_kernel(double* __restrict__ A, int64_t n, int64_t lda
 
 }  // namespace
 
+namespace {
+
+// inner loop of one outer panel: columns [K0, c1), every row below; 64-column steps
+int factor_panel(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t K0, int64_t c1)
+{
+    for (int64_t k0 = K0; k0 < c1; k0 += NBI) {
+        const int nb = (int)((c1 - k0) < NBI ? (c1 - k0) : NBI);
+        hipLaunchKernelGGL(potf2_64_kernel, dim3(1), dim3(256), 0, stream, A + k0 + k0 * lda, lda, nb, (int)k0,
+                           h->d_info);
+        const int64_t r0 = k0 + nb;
+        if (r0 >= n) break;
+        const int64_t rows = n - r0;
+        hipLaunchKernelGGL(panel_trsm_64_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, stream, A, lda,
+                           n, k0, nb, r0);
+        if (r0 < c1) {
+            // rest of the outer panel: A[r0:n, r0:c1] -= A[r0:n, k0:r0] A[r0:c1, k0:r0]^T
+            GP_TRY(launch_gemm(h, stream, false, true, TRI_SYRK_LOWER, rows, c1 - r0, nb, -1.0,
+                               A + r0 + k0 * lda, lda, A + r0 + k0 * lda, lda, 1.0, A + r0 + r0 * lda, lda));
+        }
+    }
+    return 0;
+}
+
+// trailing update restricted to the column range [lo, hi):
+//   A[lo:n, lo:hi] -= A[lo:n, K0:c1] A[lo:hi, K0:c1]^T      (lower trapezoid, fp64 MFMA syrk)
+int trailing(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t K0, int64_t c1,
+             int64_t lo, int64_t hi, bool shared = false)
+{
+    const bool prof = h->prof.enabled;
+    ProfPair pp{nullptr, nullptr, 0.0};
+    if (prof) {
+        if (!h->prof.free_pairs.empty()) { pp = h->prof.free_pairs.back(); h->prof.free_pairs.pop_back(); }
+        else { GP_HIP(hipEventCreate(&pp.e0)); GP_HIP(hipEventCreate(&pp.e1)); }
+        GP_HIP(hipEventRecord(pp.e0, stream));
+    }
+    const int64_t M = n - lo, N = hi - lo, K = c1 - K0;
+    GP_TRY(launch_gemm(h, stream, false, true, shared ? TRI_SYRK_LOWER_SHARED : TRI_SYRK_LOWER, M, N, K, -1.0,
+                       A + lo + K0 * lda, lda, A + lo + K0 * lda, lda, 1.0, A + lo + lo * lda, lda));
+    if (prof) {
+        GP_HIP(hipEventRecord(pp.e1, stream));
+        // algorithmic flops of the lower trapezoid: 2 K (M N - N (N - 1) / 2)
+        pp.flops = 2.0 * (double)K * ((double)M * (double)N - 0.5 * (double)N * (double)(N - 1));
+        h->prof.pending.push_back(pp);
+    }
+    return 0;
+}
+
+int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    const int x = atoi(v);
+    return x > 0 ? x : dflt;
+}
+
+}  // namespace
+
+// Look-ahead schedule: the trailing update of panel p is split into the columns of panel p+1
+// (done first, on the main stream) and the rest; panel p+1 is then factored on a high-priority
+// side stream WHILE the rest of update p runs on the main stream.  The panel chain (128 dependent
+// diagonal-block factorisations for n = 8192) is latency-bound and would otherwise serialise with
+// the MFMA-bound trailing updates.
 int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda,
                        bool zero_upper)
 {
     if (n <= 0) return 0;
+    static const int nbo_env = env_int("GPIRT_NBO", NBO);
+    static const int lookahead = env_int("GPIRT_LOOKAHEAD", 1);
+    static const int shared_occ = env_int("GPIRT_SHARED_OCC", 1);
+    const int64_t nbo = (nbo_env / NBI) * NBI > 0 ? (nbo_env / NBI) * NBI : NBO;
     GP_HIP(hipMemsetAsync(h->d_info, 0, sizeof(int), stream));
-    const bool prof = h->prof.enabled;
-    for (int64_t K0 = 0; K0 < n; K0 += NBO) {
-        const int64_t c1 = (K0 + NBO < n) ? K0 + NBO : n;      // end of this outer panel
-        for (int64_t k0 = K0; k0 < c1; k0 += NBI) {
-            const int nb = (int)((c1 - k0) < NBI ? (c1 - k0) : NBI);
-            hipLaunchKernelGGL(potf2_64_kernel, dim3(1), dim3(256), 0, stream,
-                               A + k0 + k0 * lda, lda, nb, (int)k0, h->d_info);
-            const int64_t r0 = k0 + nb;
-            if (r0 >= n) break;
-            const int64_t rows = n - r0;
-            hipLaunchKernelGGL(panel_trsm_64_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, stream,
-                               A, lda, n, k0, nb, r0);
-            if (r0 < c1) {
-                // rest of the outer panel: A[r0:n, r0:c1] -= A[r0:n, k0:r0] A[r0:c1, k0:r0]^T
-                GP_TRY(launch_gemm(h, stream, false, true, TRI_SYRK_LOWER, rows, c1 - r0, nb, -1.0,
-                                   A + r0 + k0 * lda, lda, A + r0 + k0 * lda, lda, 1.0,
-                                   A + r0 + r0 * lda, lda));
-            }
-        }
-        if (c1 < n) {
-            const int64_t rows = n - c1;
-            ProfPair pp{nullptr, nullptr, 0.0};
-            if (prof) {
-                if (!h->prof.free_pairs.empty()) { pp = h->prof.free_pairs.back(); h->prof.free_pairs.pop_back(); }
-                else { GP_HIP(hipEventCreate(&pp.e0)); GP_HIP(hipEventCreate(&pp.e1)); }
-                GP_HIP(hipEventRecord(pp.e0, stream));
-            }
-            GP_TRY(launch_gemm(h, stream, false, true, TRI_SYRK_LOWER, rows, rows, c1 - K0, -1.0,
-                               A + c1 + K0 * lda, lda, A + c1 + K0 * lda, lda, 1.0,
-                               A + c1 + c1 * lda, lda));
-            if (prof) {
-                GP_HIP(hipEventRecord(pp.e1, stream));
-                pp.flops = (double)rows * (double)rows * (double)(c1 - K0);   // n^2 k (lower half, 2 flop/fma)
-                h->prof.pending.push_back(pp);
-            }
+    const bool la = (lookahead == 1) && (n > 2 * nbo);
+    if (la && !h->side) {
+        int lo_pri = 0, hi_pri = 0;
+        GP_HIP(hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
+        GP_HIP(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, hi_pri));
+        GP_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        GP_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
+    GP_TRY(factor_panel(h, stream, A, n, lda, 0, nbo < n ? nbo : n));
+    for (int64_t K0 = 0; K0 < n; K0 += nbo) {
+        const int64_t c1 = (K0 + nbo < n) ? K0 + nbo : n;
+        if (c1 >= n) break;
+        const int64_t c2 = (c1 + nbo < n) ? c1 + nbo : n;
+        GP_TRY(trailing(h, stream, A, n, lda, K0, c1, c1, c2));           // columns of the next panel
+        if (la && c2 < n) {
+            GP_HIP(hipEventRecord(h->ev_fork, stream));
+            GP_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+            GP_TRY(factor_panel(h, h->side, A, n, lda, c1, c2));          // next panel, side stream
+            GP_TRY(trailing(h, stream, A, n, lda, K0, c1, c2, n, shared_occ == 1));  // the rest, concurrently
+            GP_HIP(hipEventRecord(h->ev_join, h->side));
+            GP_HIP(hipStreamWaitEvent(stream, h->ev_join, 0));
+        } else {
+            if (c2 < n) GP_TRY(trailing(h, stream, A, n, lda, K0, c1, c2, n));
+            GP_TRY(factor_panel(h, stream, A, n, lda, c1, c2));
         }
     }
     if (zero_upper) {

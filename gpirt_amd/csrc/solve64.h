@@ -7,9 +7,11 @@
 // 16J + 4g + r (r = 0..3) of vector i.  With that layout
 //   * the off-diagonal work  x_J -= M[J,I] x_I  (I < J) is 4 MFMAs per block pair whose B operand
 //     is literally the registers that hold x_I -- no shuffle, no LDS round trip for x;
-//   * only the 16 x 16 diagonal blocks are solved by substitution: 16 steps, each one division,
-//     one cross-lane broadcast (ds_bpermute from the owning 16-lane group) and 4 FMAs per lane,
-//     with the block's coefficients pre-loaded into registers so no step waits on LDS.
+//   * only the 16 x 16 diagonal blocks are solved by substitution, in four group steps: a lane
+//     group owns four consecutive columns, so each 4 x 4 diagonal sub-block is solved inside the
+//     lane, broadcast once (ds_bpermute from the owning 16-lane group) and folded into the other
+//     columns with 16 FMAs per lane; coefficients and pivot reciprocals are in registers before
+//     the dependent chain starts, so no step waits on LDS or on a division.
 // True substitution throughout (no inverted blocks): S = K + 1e-3 I has condition ~1e6 here.
 #pragma once
 
@@ -17,7 +19,7 @@
 
 namespace gpirt {
 
-constexpr int S64_LS = 80;     // LDS column stride (doubles): 64 + 16 keeps both read patterns conflict-free
+constexpr int S64_LS = 84;     // LDS column stride (doubles): 4 columns apart = 16 (mod 32) 8-byte banks
 
 // sM[c * S64_LS + r] = M[r][c] for r >= c (lower triangle incl. diagonal), zeros above.
 __device__ __forceinline__ void solve64_lower(d4 (&X)[4], const double* __restrict__ sM)
@@ -37,29 +39,72 @@ __device__ __forceinline__ void solve64_lower(d4 (&X)[4], const double* __restri
             for (int s = 0; s < 4; ++s)
                 X[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], X[I][s], X[J], 0, 0, 0);
         }
-        // ---- diagonal block: coefficients of this lane's four columns, all 16 steps, up front
-        double Ld[16][4];
-        double dj[16];
+        // ---- 16 x 16 diagonal block in four group steps.  Lane group gq owns columns 4gq..4gq+3 of
+        // every vector, so the 4 x 4 diagonal sub-block is solved inside the lane (no cross-lane
+        // traffic), the four results are broadcast once from the owner group (ds_bpermute) and
+        // every lane folds them into its own four columns.  Reciprocals of the pivots are formed
+        // up front (off the dependent chain); coefficients come from LDS before the chain starts.
+        double C[4][4][4];                         // C[gq][r][q] = M[16J+4g+r][16J+4gq+q]
+        double rinv[4];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const double* col = sM + (16 * J + j) * S64_LS + 16 * J;
-            dj[j] = col[j];
+        for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Ld[j][r] = col[4 * g + r];
-        }
+            for (int q = 0; q < 4; ++q) {
+                const double* col = sM + (16 * J + 4 * gq + q) * S64_LS + 16 * J + 4 * g;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int gj = j >> 2, rj = j & 3;
-            const double t = X[J][rj] / dj[j];                       // valid on the owner group
-            const int src = (i | (gj << 4)) << 2;                    // byte address for bpermute
-            const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(t));
-            const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(t));
-            const double xj = __hiloint2double(hi, lo);
+                for (int r = 0; r < 4; ++r) C[gq][r][q] = col[r];
+            }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) X[J][r] = fma(-xj, Ld[j][r], X[J][r]);
-            if (g == gj) X[J][rj] = xj;
+        for (int r = 0; r < 4; ++r) rinv[r] = 1.0 / sM[(16 * J + 4 * g + r) * S64_LS + 16 * J + 4 * g + r];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            // in-lane 4 x 4 forward substitution with this lane's OWN diagonal sub-block
+            // (meaningful on the owner group g == gq; the other groups' results are discarded)
+            double x[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double acc = X[J][r];
+#pragma unroll
+                for (int q = 0; q < r; ++q) acc = fma(-C[gq][r][q], x[q], acc);
+                x[r] = acc * rinv[r];
+            }
+            const int src = (i | (gq << 4)) << 2;
+            double xb[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(x[r]));
+                const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(x[r]));
+                xb[r] = __hiloint2double(hi, lo);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double acc = X[J][r];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = fma(-C[gq][r][q], xb[q], acc);   // zero above the diagonal
+                X[J][r] = (g == gq) ? xb[r] : acc;
+            }
         }
     }
+}
+
+// X_J -= T X_I for one 64 x 64 coefficient block T (sT[c * S64_LS + r] = T[r][c], full block):
+// the off-diagonal step between two 64-row blocks of a taller solve.  64 MFMAs per wavefront.
+__device__ __forceinline__ void strip64_update(d4 (&XJ)[4], const d4 (&XI)[4], const double* __restrict__ sT)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, g = lane >> 4;
+    const int pi = 4 * (i & 3) + (i >> 2);
+#pragma unroll
+    for (int J = 0; J < 4; ++J)
+#pragma unroll
+        for (int I = 0; I < 4; ++I) {
+            double a[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) a[s] = -sT[(16 * I + 4 * g + s) * S64_LS + 16 * J + pi];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                XJ[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], XI[I][s], XJ[J], 0, 0, 0);
+        }
 }
 
 }  // namespace gpirt

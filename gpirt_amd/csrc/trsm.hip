@@ -20,6 +20,35 @@ namespace {
 constexpr int NL = 64;          // leaf rows
 constexpr int CB = 64;          // right-hand-side columns per work-group
 
+template <bool BACK>
+__device__ __forceinline__ void stage_block(const double* __restrict__ L, int64_t ldl, int nb, int rb, int cb,
+                                            bool diag, double* __restrict__ s)
+{
+    // s[c * S64_LS + r] = M[64 rb + r][64 cb + c];  M = L (forward) or the flipped transpose (backward).
+    // All 16 loads of a thread are issued before the first LDS store (one memory round trip, not 16).
+    const int t = threadIdx.x;
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int idx = t + 256 * k;
+        int r, c;
+        if (!BACK) { r = idx & (NL - 1); c = idx >> 6; } else { c = idx & (NL - 1); r = idx >> 6; }
+        const int a = 64 * rb + r, b = 64 * cb + c;            // M[a][b]
+        double x = 0.0;
+        if (a < nb && b < nb && (!diag || a >= b))
+            x = BACK ? L[(int64_t)(nb - 1 - b) + (int64_t)(nb - 1 - a) * ldl] : L[(int64_t)a + (int64_t)b * ldl];
+        else if (diag && a == b) x = 1.0;                      // identity padding of a ragged last block
+        v[k] = x;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int idx = t + 256 * k;
+        int r, c;
+        if (!BACK) { r = idx & (NL - 1); c = idx >> 6; } else { c = idx & (NL - 1); r = idx >> 6; }
+        s[c * S64_LS + r] = v[k];
+    }
+}
+
 // Solves the nb x nb system for 64 right-hand sides per work-group (16 per wavefront) with the
 // MFMA-layout substitution core.  BACK = false: L x = b.  BACK = true: L^T x = b, run as the same
 // forward substitution on the flipped transpose M'[a][b] = L[nb-1-b][nb-1-a] with the vector
@@ -31,14 +60,7 @@ __global__ __launch_bounds__(256) void trsm_leaf_kernel(const double* __restrict
 {
     __shared__ __attribute__((aligned(16))) double sM[NL * S64_LS];
     const int t = threadIdx.x;
-    for (int idx = t; idx < NL * NL; idx += 256) {
-        const int r = idx & (NL - 1), c = idx >> 6;       // M[r][c], r >= c
-        double v = 0.0;
-        if (r < nb && c < nb && r >= c)
-            v = BACK ? L[(int64_t)(nb - 1 - c) + (int64_t)(nb - 1 - r) * ldl] : L[(int64_t)r + (int64_t)c * ldl];
-        else if (r == c) v = 1.0;
-        sM[c * S64_LS + r] = v;
-    }
+    stage_block<BACK>(L, ldl, nb, 0, 0, true, sM);
     __syncthreads();
     const int lane = t & 63, wave = t >> 6;
     const int i = lane & 15, g = lane >> 4;
@@ -67,10 +89,78 @@ __global__ __launch_bounds__(256) void trsm_leaf_kernel(const double* __restrict
     }
 }
 
+// Fused 256-row leaf: one work-group carries 64 right-hand sides (16 per wavefront) through up to
+// four 64-row blocks without leaving the chip: the vectors stay in registers (16 x d4 per lane),
+// every 64 x 64 coefficient block of L is staged once through LDS (double buffered), off-diagonal
+// blocks are applied with MFMA (strip64_update), diagonal blocks with solve64_lower.  Replaces
+// 4 leaf launches + 3 small gemm launches (and their 6 kernel boundaries) of the recursion.
+constexpr int NL4 = 256;
+
+template <bool BACK>
+__global__ __launch_bounds__(256) void trsm_leaf256_kernel(const double* __restrict__ L, int64_t ldl, int nb,
+                                                           double* __restrict__ B, int64_t ldb, int64_t nrhs)
+{
+    __shared__ __attribute__((aligned(16))) double sbuf[2][NL * S64_LS];
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int64_t col = (int64_t)blockIdx.x * CB + wave * 16 + i;
+    const bool live = col < nrhs;
+    double* b = B + col * ldb;
+    const int nblk = (nb + NL - 1) / NL;
+    d4 X[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * q + 4 * g + r;
+            const int p = BACK ? (nb - 1 - c) : c;
+            X[q][r] = (live && c < nb) ? b[p] : 0.0;
+        }
+    int buf = 0;
+#pragma unroll
+    for (int JB = 0; JB < 4; ++JB) {
+        if (JB < nblk) {
+#pragma unroll
+            for (int IB = 0; IB < JB; ++IB) {
+                stage_block<BACK>(L, ldl, nb, JB, IB, false, sbuf[buf]);
+                __syncthreads();
+                strip64_update(reinterpret_cast<d4(&)[4]>(X[4 * JB]), reinterpret_cast<const d4(&)[4]>(X[4 * IB]),
+                               sbuf[buf]);
+                buf ^= 1;
+            }
+            stage_block<BACK>(L, ldl, nb, JB, JB, true, sbuf[buf]);
+            __syncthreads();
+            solve64_lower(reinterpret_cast<d4(&)[4]>(X[4 * JB]), sbuf[buf]);
+            buf ^= 1;
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * q + 4 * g + r;
+                const int p = BACK ? (nb - 1 - c) : c;
+                if (c < nb) b[p] = X[q][r];
+            }
+    }
+}
+
 int trsm_rec(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t ldl, double* B,
              int64_t nrhs, int64_t ldb, bool trans, int64_t r0, int64_t r1)
 {
     const int64_t len = r1 - r0;
+    if (len <= NL4 && len > NL) {
+        const unsigned grid = (unsigned)((nrhs + CB - 1) / CB);
+        if (!trans)
+            hipLaunchKernelGGL(trsm_leaf256_kernel<false>, dim3(grid), dim3(256), 0, stream,
+                               L + r0 + r0 * ldl, ldl, (int)len, B + r0, ldb, nrhs);
+        else
+            hipLaunchKernelGGL(trsm_leaf256_kernel<true>, dim3(grid), dim3(256), 0, stream,
+                               L + r0 + r0 * ldl, ldl, (int)len, B + r0, ldb, nrhs);
+        return 0;
+    }
     if (len <= NL) {
         const unsigned grid = (unsigned)((nrhs + CB - 1) / CB);
         if (!trans)
@@ -81,9 +171,9 @@ int trsm_rec(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t ldl,
                                L + r0 + r0 * ldl, ldl, (int)len, B + r0, ldb, nrhs);
         return 0;
     }
-    // split at a multiple of 64 nearest the middle
-    int64_t half = ((len / 2 + NL - 1) / NL) * NL;
-    if (half >= len) half = len - NL > 0 ? ((len - 1) / NL) * NL : len / 2;
+    // split at a multiple of the fused-leaf height nearest the middle
+    int64_t half = ((len / 2 + NL4 - 1) / NL4) * NL4;
+    if (half >= len) half = ((len / 2 + NL - 1) / NL) * NL;
     const int64_t mid = r0 + half;
     if (!trans) {
         GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, r0, mid));
