@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--n", type=int, default=8192)
     ap.add_argument("--m", type=int, default=1024)
     ap.add_argument("--chol", default="replicated", choices=["replicated", "bcast"])
-    ap.add_argument("--fstar", default="double_solve", choices=["double_solve", "fused"])
+    ap.add_argument("--fstar", default="fused", choices=["double_solve", "fused"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

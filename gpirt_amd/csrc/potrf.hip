@@ -1,13 +1,13 @@
 // potrf.hip -- lower Cholesky of S = K + jitter*I : arma::chol(S,"lower") -> LAPACK dpotrf('L')
 // (src/gpirtMCMC.cpp:17,78,97), as a two-level blocked right-looking factorisation:
 //
-//   outer panels of NBO = 256 columns: trailing update  A22 -= P P^T  (lower blocks only) is one
-//       fp64-MFMA syrk launch with K = 256  (gemm_f64.hip, TRI_SYRK_LOWER) -- n^3/3 of the flops;
+//   outer panels of NBO = 512 columns: trailing update  A22 -= P P^T  (lower blocks only) is an
+//       fp64-MFMA syrk with K = 512  (gemm_f64.hip, 128 x 128 tiles) -- n^3/3 of the flops;
 //   inside a panel, steps of NBI = 64 columns:
-//       potf2_64      one work-group factors the 64 x 64 diagonal block in LDS;
-//       panel_trsm_64 X L_kk^T = A_panel by substitution, one lane per row (the row lives in 64
-//                     fp64 registers, L_kk is broadcast from LDS): rows are independent, so this
-//                     is perfectly parallel over the n - k rows below the block;
+//       potf2_64      one work-group factors the 64 x 64 diagonal block, register tiled;
+//       panel_trsm_64 X L_kk^T = A_panel by substitution, 16 rows per wavefront in the MFMA
+//                     accumulator layout (solve64.h): rows are independent, so this is perfectly
+//                     parallel over the n - k rows below the block;
 //       the panel's remaining columns are updated with a K = 64 MFMA gemm (masked to the lower
 //       triangle).
 // Nothing above the diagonal is ever written; the strict upper triangle keeps whatever it held
@@ -25,7 +25,7 @@ namespace gpirt {
 namespace {
 
 constexpr int NBI = 64;
-constexpr int NBO = 256;
+constexpr int NBO = 512;
 
 // ------------------------------------------------------------------ diagonal block ---------
 // 64 x 64 Cholesky in one work-group, register tiled: thread (tr, tc) = (t & 15, t >> 4) owns the
@@ -214,15 +214,16 @@ int factor_panel(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int
 int trailing(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t K0, int64_t c1,
              int64_t lo, int64_t hi, bool shared = false)
 {
-    const bool prof = h->prof.enabled;
+    const int64_t M = n - lo, N = hi - lo, K = c1 - K0;
+    // the roofline figure covers the launches of the dominant kernel only (128-tile syrk)
+    const bool prof = h->prof.enabled && (shared || gemm_trailing_uses_128(M, N));
     ProfPair pp{nullptr, nullptr, 0.0};
     if (prof) {
         if (!h->prof.free_pairs.empty()) { pp = h->prof.free_pairs.back(); h->prof.free_pairs.pop_back(); }
         else { GP_HIP(hipEventCreate(&pp.e0)); GP_HIP(hipEventCreate(&pp.e1)); }
         GP_HIP(hipEventRecord(pp.e0, stream));
     }
-    const int64_t M = n - lo, N = hi - lo, K = c1 - K0;
-    GP_TRY(launch_gemm(h, stream, false, true, shared ? TRI_SYRK_LOWER_SHARED : TRI_SYRK_LOWER, M, N, K, -1.0,
+    GP_TRY(launch_gemm(h, stream, false, true, shared ? TRI_SYRK_LOWER_SHARED : TRI_SYRK_LOWER_TRAILING, M, N, K, -1.0,
                        A + lo + K0 * lda, lda, A + lo + K0 * lda, lda, 1.0, A + lo + lo * lda, lda));
     if (prof) {
         GP_HIP(hipEventRecord(pp.e1, stream));
@@ -253,8 +254,8 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
 {
     if (n <= 0) return 0;
     static const int nbo_env = env_int("GPIRT_NBO", NBO);
-    static const int lookahead = env_int("GPIRT_LOOKAHEAD", 1);
-    static const int shared_occ = env_int("GPIRT_SHARED_OCC", 1);
+    static const int lookahead = env_int("GPIRT_LOOKAHEAD", 1);     // 2 = off
+    static const int shared_occ = env_int("GPIRT_SHARED_OCC", 2);   // 1 = single-occupancy trailing GEMM (measured slower)
     const int64_t nbo = (nbo_env / NBI) * NBI > 0 ? (nbo_env / NBI) * NBI : NBO;
     GP_HIP(hipMemsetAsync(h->d_info, 0, sizeof(int), stream));
     const bool la = (lookahead == 1) && (n > 2 * nbo);
