@@ -65,8 +65,12 @@ __global__ __launch_bounds__(256) void potf2_64_kernel(double* __restrict__ A, i
 #pragma unroll
     for (int jb = 0; jb < 16; ++jb) {
         const int buf = jb & 1;
-        if (tc == jb) {
-            const int src = jb + 16 * (jb & 3);                       // lane of thread (tr = jb, tc = jb)
+        if (tc == jb && tr >= jb) {
+            // The 16-lane group of panel jb.  Lane `src` (tr == jb) holds the 4 x 4 diagonal tile and
+            // factors it in place with static indices; the lanes below (tr > jb) hold full tiles and
+            // need no per-element predicates -- the two roles diverge once per column.
+            const int src = jb + 16 * (jb & 3);
+            const bool is_diag = (tr == jb);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int j = 4 * jb + jj;
@@ -75,42 +79,54 @@ __global__ __launch_bounds__(256) void potf2_64_kernel(double* __restrict__ A, i
                 // pivot column scaled by 1/sqrt(d) (LAPACK dpotf2 scales by the reciprocal too);
                 // rsqrt keeps the 64-step dependent chain short.  d <= 0 gives NaN: propagates.
                 const double rinv = (d > 0.0) ? rsqrt(d) : __builtin_nan("");
+                if (is_diag) {
+                    a[jj][jj] = d * rinv;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = 4 * tr + i;
-                    if (row > j) a[i][jj] *= rinv;
-                    else if (row == j) a[i][jj] = d * rinv;
+                    for (int i = jj + 1; i < 4; ++i) a[i][jj] *= rinv;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a[i][jj] *= rinv;
                 }
 #pragma unroll
                 for (int jj2 = jj + 1; jj2 < 4; ++jj2) {
                     const double lc = readlane_f64(a[jj2][jj], src);  // L[4jb+jj2][j]
+                    if (is_diag) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (4 * tr + i >= 4 * jb + jj2) a[i][jj2] = fma(-a[i][jj], lc, a[i][jj2]);
+                        for (int i = jj2; i < 4; ++i) a[i][jj2] = fma(-a[i][jj], lc, a[i][jj2]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) a[i][jj2] = fma(-a[i][jj], lc, a[i][jj2]);
+                    }
                 }
             }
+            // publish the panel: sP[buf][k * 64 + row]; the strict upper part of the diagonal tile is zero
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    sP[buf][k * NBI + 4 * tr + i] = (4 * tr + i >= 4 * jb + k) ? a[i][k] : 0.0;
+            for (int k = 0; k < 4; ++k) {
+                double4 v;
+                v.x = (is_diag && 0 < k) ? 0.0 : a[0][k];
+                v.y = (is_diag && 1 < k) ? 0.0 : a[1][k];
+                v.z = (is_diag && 2 < k) ? 0.0 : a[2][k];
+                v.w = a[3][k];
+                *reinterpret_cast<double4*>(&sP[buf][k * NBI + 4 * tr]) = v;
+            }
         }
         __syncthreads();
         if (tc > jb && tr >= tc) {
-            double lr[4][4], lcn[4][4];
+            double4 lr[4], lcn[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < 4; ++k) {
+                lr[k] = *reinterpret_cast<const double4*>(&sP[buf][k * NBI + 4 * tr]);
+                lcn[k] = *reinterpret_cast<const double4*>(&sP[buf][k * NBI + 4 * tc]);
+            }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    lr[i][k] = sP[buf][k * NBI + 4 * tr + i];
-                    lcn[i][k] = sP[buf][k * NBI + 4 * tc + i];
-                }
+            for (int k = 0; k < 4; ++k) {
+                const double r4[4] = { lr[k].x, lr[k].y, lr[k].z, lr[k].w };
+                const double c4[4] = { lcn[k].x, lcn[k].y, lcn[k].z, lcn[k].w };
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) a[i][kk] = fma(-lr[i][k], lcn[kk][k], a[i][kk]);
+                    for (int kk = 0; kk < 4; ++kk) a[i][kk] = fma(-r4[i], c4[kk], a[i][kk]);
+            }
         }
     }
 #pragma unroll
