@@ -64,15 +64,20 @@ class ShardedSampler:
     def init(self):
         self.engine.init()
 
-    def step(self):
+    STAGES = ("draw_f", "draw_fstar", "theta_gemm", "theta_allreduce", "theta_sample", "draw_beta", "factor")
+
+    def step(self, timer=None):
+        """One MCMC iteration.  `timer(name)` (optional) is called after each stage is enqueued --
+        bench.py passes a function that records a device event, to attribute time to stages."""
         e = self.engine
-        e.draw_f()
-        e.draw_fstar()
-        e.theta_partial()
-        self._allreduce_logpost()
-        e.theta_finish()
-        e.draw_beta()
-        self._factor()
+        t = timer if timer is not None else (lambda name: None)
+        e.draw_f(); t("draw_f")
+        e.draw_fstar(); t("draw_fstar")
+        e.theta_partial(); t("theta_gemm")
+        self._allreduce_logpost(); t("theta_allreduce")
+        e.theta_finish(); t("theta_sample")
+        e.draw_beta(); t("draw_beta")
+        self._factor(); t("factor")
 
     def gather(self, name: str):
         """All ranks receive the full (column-concatenated) array `name` of item-sharded state."""
