@@ -80,3 +80,62 @@ def test_sampler_stage_api_equals_step(handle, oracle):
         assert np.array_equal(a.get(name), b.get(name))
     assert a.iteration == b.iteration == 2
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("n,m,S,B", [(5, 1, 1, 0), (64, 2, 1, 1), (65, 3, 0, 1), (257, 4, 1, 0)])
+def test_mcmc_edge_shapes(handle, oracle, n, m, S, B):
+    """Tiny / ragged problems (n below, at and just above a 64-column panel; a single item; S = 0 -> NaN IRFs)."""
+    from gpirt_amd import gpirtMCMC
+    from gpirt_amd.ops import RStream
+    from gpirt_amd.synthetic import make_responses
+    y, _ = make_responses(n, m, seed=n + m, snap_theta=False)
+    codes = dict(yea=[1], nay=[-1], missing=[None])
+    with np.errstate(all="ignore"):
+        res = gpirtMCMC(y, S, B, vote_codes=codes, rng="reference", rstream=RStream(714))
+        r = oracle.RStream(714)
+        ref = oracle.gpirt_mcmc(r, y, r.rnorm(n), S, B)
+    assert res["theta"].shape == (S + 1, n) and res["f"].shape == (n, m, S + 1)
+    assert np.array_equal(res["theta"], ref["theta"])
+    assert np.abs(res["f"] - ref["f"]).max() <= 1e-9
+    if S == 0:
+        assert np.isnan(res["IRFs"]).all() and np.isnan(ref["IRFs"]).all()        # quirk Q7
+    else:
+        assert np.abs(res["IRFs"] - ref["IRFs"]).max() <= 1e-9
+
+
+def test_mcmc_reference_rng_with_zero_step_and_missing_column(handle, oracle):
+    """rnorm(mu, 0) consumes nothing (src/draw-beta.cpp:22 through R::rnorm) and an all-but-two-NA item."""
+    from gpirt_amd import gpirtMCMC
+    from gpirt_amd.ops import RStream
+    from gpirt_amd.synthetic import make_responses
+    n, m = 70, 5
+    y, _ = make_responses(n, m, seed=2, snap_theta=False)
+    y[2:, 3] = np.nan
+    y[0, 3], y[1, 3] = 1.0, -1.0
+    st = np.full((2, m), 0.1)
+    st[1, 2] = 0.0
+    codes = dict(yea=[1], nay=[-1], missing=[None])
+    rs = RStream(99)
+    res = gpirtMCMC(y, 2, 1, vote_codes=codes, beta_proposal_sds=st, rng="reference", rstream=rs)
+    r = oracle.RStream(99)
+    ref = oracle.gpirt_mcmc(r, y, r.rnorm(n), 2, 1, step=st)
+    _check(res, ref)
+    mt, mti = rs.state()
+    mt_ref, mti_ref = r.mt_state()
+    assert mti == mti_ref and np.array_equal(mt, mt_ref)
+
+
+def test_theta_degenerate_without_stabilisation_is_reported(handle):
+    """With ~2000 items exp() underflows in the reference's draw_theta (0/0, out-of-bounds read):
+    the unstabilised device path reports it, the stabilised one draws normally."""
+    import torch
+    from gpirt_amd.ops import to_device
+    from gpirt_amd.synthetic import make_responses
+    n, m = 64, 2500
+    y, th = make_responses(n, m, seed=1)
+    ts = -5.0 + 0.01 * np.arange(1001)
+    fstar = 2.0 * ts[:, None] * np.ones((1, m))
+    out, deg = handle.draw_theta(to_device(y), to_device(fstar), 3, 1, stabilise=False)
+    assert deg > 0 and int(torch.isnan(out).sum().item()) == deg
+    out, deg = handle.draw_theta(to_device(y), to_device(fstar), 3, 1, stabilise=True)
+    assert deg == 0 and not torch.isnan(out).any()
