@@ -19,7 +19,7 @@ int launch_se_kernel(hipStream_t stream, const double* x1, int64_t n1, const dou
                      double* out, int64_t ld, double jitter);
 // lower-triangular blocks only (upper blocks are left untouched): the potrf input
 int launch_se_kernel_lower(hipStream_t stream, const double* x, int64_t n, double* out, int64_t ld,
-                           double jitter);
+                           double jitter, bool fp32 = false);
 
 // potrf.hip
 int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda,

@@ -222,7 +222,7 @@ int do_draw_beta(gpirt_sampler_s* s)
 int do_factor(gpirt_sampler_s* s)
 {
     hipStream_t st = s->h->stream;
-    GP_TRY(launch_se_kernel_lower(st, s->theta, s->n, s->L, s->n, GPIRT_JITTER));   // :76-77
+    GP_TRY(launch_se_kernel_lower(st, s->theta, s->n, s->L, s->n, GPIRT_JITTER, s->opt.reserved[1] != 0));   // :76-77
     return launch_potrf_lower(s->h, st, s->L, s->n, s->n, false);                  // :78
 }
 

@@ -18,7 +18,7 @@ constexpr int TC = 32;    // tile columns
 __device__ __forceinline__ void se_tile(const double* __restrict__ x1, int64_t n1,
                                         const double* __restrict__ x2, int64_t n2,
                                         double* __restrict__ out, int64_t ld, double jitter,
-                                        int64_t i0, int64_t j0, bool lower_only)
+                                        int64_t i0, int64_t j0, bool lower_only, bool fp32 = false)
 {
     const int t = threadIdx.x;
     const int64_t r = i0 + (t & 63) * 2;
@@ -32,8 +32,14 @@ __device__ __forceinline__ void se_tile(const double* __restrict__ x1, int64_t n
         if (c >= n2) break;
         const double b = x2[c];
         const double d0 = a0 - b, d1 = a1 - b;
-        double v0 = exp(-0.5 * d0 * d0);
-        double v1 = exp(-0.5 * d1 * d1);
+        double v0, v1;
+        if (fp32) {      // config C5: single-precision kernel build feeding the fp64 factorisation
+            v0 = (double)expf((float)(-0.5 * d0 * d0));
+            v1 = (double)expf((float)(-0.5 * d1 * d1));
+        } else {
+            v0 = exp(-0.5 * d0 * d0);
+            v1 = exp(-0.5 * d1 * d1);
+        }
         if (r == c) v0 += jitter;
         if (r + 1 == c) v1 += jitter;
         if (lower_only) {                 // strict upper part of a diagonal tile: exact zeros
@@ -62,7 +68,7 @@ __global__ __launch_bounds__(256) void se_kernel_full(const double* __restrict__
 // blockIdx.x enumerates (lower block pair, 32-column strip) ; pairs are 128 x 128
 __global__ __launch_bounds__(256) void se_kernel_lower(const double* __restrict__ x, int64_t n,
                                                        double* __restrict__ out, int64_t ld,
-                                                       double jitter)
+                                                       double jitter, bool fp32)
 {
     const int strip = blockIdx.x & 3;
     const int t = blockIdx.x >> 2;
@@ -70,7 +76,7 @@ __global__ __launch_bounds__(256) void se_kernel_lower(const double* __restrict_
     while ((r + 1) * (r + 2) / 2 <= t) ++r;
     while (r * (r + 1) / 2 > t) --r;
     const int bi = r, bj = t - r * (r + 1) / 2;
-    se_tile(x, n, x, n, out, ld, jitter, (int64_t)bi * TR, (int64_t)bj * 128 + strip * TC, bi == bj);
+    se_tile(x, n, x, n, out, ld, jitter, (int64_t)bi * TR, (int64_t)bj * 128 + strip * TC, bi == bj, fp32);
 }
 
 }  // namespace
@@ -88,13 +94,13 @@ int launch_se_kernel(hipStream_t stream, const double* x1, int64_t n1, const dou
 }
 
 int launch_se_kernel_lower(hipStream_t stream, const double* x, int64_t n, double* out, int64_t ld,
-                           double jitter)
+                           double jitter, bool fp32)
 {
     if (n <= 0) return 0;
     const int64_t nb = (n + 127) / 128;
     const int64_t pairs = nb * (nb + 1) / 2;
     hipLaunchKernelGGL(se_kernel_lower, dim3((unsigned)(pairs * 4)), dim3(256), 0, stream, x, n, out,
-                       ld, jitter);
+                       ld, jitter, fp32);
     GP_HIP(hipGetLastError());
     return 0;
 }

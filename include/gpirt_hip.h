@@ -168,7 +168,8 @@ typedef struct gpirt_options {
      * global problem with m_total items; y / priors / outputs passed in are the LOCAL columns. */
     int64_t  item0;
     int64_t  m_total;
-    int      reserved[8];
+    int      reserved[8];     /* reserved[1] = 1: build K(theta,theta) with single-precision exp() before the
+                               * fp64 factorisation (BASELINE config C5; parity then only statistical) */
 } gpirt_options;
 
 void gpirt_default_options(gpirt_options* o);
