@@ -223,9 +223,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int bi, con
     }
 }
 
-// PAD > 0 inflates the static LDS footprint past half a CU so only ONE work-group is resident per
-// CU: ~7 % less MFMA throughput, but every CU keeps LDS, registers and wave slots free for the
-// latency-bound Cholesky panel kernels that run concurrently on the side stream (look-ahead).
+// PAD only distinguishes instantiations by name (see launch_gemm_trailing); it adds PAD doubles of LDS.
 template <bool TA, bool TB, int T, int PAD = 0>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p)
 {
@@ -267,17 +265,14 @@ static int launch_gemm_t(hipStream_t stream, bool ta, bool tb, GemmParams p);
 
 // The Cholesky trailing update gets its own instantiations of the NT / syrk-lower 128-tile kernel
 // (PAD = 8: same code, +64 B of LDS) so kernel traces and PMC profiles can tell it apart by name
-// from the other NT products (draw_theta's GEMM); PAD = 1100 is the single-occupancy variant.
-static int launch_gemm_trailing(hipStream_t stream, GemmParams p, bool single_occupancy)
+// from the other NT products (draw_theta's GEMM).
+static int launch_gemm_trailing(hipStream_t stream, GemmParams p)
 {
     constexpr int T = 128;
     p.mblocks = (p.M + T - 1) / T;
     p.nblocks = (p.N + T - 1) / T;
     const int64_t grid = (int64_t)p.nblocks * p.mblocks - (int64_t)p.nblocks * (p.nblocks - 1) / 2;
-    if (single_occupancy)
-        hipLaunchKernelGGL((gemm_f64_kernel<false, true, 128, 1100>), dim3((unsigned)grid), dim3(256), 0, stream, p);
-    else
-        hipLaunchKernelGGL((gemm_f64_kernel<false, true, 128, 8>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((gemm_f64_kernel<false, true, 128, 8>), dim3((unsigned)grid), dim3(256), 0, stream, p);
     GP_HIP(hipGetLastError());
     return 0;
 }
@@ -320,11 +315,10 @@ int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri,
     p.mblocks = p.nblocks = 0;
     p.fastA = (((uintptr_t)A & 15) == 0) && (lda % 2 == 0);
     p.fastB = (((uintptr_t)B & 15) == 0) && (ldb % 2 == 0);
-    if (tri == TRI_SYRK_LOWER_SHARED || tri == TRI_SYRK_LOWER_TRAILING) {
+    if (tri == TRI_SYRK_LOWER_TRAILING) {
         p.tri = TRI_SYRK_LOWER;
         if (M < N || ta || !tb) { set_error("trailing syrk mode needs the NT form and M >= N"); return GPIRT_E_ARG; }
-        if (tri == TRI_SYRK_LOWER_SHARED || gemm_trailing_uses_128(M, N))
-            return launch_gemm_trailing(stream, p, tri == TRI_SYRK_LOWER_SHARED);
+        if (gemm_trailing_uses_128(M, N)) return launch_gemm_trailing(stream, p);
         return launch_gemm_t<64>(stream, ta, tb, p);
     }
     if (tri == TRI_SYRK_LOWER && M < N) { set_error("syrk mode needs M >= N"); return GPIRT_E_ARG; }

@@ -5,8 +5,7 @@
 
 namespace gpirt {
 
-enum { TRI_NONE = 0, TRI_SYRK_LOWER = 1, TRI_A_LOWER = 2, TRI_A_UPPER = 3, TRI_SYRK_LOWER_SHARED = 4,
-       TRI_SYRK_LOWER_TRAILING = 5 };
+enum { TRI_NONE = 0, TRI_SYRK_LOWER = 1, TRI_A_LOWER = 2, TRI_A_UPPER = 3, TRI_SYRK_LOWER_TRAILING = 4 };
 bool gemm_trailing_uses_128(int64_t M, int64_t N);   // does a trailing update of this shape run the 128-tile kernel?
 
 // gemm_f64.hip

@@ -228,18 +228,18 @@ int factor_panel(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int
 // trailing update restricted to the column range [lo, hi):
 //   A[lo:n, lo:hi] -= A[lo:n, K0:c1] A[lo:hi, K0:c1]^T      (lower trapezoid, fp64 MFMA syrk)
 int trailing(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t K0, int64_t c1,
-             int64_t lo, int64_t hi, bool shared = false)
+             int64_t lo, int64_t hi)
 {
     const int64_t M = n - lo, N = hi - lo, K = c1 - K0;
     // the roofline figure covers the launches of the dominant kernel only (128-tile syrk)
-    const bool prof = h->prof.enabled && (shared || gemm_trailing_uses_128(M, N));
+    const bool prof = h->prof.enabled && gemm_trailing_uses_128(M, N);
     ProfPair pp{nullptr, nullptr, 0.0};
     if (prof) {
         if (!h->prof.free_pairs.empty()) { pp = h->prof.free_pairs.back(); h->prof.free_pairs.pop_back(); }
         else { GP_HIP(hipEventCreate(&pp.e0)); GP_HIP(hipEventCreate(&pp.e1)); }
         GP_HIP(hipEventRecord(pp.e0, stream));
     }
-    GP_TRY(launch_gemm(h, stream, false, true, shared ? TRI_SYRK_LOWER_SHARED : TRI_SYRK_LOWER_TRAILING, M, N, K, -1.0,
+    GP_TRY(launch_gemm(h, stream, false, true, TRI_SYRK_LOWER_TRAILING, M, N, K, -1.0,
                        A + lo + K0 * lda, lda, A + lo + K0 * lda, lda, 1.0, A + lo + lo * lda, lda));
     if (prof) {
         GP_HIP(hipEventRecord(pp.e1, stream));
@@ -262,16 +262,16 @@ int env_int(const char* name, int dflt)
 
 // Look-ahead schedule: the trailing update of panel p is split into the columns of panel p+1
 // (done first, on the main stream) and the rest; panel p+1 is then factored on a high-priority
-// side stream WHILE the rest of update p runs on the main stream.  The panel chain (128 dependent
-// diagonal-block factorisations for n = 8192) is latency-bound and would otherwise serialise with
-// the MFMA-bound trailing updates.
+// side stream WHILE the rest of update p runs on the main stream.  Measured gain is small (~3 %):
+// the panel chain is fp64-VALU latency-bound and the fp64 MFMA shares the same FP64 pipes, so chain
+// kernels run ~6x slower while a trailing update is resident (profiles/r01_summary.md); CU masks
+// (hipExtStreamCreateWithCUMask) and single-occupancy GEMM variants were measured and made it worse.
 int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda,
                        bool zero_upper)
 {
     if (n <= 0) return 0;
     static const int nbo_env = env_int("GPIRT_NBO", NBO);
     static const int lookahead = env_int("GPIRT_LOOKAHEAD", 1);     // 2 = off
-    static const int shared_occ = env_int("GPIRT_SHARED_OCC", 2);   // 1 = single-occupancy trailing GEMM (measured slower)
     const int64_t nbo = (nbo_env / NBI) * NBI > 0 ? (nbo_env / NBI) * NBI : NBO;
     GP_HIP(hipMemsetAsync(h->d_info, 0, sizeof(int), stream));
     const bool la = (lookahead == 1) && (n > 2 * nbo);
@@ -292,7 +292,7 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
             GP_HIP(hipEventRecord(h->ev_fork, stream));
             GP_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
             GP_TRY(factor_panel(h, h->side, A, n, lda, c1, c2));          // next panel, side stream
-            GP_TRY(trailing(h, stream, A, n, lda, K0, c1, c2, n, shared_occ == 1));  // the rest, concurrently
+            GP_TRY(trailing(h, stream, A, n, lda, K0, c1, c2, n));        // the rest, concurrently
             GP_HIP(hipEventRecord(h->ev_join, h->side));
             GP_HIP(hipStreamWaitEvent(stream, h->ev_join, 0));
         } else {
