@@ -181,7 +181,8 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "MCMC iterations/sec at N=8192 x m=1024",
+            "metric": "MCMC iterations/sec at N=8192 x m=1024" if (n, m) == (8192, 1024)
+                      else f"MCMC iterations/sec at N={n} x m={m} (not the BASELINE metric shape)",
             "value": args.steps / dt,
             "unit": "iterations/s",
             "n_gpus": world,
@@ -203,7 +204,7 @@ def main():
                 "item_sharded_stages": ["draw_f", "draw_fstar", "theta_gemm", "draw_beta"],
             },
             "roofline": {
-                "kernel": "gemm_f64_kernel<false,true> (potrf trailing update, syrk lower, v_mfma_f64_16x16x4_f64)",
+                "kernel": "gemm_f64_kernel<false, true, 128, 8> (potrf trailing update, syrk lower, v_mfma_f64_16x16x4_f64)",
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": PEAK_FP64_MFMA_TFLOPS,
