@@ -17,8 +17,10 @@ CONFIGS = {
 }
 
 
-def make_responses(n: int, m: int, seed: int = 20240, na_frac: float = 0.05, snap_theta: bool = True):
-    """Returns (y [n x m, column-major float64 in {-1,+1,NaN}], theta_init [n])."""
+def make_responses(n: int, m: int, seed: int = 20240, na_frac: float = 0.05, snap_theta: bool = True,
+                   return_truth: bool = False):
+    """Returns (y [n x m, column-major float64 in {-1,+1,NaN}], theta_init [n]) and, with return_truth,
+    the generating theta as a third value."""
     rng = np.random.default_rng(seed)
     theta_true = rng.standard_normal(n)
     a = rng.uniform(-2.0, 2.0, m)
@@ -39,4 +41,6 @@ def make_responses(n: int, m: int, seed: int = 20240, na_frac: float = 0.05, sna
         # steady-state condition of the sampler: every theta lies on the -5:0.01:5 grid (Q6)
         k = np.clip(np.rint((theta_init + 5.0) / 0.01), 0, 1000)
         theta_init = -5.0 + k * 0.01
+    if return_truth:
+        return y, theta_init, theta_true
     return y, theta_init

@@ -174,3 +174,20 @@ def test_long_run_item_rng_stays_on_the_oracle_trajectory(handle, oracle):
     pm_gpu, pm_ref = res["f"][:, :, 1:].mean(axis=2), ref["f"][:, :, 1:].mean(axis=2)
     assert np.abs(pm_gpu - pm_ref).max() <= 1e-8 * max(1.0, np.abs(pm_ref).max())
     assert np.abs(res["IRFs"] - ref["IRFs"]).max() <= 1e-8
+
+
+def test_sampler_recovers_the_latent_trait(handle):
+    """Statistical sanity of the whole device path (no oracle involved): on 2PL data the posterior mean of
+    theta must track the generating theta up to the model's reflection."""
+    from gpirt_amd import gpirtMCMC
+    from gpirt_amd.synthetic import make_responses
+    n, m = 512, 64
+    y, th0, truth = make_responses(n, m, seed=77, return_truth=True)
+    res = gpirtMCMC(y, 60, 40, vote_codes=dict(yea=[1], nay=[-1], missing=[None]), theta_init=th0, rng="item",
+                    seed=5, theta_stabilise=True, fstar_fused=True)
+    assert np.isfinite(res["theta"]).all() and np.isfinite(res["f"]).all() and np.isfinite(res["IRFs"]).all()
+    post = res["theta"][1:].mean(axis=0)
+    r = np.corrcoef(post, truth)[0, 1]
+    assert abs(r) > 0.9, r
+    irf = res["IRFs"]
+    assert irf.min() >= 0.0 and irf.max() <= 1.0
