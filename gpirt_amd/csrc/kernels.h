@@ -58,6 +58,7 @@ struct FstarEpiArgs {
     uint64_t seed; uint32_t iter; uint32_t item0;
     const double* U; uint64_t* pos; uint64_t cap; int* err;   // R-stream replay when U != null
     double* mean_out;     // optional copy of mean + mu_star
+    int* off_scratch;     // N + 1 ints of device scratch for the R-stream consumption offsets
 };
 int launch_fstar_epilogue(hipStream_t stream, const FstarEpiArgs& a);
 

@@ -41,6 +41,7 @@ struct gpirt_sampler_s {
            *mean = nullptr, *s = nullptr, *Gpm = nullptr, *logpost = nullptr, *irf_sum = nullptr,
            *pm = nullptr, *ps = nullptr, *step = nullptr;
     int *ess_k = nullptr, *flags = nullptr;    // flags[0] = err, flags[1] = degenerate theta count
+    int *fstar_off = nullptr;                  // R-stream replay: consumption offsets of draw_fstar
     int *h_flags = nullptr;                    // pinned
     // R-stream replay
     double* U = nullptr; double* hU = nullptr; uint64_t U_cap = 0;
@@ -179,7 +180,7 @@ int do_draw_fstar(gpirt_sampler_s* s, uint32_t iter)
     FstarEpiArgs a{};
     a.mean = s->mean; a.mu_star = s->mu_star; a.s = s->s; a.out = s->fstar; a.N = N; a.m = m;
     a.seed = s->opt.seed; a.iter = iter; a.item0 = (uint32_t)s->opt.item0; a.err = s->flags;
-    if (stream_mode(s)) { a.U = s->U; a.pos = s->pos; a.cap = s->U_cap; }
+    if (stream_mode(s)) { a.U = s->U; a.pos = s->pos; a.cap = s->U_cap; a.off_scratch = s->fstar_off; }
     return launch_fstar_epilogue(st, a);                                                      // :26-28
 }
 
@@ -283,6 +284,7 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
         GP_A(s->U, s->U_cap);
         GP_A(s->pos, 2);
         GP_A(s->beta_off, m);
+        GP_A(s->fstar_off, N + 8);
         if (hipHostMalloc(&s->hU, s->U_cap * sizeof(double), hipHostMallocDefault) != hipSuccess ||
             hipHostMalloc(&s->h_pos, 2 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
             set_error("pinned allocation for the R-stream window failed");

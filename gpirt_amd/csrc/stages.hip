@@ -288,19 +288,14 @@ int launch_colnorm_s(hipStream_t stream, const double* tmp, int64_t n, int64_t N
     return 0;
 }
 
-// scratch for the R-stream consumption offsets (N+1 ints), owned by the caller via a.err's
-// neighbour: we keep one static device buffer per process (tiny, allocated on first use).
-static int* g_fstar_off = nullptr;
-
 int launch_fstar_epilogue(hipStream_t stream, const FstarEpiArgs& a)
 {
     if (a.N <= 0 || a.m <= 0) return 0;
     const int* off = nullptr;
     if (a.U) {
-        if (!g_fstar_off) GP_HIP(hipMalloc(&g_fstar_off, sizeof(int) * (GPIRT_NGRID + 8)));
-        if (a.N > GPIRT_NGRID) { set_error("R-stream fstar replay supports N <= %d", GPIRT_NGRID); return GPIRT_E_ARG; }
-        hipLaunchKernelGGL(fstar_offsets_kernel, dim3(1), dim3(64), 0, stream, a.s, (int)a.N, g_fstar_off);
-        off = g_fstar_off;
+        if (!a.off_scratch) { set_error("R-stream fstar replay needs the offset scratch (N + 1 ints)"); return GPIRT_E_ARG; }
+        hipLaunchKernelGGL(fstar_offsets_kernel, dim3(1), dim3(64), 0, stream, a.s, (int)a.N, a.off_scratch);
+        off = a.off_scratch;
     }
     dim3 grid((unsigned)((a.N + 255) / 256), (unsigned)a.m);
     hipLaunchKernelGGL(fstar_epilogue_kernel, grid, dim3(256), 0, stream, a, off);
