@@ -22,7 +22,7 @@ int launch_se_kernel_lower(hipStream_t stream, const double* x, int64_t n, doubl
 
 // potrf.hip
 int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda,
-                       bool zero_upper);
+                       bool zero_upper, bool reset_info = true);
 
 // trsm.hip
 int launch_trsm_lower(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t n, int64_t ldl,

@@ -267,13 +267,13 @@ int env_int(const char* name, int dflt)
 // kernels run ~6x slower while a trailing update is resident (profiles/r01_summary.md); CU masks
 // (hipExtStreamCreateWithCUMask) and single-occupancy GEMM variants were measured and made it worse.
 int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda,
-                       bool zero_upper)
+                       bool zero_upper, bool reset_info)
 {
     if (n <= 0) return 0;
     static const int nbo_env = env_int("GPIRT_NBO", NBO);
     static const int lookahead = env_int("GPIRT_LOOKAHEAD", 1);     // 2 = off
     const int64_t nbo = (nbo_env / NBI) * NBI > 0 ? (nbo_env / NBI) * NBI : NBO;
-    GP_HIP(hipMemsetAsync(h->d_info, 0, sizeof(int), stream));
+    if (reset_info) GP_HIP(hipMemsetAsync(h->d_info, 0, sizeof(int), stream));
     const bool la = (lookahead == 1) && (n > 2 * nbo);
     if (la && !h->side) {
         int lo_pri = 0, hi_pri = 0;

@@ -52,6 +52,7 @@ struct gpirt_sampler_s {
     // bookkeeping
     int iter = 0;                     // completed iterations
     bool initialised = false;
+    bool sticky_info = false;         // gpirt_mcmc: potrf info is not cleared between iterations
     bool timing = false;
     hipEvent_t ev[ST_COUNT + 1] = {};
     double stage_ms[ST_COUNT] = {};
@@ -224,7 +225,7 @@ int do_factor(gpirt_sampler_s* s)
 {
     hipStream_t st = s->h->stream;
     GP_TRY(launch_se_kernel_lower(st, s->theta, s->n, s->L, s->n, GPIRT_JITTER, s->opt.reserved[1] != 0));   // :76-77
-    return launch_potrf_lower(s->h, st, s->L, s->n, s->n, false);                  // :78
+    return launch_potrf_lower(s->h, st, s->L, s->n, s->n, false, !s->sticky_info); // :78
 }
 
 inline void mark(gpirt_sampler_s* s, int idx)
@@ -590,28 +591,108 @@ int gpirt_mcmc(const double* h_y, int64_t n, int64_t m, const double* h_theta0, 
     gpirt_sampler_t s = nullptr;
     int rc = gpirt_sampler_create(&s, h, h_y, n, m, h_theta0, h_pm, h_ps, h_step, &o, rs);
     if (rc) { gpirt_destroy(h); return rc; }
+    // Storage of the sampled draws (src/gpirtMCMC.cpp:99-101) is taken off the critical path: after a
+    // sampled iteration theta / beta / f are snapshotted device-to-device on the compute stream, the next
+    // iteration is enqueued, and only then is the snapshot copied to the caller's arrays on a second
+    // stream -- the PCIe transfer (64 MiB per stored iteration at the metric size) overlaps the next
+    // iteration's kernels.  Errors (potrf info, sampler flags) are sticky on the device and polled
+    // without synchronising.
     std::vector<double> th((size_t)n);
-    auto store = [&](int slot) -> int {
-        // theta_draws.row(slot), beta_draws.slice(slot), f_draws.slice(slot): :53-55, :99-101
+    double *snap_f = nullptr, *snap_small = nullptr;       // snap_small: [theta (n) | beta (2m)]
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_snap = nullptr, ev_flags = nullptr;
+    int* h_poll = nullptr;                                 // pinned: [potrf info, flag0, flag1]
+    auto cleanup = [&]() {
+        if (snap_f) hipFree(snap_f);
+        if (snap_small) hipFree(snap_small);
+        if (copy_stream) hipStreamDestroy(copy_stream);
+        if (ev_snap) hipEventDestroy(ev_snap);
+        if (ev_flags) hipEventDestroy(ev_flags);
+        if (h_poll) hipHostFree(h_poll);
+    };
+    auto fail_hip = [&](const char* what) { set_error("%s failed in gpirt_mcmc", what); return (int)GPIRT_E_HIP; };
+    auto store_sync = [&](int slot) -> int {
+        // theta_draws.row(slot), beta_draws.slice(slot), f_draws.slice(slot): :53-55
         GP_TRY(gpirt_sampler_get(s, "theta", th.data(), n));
         for (int64_t i = 0; i < n; ++i) h_theta_draws[slot + i * (int64_t)(S_it + 1)] = th[(size_t)i];
         GP_TRY(gpirt_sampler_get(s, "beta", h_beta_draws + (int64_t)slot * 2 * m, 2 * m));
         GP_TRY(gpirt_sampler_get(s, "f", h_f_draws + (int64_t)slot * n * m, n * m));
         return 0;
     };
+    auto snapshot = [&]() -> int {                          // enqueue on the compute stream
+        hipStream_t st = h->stream;
+        if (hipMemcpyAsync(snap_f, s->f, sizeof(double) * (size_t)(n * m), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(snap_small, s->theta, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(snap_small + n, s->beta, sizeof(double) * (size_t)(2 * m), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+            hipEventRecord(ev_snap, st) != hipSuccess)
+            return fail_hip("snapshot");
+        return 0;
+    };
+    auto drain = [&](int slot) -> int {                     // blocking for the host, not for the compute stream
+        if (hipStreamWaitEvent(copy_stream, ev_snap, 0) != hipSuccess) return fail_hip("hipStreamWaitEvent");
+        if (hipMemcpyAsync(h_f_draws + (int64_t)slot * n * m, snap_f, sizeof(double) * (size_t)(n * m),
+                           hipMemcpyDeviceToHost, copy_stream) != hipSuccess ||
+            hipMemcpyAsync(th.data(), snap_small, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, copy_stream) != hipSuccess ||
+            hipMemcpyAsync(h_beta_draws + (int64_t)slot * 2 * m, snap_small + n, sizeof(double) * (size_t)(2 * m),
+                           hipMemcpyDeviceToHost, copy_stream) != hipSuccess ||
+            hipStreamSynchronize(copy_stream) != hipSuccess)
+            return fail_hip("draw copy");
+        for (int64_t i = 0; i < n; ++i) h_theta_draws[slot + i * (int64_t)(S_it + 1)] = th[(size_t)i];
+        return 0;
+    };
+    auto post_flags = [&]() -> int {                        // async read-back of the sticky error words
+        hipStream_t st = h->stream;
+        if (hipMemcpyAsync(h_poll, h->d_info, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(h_poll + 1, s->flags, 2 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipEventRecord(ev_flags, st) != hipSuccess)
+            return fail_hip("flag read-back");
+        return 0;
+    };
+    auto inspect_flags = [&]() -> int {
+        if (h_poll[0] > 0) {
+            set_error("chol(): decomposition failed (leading minor of order %d is not positive definite)", h_poll[0]);
+            return h_poll[0];
+        }
+        if (h_poll[1] != 0) { set_error("sampler state is not finite (flag %d)", h_poll[1]); return h_poll[1]; }
+        return 0;
+    };
     const int total = S_it + B_it;
     rc = gpirt_sampler_init(s);
     if (!rc) rc = gpirt_sampler_check(s);
-    if (!rc) rc = store(0);
+    if (!rc) rc = store_sync(0);
+    if (!rc) {
+        if (hipMalloc(&snap_f, sizeof(double) * (size_t)(n * m)) != hipSuccess ||
+            hipMalloc(&snap_small, sizeof(double) * (size_t)(n + 2 * m)) != hipSuccess ||
+            hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_snap, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_flags, hipEventDisableTiming) != hipSuccess ||
+            hipHostMalloc(&h_poll, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess)
+            rc = fail_hip("allocation");
+    }
+    s->sticky_info = true;            // potrf no longer clears its info word: first failure sticks
+    int pending = -1;
+    bool flags_posted = false;
     for (int it = 0; it < total && !rc; ++it) {
         if (tick && tick(tick_ctx, it, total)) { set_error("interrupted"); rc = GPIRT_E_INTERRUPT; break; }
+        if (flags_posted && hipEventQuery(ev_flags) == hipSuccess) {       // non-blocking poll
+            rc = inspect_flags();
+            if (rc) break;
+        }
         rc = gpirt_sampler_step(s);
-        if (!rc) rc = gpirt_sampler_check(s);
+        if (!rc) { rc = post_flags(); flags_posted = true; }
+        if (!rc && pending >= 0) { rc = drain(pending); pending = -1; }    // overlaps the step just enqueued
         if (!rc && it >= B_it) {
-            rc = store(it - B_it + 1);
-            if (!rc) rc = gpirt_sampler_accumulate_irf(s);
+            rc = gpirt_sampler_accumulate_irf(s);                          // :103
+            if (!rc) rc = snapshot();
+            pending = it - B_it + 1;
         }
     }
+    if (!rc && pending >= 0) rc = drain(pending);
+    if (rc != GPIRT_E_INTERRUPT) {
+        const int rc2 = gpirt_sampler_check(s);                            // final, synchronising
+        if (!rc) rc = rc2;
+    }
+    cleanup();
     if (!rc) rc = gpirt_sampler_finish_irfs(s, S_it, h_irfs);
     gpirt_sampler_destroy(s);
     gpirt_destroy(h);

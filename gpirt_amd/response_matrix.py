@@ -35,12 +35,32 @@ def response_matrix(data, response_codes=None):
     raw = np.asarray(data)
     if raw.ndim != 2:
         raise ValueError("data must be a 2-d array (respondents x items)")
-    obj = raw.astype(object)
-    isna = np.array([[v is None or (isinstance(v, float) and np.isnan(v)) for v in row] for row in obj],
-                    dtype=bool).reshape(obj.shape)
-    yea = _isin(obj, np.atleast_1d(codes["yea"])) & ~isna
-    nay = _isin(obj, np.atleast_1d(codes["nay"])) & ~isna
-    mis = _isin(obj, np.atleast_1d(codes["missing"])) | isna
+    if raw.dtype.kind in "fiub":                       # numeric input: vectorised recode
+        num = raw.astype(np.float64)
+        isna = np.isnan(num)
+
+        def _num_codes(cs):
+            out = []
+            for c in np.atleast_1d(np.array(list(cs), dtype=object)):
+                if c is None or (isinstance(c, float) and np.isnan(c)):
+                    continue
+                try:
+                    out.append(float(c))
+                except (TypeError, ValueError):
+                    pass                               # a string code can never match a number
+            return np.array(out, dtype=np.float64)
+
+        yea = np.isin(num, _num_codes(codes["yea"])) & ~isna
+        nay = np.isin(num, _num_codes(codes["nay"])) & ~isna
+        mis = np.isin(num, _num_codes(codes["missing"])) | isna
+        obj = num
+    else:
+        obj = raw.astype(object)
+        isna = np.array([[v is None or (isinstance(v, float) and np.isnan(v)) for v in row] for row in obj],
+                        dtype=bool).reshape(obj.shape)
+        yea = _isin(obj, np.atleast_1d(codes["yea"])) & ~isna
+        nay = _isin(obj, np.atleast_1d(codes["nay"])) & ~isna
+        mis = _isin(obj, np.atleast_1d(codes["missing"])) | isna
     unknown = ~(yea | nay | mis)
     if unknown.any():                                  # :72-77
         vals = sorted({str(v) for v in obj[unknown]})
@@ -50,12 +70,9 @@ def response_matrix(data, response_codes=None):
     res[yea] = 1.0                                     # :79-81
     res[nay] = -1.0
     res[mis] = np.nan
-    keep = np.ones(res.shape[1], dtype=bool)           # :87-90
-    for j in range(res.shape[1]):
-        col = res[:, j]
-        u = np.unique(col[~np.isnan(col)])
-        if len(u) == 1:
-            keep[j] = False
+    has_pos = np.any(res == 1.0, axis=0)               # :87-90  length(unique(na.omit(x))) == 1
+    has_neg = np.any(res == -1.0, axis=0)
+    keep = ~(has_pos ^ has_neg)
     if (~keep).any():
         idx = ", ".join(str(i + 1) for i in np.nonzero(~keep)[0])
         warnings.warn(f"Item(s) {idx} discarded as unanimous.")
