@@ -21,6 +21,7 @@
 // log-likelihood sums of src/draw-theta.cpp:15-19 restated as a GEMM.
 #include "common.h"
 #include "kernels.h"
+#include "potf2.h"
 
 namespace gpirt {
 
@@ -46,6 +47,8 @@ struct GemmParams {
     int tri;
     int mblocks, nblocks;
     int fastA, fastB;     // operand base/ld are 16-byte friendly
+    // fused epilogue (FUSE kernels only): work-group 0 factors this 64 x 64 block after its tile
+    double* fz_A; int64_t fz_lda; int fz_nb; int fz_k0; int* fz_info;
 };
 
 template <bool KCONTIG, int T>
@@ -224,7 +227,10 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int bi, con
 }
 
 // PAD only distinguishes instantiations by name (see launch_gemm_trailing); it adds PAD doubles of LDS.
-template <bool TA, bool TB, int T, int PAD = 0>
+// FUSE: the work-group that owns work item 0 (the tile holding the next diagonal block of the Cholesky
+// panel) factors that block right after producing it -- the potf2 launch and its kernel boundary
+// disappear from the panel chain (potrf.hip).
+template <bool TA, bool TB, int T, int PAD = 0, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p)
 {
     __shared__ __attribute__((aligned(16))) double smem[4 * Cfg<T>::TILE + PAD];
@@ -256,6 +262,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p)
         bj = blockIdx.x / p.mblocks;
     }
     gemm_tile<TA, TB, T>(p, bi, bj, smem);
+    if (FUSE) {
+        __shared__ int sfail;
+        if (blockIdx.x == 0 && p.fz_A != nullptr) {
+            // the tile was written by this work-group's own lanes: make the stores visible to all of them
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            potf2_64_body(p.fz_A, p.fz_lda, p.fz_nb, p.fz_k0, p.fz_info, smem, &sfail);
+        }
+    }
 }
 
 }  // namespace
@@ -273,6 +289,28 @@ static int launch_gemm_trailing(hipStream_t stream, GemmParams p)
     p.nblocks = (p.N + T - 1) / T;
     const int64_t grid = (int64_t)p.nblocks * p.mblocks - (int64_t)p.nblocks * (p.nblocks - 1) / 2;
     hipLaunchKernelGGL((gemm_f64_kernel<false, true, 128, 8>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    GP_HIP(hipGetLastError());
+    return 0;
+}
+
+// Panel update of the blocked Cholesky (K <= 64, lower trapezoid) with the factorisation of the next
+// diagonal block fused into work-group 0: C = A[r0:, r0:c1] and the block is C's leading 64 x 64 tile.
+int launch_gemm_update_potf2(hipStream_t stream, int64_t M, int64_t N, int64_t K, const double* P, int64_t ldp,
+                             double* C, int64_t ldc, int nb_next, int k0_next, int* info)
+{
+    if (M <= 0 || N <= 0) return 0;
+    constexpr int T = 64;
+    GemmParams p;
+    p.A = P; p.B = P; p.C = C;
+    p.lda = ldp; p.ldb = ldp; p.ldc = ldc;
+    p.M = (int)M; p.N = (int)N; p.K = (int)K;
+    p.alpha = -1.0; p.beta = 1.0; p.tri = TRI_SYRK_LOWER;
+    p.fastA = p.fastB = (((uintptr_t)P & 15) == 0) && (ldp % 2 == 0);
+    p.mblocks = (p.M + T - 1) / T;
+    p.nblocks = (p.N + T - 1) / T;
+    p.fz_A = C; p.fz_lda = ldc; p.fz_nb = nb_next; p.fz_k0 = k0_next; p.fz_info = info;
+    const int64_t grid = (int64_t)p.nblocks * p.mblocks - (int64_t)p.nblocks * (p.nblocks - 1) / 2;
+    hipLaunchKernelGGL((gemm_f64_kernel<false, true, 64, 0, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
     GP_HIP(hipGetLastError());
     return 0;
 }
@@ -313,6 +351,7 @@ int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri,
     p.M = (int)M; p.N = (int)N; p.K = (int)K;
     p.alpha = alpha; p.beta = beta; p.tri = tri;
     p.mblocks = p.nblocks = 0;
+    p.fz_A = nullptr; p.fz_lda = 0; p.fz_nb = 0; p.fz_k0 = 0; p.fz_info = nullptr;
     p.fastA = (((uintptr_t)A & 15) == 0) && (lda % 2 == 0);
     p.fastB = (((uintptr_t)B & 15) == 0) && (ldb % 2 == 0);
     if (tri == TRI_SYRK_LOWER_TRAILING) {

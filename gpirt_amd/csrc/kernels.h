@@ -6,7 +6,9 @@
 namespace gpirt {
 
 enum { TRI_NONE = 0, TRI_SYRK_LOWER = 1, TRI_A_LOWER = 2, TRI_A_UPPER = 3, TRI_SYRK_LOWER_TRAILING = 4 };
-bool gemm_trailing_uses_128(int64_t M, int64_t N);   // does a trailing update of this shape run the 128-tile kernel?
+bool gemm_trailing_uses_128(int64_t M, int64_t N);
+int launch_gemm_update_potf2(hipStream_t stream, int64_t M, int64_t N, int64_t K, const double* P, int64_t ldp,
+                             double* C, int64_t ldc, int nb_next, int k0_next, int* info);   // does a trailing update of this shape run the 128-tile kernel?
 
 // gemm_f64.hip
 int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri, int64_t M,

@@ -1,0 +1,128 @@
+// potf2.h -- 64 x 64 Cholesky of a diagonal block by one 256-thread work-group (device function, so the
+// panel-update GEMM can run it as the epilogue of the tile that produces the next diagonal block).
+#pragma once
+
+#include "common.h"
+
+namespace gpirt {
+
+// ------------------------------------------------------------------ diagonal block ---------
+// 64 x 64 Cholesky in one work-group, register tiled: thread (tr, tc) = (t & 15, t >> 4) owns the
+// 4 x 4 tile rows 4tr.., columns 4tc.. .  Per 4-column panel jb: the 16 lanes that own it (one
+// contiguous 16-lane group of one wavefront) factor it with v_readlane broadcasts of the pivot
+// row -- no barrier inside the panel --, publish it to LDS, and after ONE barrier every trailing
+// tile applies the rank-4 update from registers.  16 barriers in total (the unblocked version
+// this replaces needed 192 and ran 83 us; see profiles/).
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// sPm: 2 * 4 * 64 doubles of LDS (16-byte aligned), sfail_p: one int of LDS.  All 256 threads of the
+// work-group must call it.
+__device__ __forceinline__ void potf2_64_body(double* __restrict__ A, int64_t lda, int nb, int k0,
+                                              int* __restrict__ info, double* __restrict__ sPm,
+                                              int* __restrict__ sfail_p)
+{
+    constexpr int NBI = 64;
+    double (*sP)[4 * NBI] = reinterpret_cast<double (*)[4 * NBI]>(sPm);   // sP[buf][k * 64 + row]
+    int& sfail = *sfail_p;
+    __builtin_amdgcn_s_setprio(3);   // latency-bound chain: win issue arbitration against co-resident GEMM waves
+    const int t = threadIdx.x;
+    const int tr = t & 15, tc = t >> 4;
+    double a[4][4];                                                   // a[i][k]: row 4tr+i, col 4tc+k
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 4 * tr + i, col = 4 * tc + k;
+            double v = (row == col) ? 1.0 : 0.0;                      // identity padding for nb < 64
+            if (row >= col && row < nb && col < nb) v = A[(int64_t)row + (int64_t)col * lda];
+            a[i][k] = v;
+        }
+    if (t == 0) sfail = 0x7fffffff;
+    __syncthreads();
+    int fail = 0x7fffffff;
+#pragma unroll
+    for (int jb = 0; jb < 16; ++jb) {
+        const int buf = jb & 1;
+        if (tc == jb && tr >= jb) {
+            // The 16-lane group of panel jb.  Lane `src` (tr == jb) holds the 4 x 4 diagonal tile and
+            // factors it in place with static indices; the lanes below (tr > jb) hold full tiles and
+            // need no per-element predicates -- the two roles diverge once per column.
+            const int src = jb + 16 * (jb & 3);
+            const bool is_diag = (tr == jb);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = 4 * jb + jj;
+                const double d = readlane_f64(a[jj][jj], src);
+                if (!(d > 0.0) && j < nb && fail == 0x7fffffff) fail = j + 1;
+                // pivot column scaled by 1/sqrt(d) (LAPACK dpotf2 scales by the reciprocal too);
+                // rsqrt keeps the 64-step dependent chain short.  d <= 0 gives NaN: propagates.
+                const double rinv = (d > 0.0) ? rsqrt(d) : __builtin_nan("");
+                if (is_diag) {
+                    a[jj][jj] = d * rinv;
+#pragma unroll
+                    for (int i = jj + 1; i < 4; ++i) a[i][jj] *= rinv;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a[i][jj] *= rinv;
+                }
+#pragma unroll
+                for (int jj2 = jj + 1; jj2 < 4; ++jj2) {
+                    const double lc = readlane_f64(a[jj2][jj], src);  // L[4jb+jj2][j]
+                    if (is_diag) {
+#pragma unroll
+                        for (int i = jj2; i < 4; ++i) a[i][jj2] = fma(-a[i][jj], lc, a[i][jj2]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) a[i][jj2] = fma(-a[i][jj], lc, a[i][jj2]);
+                    }
+                }
+            }
+            // publish the panel: sP[buf][k * 64 + row]; the strict upper part of the diagonal tile is zero
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                double4 v;
+                v.x = (is_diag && 0 < k) ? 0.0 : a[0][k];
+                v.y = (is_diag && 1 < k) ? 0.0 : a[1][k];
+                v.z = (is_diag && 2 < k) ? 0.0 : a[2][k];
+                v.w = a[3][k];
+                *reinterpret_cast<double4*>(&sP[buf][k * NBI + 4 * tr]) = v;
+            }
+        }
+        __syncthreads();
+        if (tc > jb && tr >= tc) {
+            double4 lr[4], lcn[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                lr[k] = *reinterpret_cast<const double4*>(&sP[buf][k * NBI + 4 * tr]);
+                lcn[k] = *reinterpret_cast<const double4*>(&sP[buf][k * NBI + 4 * tc]);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double r4[4] = { lr[k].x, lr[k].y, lr[k].z, lr[k].w };
+                const double c4[4] = { lcn[k].x, lcn[k].y, lcn[k].z, lcn[k].w };
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) a[i][kk] = fma(-r4[i], c4[kk], a[i][kk]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 4 * tr + i, col = 4 * tc + k;
+            if (row >= col && row < nb && col < nb) A[(int64_t)row + (int64_t)col * lda] = a[i][k];
+        }
+    if (fail != 0x7fffffff) atomicMin(&sfail, fail);
+    __syncthreads();
+    if (t == 0 && sfail != 0x7fffffff) atomicCAS(info, 0, k0 + sfail);
+}
+
+
+}  // namespace gpirt

@@ -17,6 +17,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "solve64.h"
+#include "potf2.h"
 
 #include <stdlib.h>
 
@@ -28,117 +29,12 @@ constexpr int NBI = 64;
 constexpr int NBO = 512;
 
 // ------------------------------------------------------------------ diagonal block ---------
-// 64 x 64 Cholesky in one work-group, register tiled: thread (tr, tc) = (t & 15, t >> 4) owns the
-// 4 x 4 tile rows 4tr.., columns 4tc.. .  Per 4-column panel jb: the 16 lanes that own it (one
-// contiguous 16-lane group of one wavefront) factor it with v_readlane broadcasts of the pivot
-// row -- no barrier inside the panel --, publish it to LDS, and after ONE barrier every trailing
-// tile applies the rank-4 update from registers.  16 barriers in total (the unblocked version
-// this replaces needed 192 and ran 83 us; see profiles/).
-__device__ __forceinline__ double readlane_f64(double v, int lane)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
-
 __global__ __launch_bounds__(256) void potf2_64_kernel(double* __restrict__ A, int64_t lda, int nb,
                                                        int k0, int* __restrict__ info)
 {
-    __shared__ __attribute__((aligned(16))) double sP[2][4 * NBI];   // sP[buf][k * 64 + row]
+    __shared__ __attribute__((aligned(16))) double sP[2 * 4 * NBI];
     __shared__ int sfail;
-    __builtin_amdgcn_s_setprio(3);   // latency-bound chain: win issue arbitration against co-resident GEMM waves
-    const int t = threadIdx.x;
-    const int tr = t & 15, tc = t >> 4;
-    double a[4][4];                                                   // a[i][k]: row 4tr+i, col 4tc+k
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = 4 * tr + i, col = 4 * tc + k;
-            double v = (row == col) ? 1.0 : 0.0;                      // identity padding for nb < 64
-            if (row >= col && row < nb && col < nb) v = A[(int64_t)row + (int64_t)col * lda];
-            a[i][k] = v;
-        }
-    if (t == 0) sfail = 0x7fffffff;
-    __syncthreads();
-    int fail = 0x7fffffff;
-#pragma unroll
-    for (int jb = 0; jb < 16; ++jb) {
-        const int buf = jb & 1;
-        if (tc == jb && tr >= jb) {
-            // The 16-lane group of panel jb.  Lane `src` (tr == jb) holds the 4 x 4 diagonal tile and
-            // factors it in place with static indices; the lanes below (tr > jb) hold full tiles and
-            // need no per-element predicates -- the two roles diverge once per column.
-            const int src = jb + 16 * (jb & 3);
-            const bool is_diag = (tr == jb);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int j = 4 * jb + jj;
-                const double d = readlane_f64(a[jj][jj], src);
-                if (!(d > 0.0) && j < nb && fail == 0x7fffffff) fail = j + 1;
-                // pivot column scaled by 1/sqrt(d) (LAPACK dpotf2 scales by the reciprocal too);
-                // rsqrt keeps the 64-step dependent chain short.  d <= 0 gives NaN: propagates.
-                const double rinv = (d > 0.0) ? rsqrt(d) : __builtin_nan("");
-                if (is_diag) {
-                    a[jj][jj] = d * rinv;
-#pragma unroll
-                    for (int i = jj + 1; i < 4; ++i) a[i][jj] *= rinv;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) a[i][jj] *= rinv;
-                }
-#pragma unroll
-                for (int jj2 = jj + 1; jj2 < 4; ++jj2) {
-                    const double lc = readlane_f64(a[jj2][jj], src);  // L[4jb+jj2][j]
-                    if (is_diag) {
-#pragma unroll
-                        for (int i = jj2; i < 4; ++i) a[i][jj2] = fma(-a[i][jj], lc, a[i][jj2]);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) a[i][jj2] = fma(-a[i][jj], lc, a[i][jj2]);
-                    }
-                }
-            }
-            // publish the panel: sP[buf][k * 64 + row]; the strict upper part of the diagonal tile is zero
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                double4 v;
-                v.x = (is_diag && 0 < k) ? 0.0 : a[0][k];
-                v.y = (is_diag && 1 < k) ? 0.0 : a[1][k];
-                v.z = (is_diag && 2 < k) ? 0.0 : a[2][k];
-                v.w = a[3][k];
-                *reinterpret_cast<double4*>(&sP[buf][k * NBI + 4 * tr]) = v;
-            }
-        }
-        __syncthreads();
-        if (tc > jb && tr >= tc) {
-            double4 lr[4], lcn[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                lr[k] = *reinterpret_cast<const double4*>(&sP[buf][k * NBI + 4 * tr]);
-                lcn[k] = *reinterpret_cast<const double4*>(&sP[buf][k * NBI + 4 * tc]);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const double r4[4] = { lr[k].x, lr[k].y, lr[k].z, lr[k].w };
-                const double c4[4] = { lcn[k].x, lcn[k].y, lcn[k].z, lcn[k].w };
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) a[i][kk] = fma(-r4[i], c4[kk], a[i][kk]);
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = 4 * tr + i, col = 4 * tc + k;
-            if (row >= col && row < nb && col < nb) A[(int64_t)row + (int64_t)col * lda] = a[i][k];
-        }
-    if (fail != 0x7fffffff) atomicMin(&sfail, fail);
-    __syncthreads();
-    if (t == 0 && sfail != 0x7fffffff) atomicCAS(info, 0, k0 + sfail);
+    potf2_64_body(A, lda, nb, k0, info, sP, &sfail);
 }
 
 // ------------------------------------------------------------------ panel solve ------------
@@ -205,12 +101,17 @@ __global__ void zero_upper_kernel(double* __restrict__ A, int64_t n, int64_t lda
 namespace {
 
 // inner loop of one outer panel: columns [K0, c1), every row below; 64-column steps
-int factor_panel(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t K0, int64_t c1)
+int factor_panel(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t K0, int64_t c1,
+                 bool first_diag_done = false)
 {
+    static const bool fuse = !(getenv("GPIRT_FUSE_POTF2") && atoi(getenv("GPIRT_FUSE_POTF2")) == 2);
     for (int64_t k0 = K0; k0 < c1; k0 += NBI) {
         const int nb = (int)((c1 - k0) < NBI ? (c1 - k0) : NBI);
-        hipLaunchKernelGGL(potf2_64_kernel, dim3(1), dim3(256), 0, stream, A + k0 + k0 * lda, lda, nb, (int)k0,
-                           h->d_info);
+        // only the first diagonal block of an outer panel needs its own potf2 launch: every later one is
+        // factored by work-group 0 of the previous step's panel update (fused epilogue, gemm_f64.hip)
+        if ((k0 == K0 && !first_diag_done) || !fuse)
+            hipLaunchKernelGGL(potf2_64_kernel, dim3(1), dim3(256), 0, stream, A + k0 + k0 * lda, lda, nb, (int)k0,
+                               h->d_info);
         const int64_t r0 = k0 + nb;
         if (r0 >= n) break;
         const int64_t rows = n - r0;
@@ -218,8 +119,14 @@ int factor_panel(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int
                            n, k0, nb, r0);
         if (r0 < c1) {
             // rest of the outer panel: A[r0:n, r0:c1] -= A[r0:n, k0:r0] A[r0:c1, k0:r0]^T
-            GP_TRY(launch_gemm(h, stream, false, true, TRI_SYRK_LOWER, rows, c1 - r0, nb, -1.0,
-                               A + r0 + k0 * lda, lda, A + r0 + k0 * lda, lda, 1.0, A + r0 + r0 * lda, lda));
+            if (fuse) {
+                const int nb_next = (int)((c1 - r0) < NBI ? (c1 - r0) : NBI);
+                GP_TRY(launch_gemm_update_potf2(stream, rows, c1 - r0, nb, A + r0 + k0 * lda, lda, A + r0 + r0 * lda,
+                                                lda, nb_next, (int)r0, h->d_info));
+            } else {
+                GP_TRY(launch_gemm(h, stream, false, true, TRI_SYRK_LOWER, rows, c1 - r0, nb, -1.0,
+                                   A + r0 + k0 * lda, lda, A + r0 + k0 * lda, lda, 1.0, A + r0 + r0 * lda, lda));
+            }
         }
     }
     return 0;
@@ -228,7 +135,7 @@ int factor_panel(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int
 // trailing update restricted to the column range [lo, hi):
 //   A[lo:n, lo:hi] -= A[lo:n, K0:c1] A[lo:hi, K0:c1]^T      (lower trapezoid, fp64 MFMA syrk)
 int trailing(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t K0, int64_t c1,
-             int64_t lo, int64_t hi)
+             int64_t lo, int64_t hi, bool* fused_potf2 = nullptr)
 {
     const int64_t M = n - lo, N = hi - lo, K = c1 - K0;
     // the roofline figure covers the launches of the dominant kernel only (128-tile syrk)
@@ -238,6 +145,16 @@ int trailing(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t
         if (!h->prof.free_pairs.empty()) { pp = h->prof.free_pairs.back(); h->prof.free_pairs.pop_back(); }
         else { GP_HIP(hipEventCreate(&pp.e0)); GP_HIP(hipEventCreate(&pp.e1)); }
         GP_HIP(hipEventRecord(pp.e0, stream));
+    }
+    static const bool fuse = !(getenv("GPIRT_FUSE_POTF2") && atoi(getenv("GPIRT_FUSE_POTF2")) == 2);
+    if (fused_potf2) *fused_potf2 = false;
+    if (fused_potf2 && fuse && !gemm_trailing_uses_128(M, N)) {
+        // 64-tile launch: work-group 0 also factors the first diagonal block of the next panel
+        const int nb_next = (int)(N < NBI ? N : NBI);
+        GP_TRY(launch_gemm_update_potf2(stream, M, N, K, A + lo + K0 * lda, lda, A + lo + lo * lda, lda, nb_next,
+                                        (int)lo, h->d_info));
+        *fused_potf2 = true;
+        return 0;
     }
     GP_TRY(launch_gemm(h, stream, false, true, TRI_SYRK_LOWER_TRAILING, M, N, K, -1.0,
                        A + lo + K0 * lda, lda, A + lo + K0 * lda, lda, 1.0, A + lo + lo * lda, lda));
@@ -287,17 +204,18 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
         const int64_t c1 = (K0 + nbo < n) ? K0 + nbo : n;
         if (c1 >= n) break;
         const int64_t c2 = (c1 + nbo < n) ? c1 + nbo : n;
-        GP_TRY(trailing(h, stream, A, n, lda, K0, c1, c1, c2));           // columns of the next panel
+        bool diag_done = false;
+        GP_TRY(trailing(h, stream, A, n, lda, K0, c1, c1, c2, &diag_done)); // columns of the next panel
         if (la && c2 < n) {
             GP_HIP(hipEventRecord(h->ev_fork, stream));
             GP_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-            GP_TRY(factor_panel(h, h->side, A, n, lda, c1, c2));          // next panel, side stream
+            GP_TRY(factor_panel(h, h->side, A, n, lda, c1, c2, diag_done)); // next panel, side stream
             GP_TRY(trailing(h, stream, A, n, lda, K0, c1, c2, n));        // the rest, concurrently
             GP_HIP(hipEventRecord(h->ev_join, h->side));
             GP_HIP(hipStreamWaitEvent(stream, h->ev_join, 0));
         } else {
             if (c2 < n) GP_TRY(trailing(h, stream, A, n, lda, K0, c1, c2, n));
-            GP_TRY(factor_panel(h, stream, A, n, lda, c1, c2));
+            GP_TRY(factor_panel(h, stream, A, n, lda, c1, c2, diag_done));
         }
     }
     if (zero_upper) {
