@@ -132,6 +132,71 @@ __global__ __launch_bounds__(256) void ess_kernel(EssArgs a)
     }
 }
 
+// Register-resident variant for n <= 256 * EPT: each lane keeps its EPT entries of f, nu, mu and y in
+// registers, so the (2 + k) likelihood passes of a column touch memory once; arithmetic is identical
+// to ess_kernel (same per-element expression, same reduction tree).
+template <int EPT>
+__global__ __launch_bounds__(256) void ess_kernel_reg(EssArgs a)
+{
+    __shared__ double red[4];
+    const int64_t j = blockIdx.x;
+    const int64_t n = a.n;
+    double* fj = a.f + j * n;
+    const double* nj = a.nu + j * n;
+    const double* yj = a.y + j * n;
+    const double* mj = a.mu + j * n;
+    const uint32_t item = a.item0 + (uint32_t)j;
+    double F[EPT], V[EPT], M[EPT], Y[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int64_t i = threadIdx.x + 256 * e;
+        const bool in = i < n;
+        F[e] = in ? fj[i] : 0.0;
+        V[e] = in ? nj[i] : 0.0;
+        M[e] = in ? mj[i] : 0.0;
+        Y[e] = in ? yj[i] : __builtin_nan("");      // NaN = skipped, like a missing response
+    }
+    uint32_t uidx = 0;
+    double acc = 0.0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e)
+        if (Y[e] == Y[e]) acc += ll_term(Y[e] * (F[e] + M[e]));
+    const double ll0 = -block_sum_256(acc, red);
+    const double u = item_uniform(a.seed, a.iter, GPIRT_ST_F_ESS, item, uidx++);
+    const double log_y = ll0 + log(u);                                     // draw-f.cpp:28-29
+    double eps_min = 0.0, eps_max = GP_2PI;
+    double eps = eps_min + (eps_max - eps_min) * item_uniform(a.seed, a.iter, GPIRT_ST_F_ESS, item, uidx++);
+    eps_min = eps - GP_2PI;                                                // :36
+    int k = 0;
+    bool bad = false;
+    double c, s;
+    for (;;) {
+        c = cos(eps);
+        s = sin(eps);
+        acc = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e)
+            if (Y[e] == Y[e]) acc += ll_term(Y[e] * ((F[e] * c + V[e] * s) + M[e]));   // :43
+        const double llp = -block_sum_256(acc, red);
+        if (llp > log_y) break;                                            // :45-47
+        if (llp != llp) { bad = true; break; }
+        if (eps < 0.0) eps_min = eps; else eps_max = eps;                  // :50-55
+        if (eps_min == eps_max) eps = eps_min;
+        else eps = eps_min + (eps_max - eps_min) * item_uniform(a.seed, a.iter, GPIRT_ST_F_ESS, item, uidx++);
+        ++k;
+        if (k >= ESS_MAX_TRIALS) { bad = true; break; }
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int64_t i = threadIdx.x + 256 * e;
+        if (i < n) fj[i] = F[e] * c + V[e] * s;
+    }
+    if (threadIdx.x == 0) {
+        if (a.k_out) a.k_out[j] = k;
+        if (bad && a.err) atomicCAS(a.err, 0, (int)GPIRT_E_NUMERIC);
+    }
+}
+
 __global__ void advance_pos_kernel(uint64_t* pos, uint64_t delta) { *pos += delta; }
 
 }  // namespace
@@ -174,7 +239,12 @@ int launch_ll_bar(hipStream_t stream, const double* f, const double* y, const do
 int launch_ess(hipStream_t stream, const EssArgs& a)
 {
     if (a.m <= 0) return 0;
-    hipLaunchKernelGGL(ess_kernel, dim3((unsigned)a.m), dim3(256), 0, stream, a);
+    if (a.U == nullptr && a.n <= 256 * 8)
+        hipLaunchKernelGGL(ess_kernel_reg<8>, dim3((unsigned)a.m), dim3(256), 0, stream, a);
+    else if (a.U == nullptr && a.n <= 256 * 32)
+        hipLaunchKernelGGL(ess_kernel_reg<32>, dim3((unsigned)a.m), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(ess_kernel, dim3((unsigned)a.m), dim3(256), 0, stream, a);
     GP_HIP(hipGetLastError());
     return 0;
 }
