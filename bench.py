@@ -204,7 +204,7 @@ def main():
                 "item_sharded_stages": ["draw_f", "draw_fstar", "theta_gemm", "draw_beta"],
             },
             "roofline": {
-                "kernel": "gemm_f64_kernel<false, true, 128, 8> (potrf trailing update, syrk lower, v_mfma_f64_16x16x4_f64)",
+                "kernel": "gemm_f64_kernel<false, true, 128, 8, false> (potrf trailing update, syrk lower, v_mfma_f64_16x16x4_f64)",
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": PEAK_FP64_MFMA_TFLOPS,

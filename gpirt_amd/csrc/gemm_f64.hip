@@ -23,6 +23,8 @@
 #include "kernels.h"
 #include "potf2.h"
 
+#include <stdlib.h>
+
 namespace gpirt {
 
 namespace {
@@ -365,7 +367,8 @@ int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri,
     const int64_t mb = (M + 127) / 128, nb = (N + 127) / 128;
     int64_t blocks128 = (tri == TRI_SYRK_LOWER) ? nb * mb - nb * (nb - 1) / 2 : mb * nb;
     if (tri == TRI_A_LOWER || tri == TRI_A_UPPER) blocks128 *= 2;     // paired: one work-group per CU suffices
-    if (blocks128 >= 448) return launch_gemm_t<128>(stream, ta, tb, p);
+    static const int t128_min = getenv("GPIRT_T128_MIN") ? atoi(getenv("GPIRT_T128_MIN")) : 448;
+    if (blocks128 >= t128_min) return launch_gemm_t<128>(stream, ta, tb, p);
     return launch_gemm_t<64>(stream, ta, tb, p);
 }
 

@@ -2,7 +2,7 @@
 import collections, csv, glob, json, os, shutil, sys
 raw = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/profiles_raw"
 tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
-KERNEL = "gemm_f64_kernel<false, true, 128, 8>"
+KERNEL = "gemm_f64_kernel<false, true, 128, 8"
 stats = sorted(glob.glob(raw + "/stats/runc/*kernel_stats.csv"))[-1]
 shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
 rows = list(csv.DictReader(open(stats)))
@@ -22,7 +22,7 @@ traffic = (2 * fetch_kb + write_kb) * 1024
 gui, busy = mf["GRBM_GUI_ACTIVE"][0], mf["SQ_VALU_MFMA_BUSY_CYCLES"][0]
 util = busy / ((gui / 8) * 1024)
 tr = [r for r in rows if KERNEL in r["Name"]][0]
-json.dump({"kernel": KERNEL + " (potrf trailing update)", "hbm_bytes_per_launch": traffic,
+json.dump({"kernel": KERNEL + ", false> (potrf trailing update)", "hbm_bytes_per_launch": traffic,
            "fetch_size_kb_raw": fetch_kb, "write_size_kb": write_kb,
            "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950 reports "
                    "half of wide coalesced reads, MI355X_MICROARCH.md HBM section); average over the 128-tile trailing "
@@ -34,7 +34,7 @@ with open(f"profiles/{tag}_summary.md", "w") as f:
     f.write(f"# Round {tag[1:]} profiles (MI355X, ROCm 7.2, `python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline` under rocprofv3)\n\n")
     f.write(f"Raw per-kernel statistics: `profiles/{tag}_kernel_stats.csv` (rocprofv3 --kernel-trace --stats); collected by `tools/collect_profiles.sh`, summarised by `tools/summarize_profiles.py`.\n\n")
     f.write(f"bench.py line of the profiled run: {bench['value']:.2f} it/s, {bench['ms_per_step']:.2f} ms/step, stages {bench['config']['stage_ms']}\n\n")
-    f.write(f"## Dominant kernel: potrf trailing update `{KERNEL}` (fp64 MFMA syrk, lower blocks)\n\n")
+    f.write(f"## Dominant kernel: potrf trailing update `{KERNEL}, false>` (fp64 MFMA syrk, lower blocks)\n\n")
     f.write("| source | launches | avg duration (ms) | achieved TFLOP/s | frac of 78.6 |\n|---|---|---|---|---|\n")
     f.write(f"| bench.py HIP events (timed region) | {rl['launches']} | {rl['avg_launch_ms']:.4f} | {rl['achieved']:.2f} | {rl['frac']:.3f} |\n")
     avg_ms = float(tr["AverageNs"]) / 1e6
