@@ -47,6 +47,19 @@ __global__ __launch_bounds__(256) void panel_trsm_64_kernel(double* __restrict__
     __shared__ __attribute__((aligned(16))) double sM[NBI * S64_LS];
     __builtin_amdgcn_s_setprio(3);
     const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int64_t row = r0 + (int64_t)blockIdx.x * 64 + wave * 16 + i;
+    const bool live = row < n;
+    // the wave's own rows first: these loads do not depend on the staged block and fly while it lands
+    d4 X[4];
+#pragma unroll
+    for (int J = 0; J < 4; ++J)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * J + 4 * g + r;
+            X[J][r] = (live && c < nb) ? A[row + (k0 + c) * lda] : 0.0;
+        }
     {
         double v[16];
 #pragma unroll
@@ -65,18 +78,6 @@ __global__ __launch_bounds__(256) void panel_trsm_64_kernel(double* __restrict__
         }
     }
     __syncthreads();
-    const int lane = t & 63, wave = t >> 6;
-    const int i = lane & 15, g = lane >> 4;
-    const int64_t row = r0 + (int64_t)blockIdx.x * 64 + wave * 16 + i;
-    const bool live = row < n;
-    d4 X[4];
-#pragma unroll
-    for (int J = 0; J < 4; ++J)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int c = 16 * J + 4 * g + r;
-            X[J][r] = (live && c < nb) ? A[row + (k0 + c) * lda] : 0.0;
-        }
     solve64_lower(X, sM);
     if (live) {
 #pragma unroll

@@ -60,8 +60,6 @@ __global__ __launch_bounds__(256) void trsm_leaf_kernel(const double* __restrict
 {
     __shared__ __attribute__((aligned(16))) double sM[NL * S64_LS];
     const int t = threadIdx.x;
-    stage_block<BACK>(L, ldl, nb, 0, 0, true, sM);
-    __syncthreads();
     const int lane = t & 63, wave = t >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int64_t col = (int64_t)blockIdx.x * CB + wave * 16 + i;
@@ -76,6 +74,8 @@ __global__ __launch_bounds__(256) void trsm_leaf_kernel(const double* __restrict
             const int p = BACK ? (nb - 1 - c) : c;
             X[J][r] = (live && c < nb) ? b[p] : 0.0;
         }
+    stage_block<BACK>(L, ldl, nb, 0, 0, true, sM);
+    __syncthreads();
     solve64_lower(X, sM);
     if (live) {
 #pragma unroll
