@@ -86,11 +86,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=8192)
-    ap.add_argument("--m", type=int, default=1024)
+    ap.add_argument("--respondents", "--n", dest="n", type=int, default=8192)
+    ap.add_argument("--items", "--m", dest="m", type=int, default=1024)
     ap.add_argument("--chol", default="replicated", choices=["replicated", "bcast"])
     ap.add_argument("--fstar", default="fused", choices=["double_solve", "fused"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal: every rank uses cuda:0 (needs --backend gloo; RCCL refuses duplicate devices)")
     args = ap.parse_args()
 
     import numpy as np
@@ -102,11 +106,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from gpirt_amd.distributed import ShardedSampler
