@@ -191,3 +191,21 @@ def test_sampler_recovers_the_latent_trait(handle):
     assert abs(r) > 0.9, r
     irf = res["IRFs"]
     assert irf.min() >= 0.0 and irf.max() <= 1.0
+
+
+def test_config_c2_reference_rng_draw_for_draw(handle, oracle):
+    """BASELINE config C2 (N = 1024 x m = 256): one full iteration under R's stream, every stored draw
+    against the oracle (~10 s of CPU for the oracle's draw_theta)."""
+    from gpirt_amd import gpirtMCMC
+    from gpirt_amd.ops import RStream
+    from gpirt_amd.synthetic import make_responses
+    n, m = 1024, 256
+    y, _ = make_responses(n, m, seed=20241, snap_theta=False)
+    rs = RStream(1234)
+    res = gpirtMCMC(y, 1, 0, vote_codes=dict(yea=[1], nay=[-1], missing=[None]), rng="reference", rstream=rs)
+    r = oracle.RStream(1234)
+    ref = oracle.gpirt_mcmc(r, y, r.rnorm(n), 1, 0)
+    _check(res, ref)
+    mt, mti = rs.state()
+    mt_ref, mti_ref = r.mt_state()
+    assert mti == mti_ref and np.array_equal(mt, mt_ref)
