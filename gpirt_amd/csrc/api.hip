@@ -115,6 +115,7 @@ int gpirt_destroy(gpirt_handle_t h)
     if (h->d_info) hipFree(h->d_info);
     if (h->h_info) hipHostFree(h->h_info);
     if (h->d_work) hipFree(h->d_work);
+    if (h->d_prog) hipFree(h->d_prog);
     for (auto& pp : h->prof.pending) { hipEventDestroy(pp.e0); hipEventDestroy(pp.e1); }
     for (auto& pp : h->prof.free_pairs) { hipEventDestroy(pp.e0); hipEventDestroy(pp.e1); }
     if (h->side) hipStreamDestroy(h->side);
@@ -180,9 +181,14 @@ int gpirt_calibrate_mfma_f64(gpirt_handle_t h, double* tflops)
 
 static int finish_info(gpirt_handle_t h)
 {
-    GP_HIP(hipMemcpyAsync(h->h_info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    GP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     GP_HIP(hipStreamSynchronize(h->stream));
     const int info = *h->h_info;
+    if (h->h_info[1] != 0) {
+        hipMemsetAsync(h->d_info + 1, 0, sizeof(int), h->stream);
+        set_error("potrf panel kernel: a progress-counter wait expired (device hang guard)");
+        return GPIRT_E_HIP;
+    }
     if (info > 0) set_error("chol(): decomposition failed (leading minor of order %d is not positive definite)", info);
     return info;
 }

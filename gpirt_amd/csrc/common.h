@@ -67,6 +67,11 @@ struct gpirt_handle_s {
     // look-ahead Cholesky: high-priority side stream for the panel chain + fork/join events
     hipStream_t  side = nullptr;
     hipEvent_t   ev_fork = nullptr, ev_join = nullptr;
+    // persistent panel kernel (panel.hip): one progress counter per 64-row block, epoch-tagged
+    unsigned long long* d_prog = nullptr;
+    size_t       prog_cap = 0;
+    unsigned long long prog_seq = 0;
+    long long*   panel_trace = nullptr;   // debug stamps (micro-benchmarks only)
 };
 
 namespace gpirt {

@@ -26,6 +26,9 @@ int launch_se_kernel_lower(hipStream_t stream, const double* x, int64_t n, doubl
 int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda,
                        bool zero_upper, bool reset_info = true);
 
+// panel.hip: columns [K0, c1) of the Cholesky factor, all rows below, one persistent kernel
+int launch_panel_ll(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t K0, int64_t c1);
+
 // trsm.hip
 int launch_trsm_lower(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t n, int64_t ldl,
                       double* B, int64_t nrhs, int64_t ldb, bool trans);

@@ -1,0 +1,374 @@
+// panel.hip -- one outer panel of the blocked Cholesky (arma::chol(S,"lower"), src/gpirtMCMC.cpp:17,78,97)
+// factored by ONE persistent kernel instead of a chain of ~3 launches per 64 columns.
+//
+// The panel is columns [K0, c1) (<= 1024 of them) and every row from K0 down.  It is cut into 64-row
+// blocks; work-group w owns row block w (w + G, w + 2G, ... when there are more blocks than resident
+// work-groups) and sweeps it LEFT-LOOKING over the panel's 64-column blocks j = 0, 1, ...:
+//
+//     T      = A[R, j] - sum_{k<j} X[R, k] X[j, k]^T        (fp64 MFMA, accumulators in registers)
+//     X[R,j] = T L_jj^{-T}                                   (substitution in the MFMA layout, solve64.h)
+//
+// and the owner of the diagonal row block j finishes with  D = A[j,j] - sum_k X[j,k] X[j,k]^T (kept in
+// registers, updated as each X[j,k] appears) and the 64 x 64 Cholesky L_jj = chol(D) (potf2.h).
+// Row block R only ever needs finished pieces of the diagonal owners j < R: X[j, k] and L_jj.  Those are
+// handed over through memory with one progress counter per row block (release / acquire at agent scope;
+// measured hand-off ~1 us across XCDs): no grid-wide barrier, no launch on the critical path.  The
+// pivot chain  L_jj -> X[j+1,j] -> D_{j+1} -> L_{j+1,j+1}  therefore runs inside two work-groups while
+// every other work-group streams its GEMMs behind it.
+//
+// Deadlock freedom: dependencies point to strictly smaller row-block indices, the diagonal owners are the
+// first <= 16 work-groups of the grid (dispatched first), and the grid never exceeds the number of CUs.
+// Every spin is bounded (GPIRT_SPIN_LIMIT polls): on expiry the work-group raises info[1] and leaves, so
+// the grid always drains; the host turns info[1] into an error.  A non-positive pivot is recorded in
+// info[0] like before and NaNs propagate -- the counters are still published, nobody waits forever.
+#include "common.h"
+#include "kernels.h"
+#include "solve64.h"
+#include "potf2.h"
+
+namespace gpirt {
+
+namespace {
+
+constexpr int PB = 64;                     // block size
+constexpr int SPIN_LIMIT = 1 << 22;        // polls (each with an s_sleep) before giving up: ~ seconds
+
+struct PanelArgs {
+    double* A; int64_t lda; int64_t n;
+    int64_t K0, c1;                        // panel columns [K0, c1)
+    unsigned long long* prog;              // one counter per absolute 64-row block
+    unsigned long long base;               // epoch of this launch: counters below base are stale
+    int* info;
+    int nrb;                               // row blocks of this panel (rows K0 .. n-1)
+    int ncb;                               // column blocks of this panel
+    long long* trace;                      // optional (tools/micro/panel_bench.hip): [row block][step][8] 100 MHz stamps
+};
+
+#define PANEL_STAMP(slot)                                                                         \
+    do {                                                                                          \
+        if (p.trace && threadIdx.x == 0) p.trace[((int64_t)Rr * 40 + (tstep)) * 8 + (slot)] = wall_clock64(); \
+    } while (0)
+
+__device__ __forceinline__ unsigned long long ld_prog(const unsigned long long* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// All 256 threads call it.  Returns false when the wait expired (uniform across the work-group).
+// `have` caches the last value seen for this counter so later waits on smaller values cost nothing.
+// `urgent` (uniform): the waiter is the next diagonal owner -- it polls back to back; everybody else naps
+// between polls, which also keeps them from crowding the memory channel that holds the fresh block.
+__device__ __forceinline__ bool wait_prog(const unsigned long long* p, unsigned long long need,
+                                          unsigned long long& have, unsigned long long* s_seen, int* info,
+                                          bool urgent = false)
+{
+    if (have >= need) return true;
+    if (threadIdx.x == 0) {
+        unsigned long long v = ld_prog(p);
+        int spins = 0;
+        while (v < need && ++spins < SPIN_LIMIT) {
+            if (urgent) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(24);
+            v = ld_prog(p);
+        }
+        if (v < need) { atomicExch(info + 1, 1); v = 0; }
+        *s_seen = v;
+    }
+    __syncthreads();
+    const unsigned long long v = *s_seen;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop stale L1/L2 lines before reading the data
+    __syncthreads();                                  // s_seen may be rewritten by the next wait
+    if (v < need) return false;
+    have = v;
+    return true;
+}
+
+// make this work-group's global stores visible, then raise the row block's counter
+__device__ __forceinline__ void publish(unsigned long long* p, unsigned long long value)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(p, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Global accesses are written as (wave-uniform base) + (32-bit per-lane byte offset): the column part of
+// every address is scalar arithmetic, the lane offset is computed once, and out-of-range rows are clamped
+// to the last row and zeroed after the load -- no predicated loads, so a block's 16 loads fly together.
+__device__ __forceinline__ double ldg_off(const double* sbase, uint32_t voff)
+{
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(sbase) + voff);
+}
+// Results other work-groups will read are stored write-through at agent scope (sc1): nothing of ours stays
+// dirty in the XCD's L2, so the release fence before a counter update has (almost) nothing to write back.
+__device__ __forceinline__ void stg_off(double* sbase, uint32_t voff, double x)
+{
+    __hip_atomic_store(reinterpret_cast<double*>(reinterpret_cast<char*>(sbase) + voff), x, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// 64 x 64 block of A at (row0, col0), all 64 columns valid -> 16 doubles per thread, ready for store_block_lds
+__device__ __forceinline__ void load_block_regs(double (&v)[16], const double* A, int64_t lda,
+                                                int64_t n, int64_t row0, int64_t col0)
+{
+    const int t = threadIdx.x;
+    const int r = t & 63;
+    const int last = (int)(n - 1 - row0);
+    const bool live = r <= last;
+    const uint32_t voff = (uint32_t)(((live ? r : last) + (int64_t)(t >> 6) * lda) * 8);
+    if (row0 + PB <= n) {        // full block (uniform): plain loads, nothing between them and their first use
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = ldg_off(A + row0 + (col0 + 4 * q) * lda, voff);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const double x = ldg_off(A + row0 + (col0 + 4 * q) * lda, voff);
+            v[q] = live ? x : 0.0;
+        }
+    }
+}
+__device__ __forceinline__ void store_block_lds(const double (&v)[16], double* __restrict__ sT)
+{
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int idx = t + 256 * q;
+        sT[(idx >> 6) * S64_LS + (idx & 63)] = v[q];
+    }
+}
+
+// the wave's 16-row strip of a 64-column block, in the accumulator layout of solve64.h:
+// lane (i, g) gets columns 16J + 4g + r of row  row0 + 16 wave + i.  ncols < 64 only for the matrix's
+// last, ragged block (then the column index is clamped per lane).
+__device__ __forceinline__ void load_strip(d4 (&X)[4], const double* A, int64_t lda, int64_t n,
+                                           int64_t row0, int64_t col0, int ncols)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int rr = 16 * wave + i;
+    const int last = (int)(n - 1 - row0);
+    const bool live = rr <= last;
+    const int rc = live ? rr : last;
+    if (ncols == PB && row0 + PB <= n) {
+        const uint32_t voff = (uint32_t)((rr + (int64_t)(4 * g) * lda) * 8);
+#pragma unroll
+        for (int J = 0; J < 4; ++J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) X[J][r] = ldg_off(A + row0 + (col0 + 16 * J + r) * lda, voff);
+    } else if (ncols == PB) {
+        const uint32_t voff = (uint32_t)((rc + (int64_t)(4 * g) * lda) * 8);
+#pragma unroll
+        for (int J = 0; J < 4; ++J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double x = ldg_off(A + row0 + (col0 + 16 * J + r) * lda, voff);
+                X[J][r] = live ? x : 0.0;
+            }
+    } else {
+#pragma unroll
+        for (int J = 0; J < 4; ++J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * J + 4 * g + r;
+                const bool ok = live && c < ncols;
+                const double x = A[row0 + rc + (col0 + (c < ncols ? c : 0)) * lda];
+                X[J][r] = ok ? x : 0.0;
+            }
+    }
+}
+__device__ __forceinline__ void store_strip(const d4 (&X)[4], double* A, int64_t lda, int64_t n,
+                                            int64_t row0, int64_t col0, int ncols, bool lower_only)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int rr = 16 * wave + i;
+    if (row0 + rr >= n) return;
+    const uint32_t voff = (uint32_t)((rr + (int64_t)(4 * g) * lda) * 8);
+#pragma unroll
+    for (int J = 0; J < 4; ++J)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * J + 4 * g + r;
+            if (c < ncols && (!lower_only || rr >= c)) stg_off(A + row0 + (col0 + 16 * J + r) * lda, voff, X[J][r]);
+        }
+}
+
+__global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* sT0 = smem;                               // two staging buffers for the "other" 64 x 64 operand
+    double* sT1 = smem + PB * S64_LS;
+    double* sM = smem + 2 * PB * S64_LS;              // L_jj for the solve; X for the diagonal update; D for potf2
+    __shared__ unsigned long long s_seen;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    double* A = p.A;      // read and written by many work-groups: no restrict anywhere in this file
+    const int64_t lda = p.lda, n = p.n;
+    const int cb0 = (int)(p.K0 / PB);                 // absolute index of the panel's first block
+
+    for (int Rr = blockIdx.x; Rr < p.nrb; Rr += gridDim.x) {
+        const int64_t row0 = p.K0 + (int64_t)Rr * PB;
+        const bool is_diag = Rr < p.ncb;
+        const int jend = is_diag ? Rr : p.ncb;        // off-diagonal column blocks of this row block
+        unsigned long long* my_prog = p.prog + cb0 + Rr;
+        d4 D[4];
+        int dcols = 0;
+        if (is_diag) {
+            const int64_t left = p.c1 - row0;
+            dcols = (int)(left < PB ? left : PB);
+            load_strip(D, A, lda, n, row0, row0, dcols);
+        }
+        for (int j = 0; j < jend; ++j) {
+            const int64_t col0 = p.K0 + (int64_t)j * PB;
+            const int64_t orow0 = col0;               // the diagonal owner of column block j sits at rows col0..
+            const unsigned long long* o_prog = p.prog + cb0 + j;
+            unsigned long long have = 0;
+            const int tstep = j;
+            PANEL_STAMP(0);
+            const int jcols = (int)((p.c1 - col0) < PB ? (p.c1 - col0) : PB);   // < 64 only in the matrix's last block
+            d4 T[4];
+            load_strip(T, A, lda, n, row0, col0, jcols);
+            // ---- T -= sum_k X[R,k] X[j,k]^T, chunks of 64, the other operand double-buffered through LDS
+            if (j > 0) {
+                double breg[16];
+                d4 XI[4];
+                if (!wait_prog(o_prog, p.base + 1, have, &s_seen, p.info)) return;
+                load_block_regs(breg, A, lda, n, orow0, p.K0);
+                load_strip(XI, A, lda, n, row0, p.K0, PB);
+                for (int k = 0; k < j; ++k) {
+                    double* sT = (k & 1) ? sT1 : sT0;
+                    store_block_lds(breg, sT);
+                    __syncthreads();
+                    d4 XC[4];
+#pragma unroll
+                    for (int J = 0; J < 4; ++J) XC[J] = XI[J];
+                    if (k + 1 < j) {
+                        if (!wait_prog(o_prog, p.base + (unsigned long long)(k + 2), have, &s_seen, p.info)) return;
+                        const int64_t kc = p.K0 + (int64_t)(k + 1) * PB;
+                        load_block_regs(breg, A, lda, n, orow0, kc);
+                        load_strip(XI, A, lda, n, row0, kc, PB);
+                    }
+                    strip64_update(T, XC, sT);
+                }
+            }
+            // ---- X = T L_jj^{-T}
+            PANEL_STAMP(1);
+            if (!wait_prog(o_prog, p.base + (unsigned long long)(j + 1), have, &s_seen, p.info, Rr == j + 1)) return;
+            PANEL_STAMP(2);
+            {
+                double v[16];
+                const int r = t & 63, cq = t >> 6;
+                const int last = (int)(n - 1 - orow0);
+                const uint32_t voff = (uint32_t)(((r <= last ? r : last) + (int64_t)cq * lda) * 8);
+                if (jcols == PB) {                    // 16 plain loads in flight, masks applied afterwards
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) v[q] = ldg_off(A + orow0 + (col0 + 4 * q) * lda, voff);
+                } else {                              // ragged last block of the matrix
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int c = cq + 4 * q;
+                        v[q] = A[orow0 + (r <= last ? r : last) + (col0 + (c < jcols ? c : 0)) * lda];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int c = cq + 4 * q;
+                    const bool ok = r >= c && r <= last && c < jcols;
+                    v[q] = ok ? v[q] : ((r == c) ? 1.0 : 0.0);
+                }
+                __syncthreads();                      // every wave is done with sM (previous diagonal update)
+                store_block_lds(v, sM);
+            }
+            __syncthreads();
+            PANEL_STAMP(4);
+            solve64_lower(T, sM);
+            PANEL_STAMP(5);
+            store_strip(T, A, lda, n, row0, col0, jcols, false);
+            if (is_diag) {
+                // D -= X X^T with X straight from the registers: the four strips meet in LDS
+                __syncthreads();                      // all waves finished reading L_jj from sM
+#pragma unroll
+                for (int J = 0; J < 4; ++J)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sM[(16 * J + 4 * g + r) * S64_LS + 16 * wave + i] = T[J][r];
+                __syncthreads();
+                PANEL_STAMP(6);
+                strip64_update(D, T, sM);
+                // X[R,j] is published only now: its global stores drained behind the MFMAs, so the release
+                // fence is cheap, and the barrier inside publish() also frees sM for its next use
+                publish(my_prog, p.base + (unsigned long long)(j + 1));
+            }
+            PANEL_STAMP(3);
+        }
+        if (is_diag) {
+            // ---- L_RR = chol(D): the accumulators go to LDS (identity-padded past a ragged end) and
+            // potf2_64_lds factors them there, storing L to global on the way
+            const int tstep = 39;
+            PANEL_STAMP(0);
+            if (Rr == 0) __syncthreads();             // (otherwise the last publish() already fenced sM)
+#pragma unroll
+            for (int J = 0; J < 4; ++J)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 16 * J + 4 * g + r, rr = 16 * wave + i;
+                    double v = D[J][r];
+                    if (rr >= dcols || c >= dcols) v = (rr == c) ? 1.0 : 0.0;
+                    sM[c * S64_LS + rr] = v;
+                }
+            __syncthreads();
+            PANEL_STAMP(2);
+            potf2_64_lds<S64_LS>(sM, A + row0 + row0 * lda, lda, dcols, (int)row0, p.info);
+            PANEL_STAMP(3);
+            publish(my_prog, p.base + (unsigned long long)(Rr + 1));
+            PANEL_STAMP(1);
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+size_t panel_ll_smem_bytes() { return (size_t)(3 * PB * S64_LS) * sizeof(double); }
+
+// factor panel columns [K0, c1) (all rows below) with the persistent kernel
+int launch_panel_ll(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t K0, int64_t c1)
+{
+    if (K0 >= c1) return 0;
+    const int64_t need = (n + PB - 1) / PB + 1;
+    if ((int64_t)h->prog_cap < need) {
+        // counters only ever grow (epochs), so a fresh zeroed array is always consistent
+        GP_HIP(hipStreamSynchronize(stream));
+        if (h->side) GP_HIP(hipStreamSynchronize(h->side));
+        if (h->d_prog) GP_HIP(hipFree(h->d_prog));
+        h->d_prog = nullptr;
+        GP_HIP(hipMalloc(&h->d_prog, (size_t)need * sizeof(unsigned long long)));
+        GP_HIP(hipMemset(h->d_prog, 0, (size_t)need * sizeof(unsigned long long)));
+        h->prog_cap = (size_t)need;
+    }
+    static int n_cu = 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipDeviceProp_t prop;
+        GP_HIP(hipGetDeviceProperties(&prop, h->device));
+        n_cu = prop.multiProcessorCount;
+        GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_ll_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel_ll_smem_bytes()));
+        attr_set = true;
+    }
+    PanelArgs p;
+    p.A = A; p.lda = lda; p.n = n; p.K0 = K0; p.c1 = c1;
+    p.prog = h->d_prog;
+    h->prog_seq += 1;
+    p.base = h->prog_seq * 64ull;                    // a panel publishes at most ncb + 1 <= 17 steps
+    p.info = h->d_info;
+    p.trace = h->panel_trace;
+    p.nrb = (int)((n - K0 + PB - 1) / PB);
+    p.ncb = (int)((c1 - K0 + PB - 1) / PB);
+    if (p.ncb > 32) { set_error("panel wider than 2048 columns"); return GPIRT_E_ARG; }
+    const int grid = p.nrb < n_cu ? p.nrb : n_cu;
+    hipLaunchKernelGGL(panel_ll_kernel, dim3((unsigned)grid), dim3(256), panel_ll_smem_bytes(), stream, p);
+    GP_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace gpirt

@@ -126,3 +126,98 @@ __device__ __forceinline__ void potf2_64_body(double* __restrict__ A, int64_t ld
 
 
 }  // namespace gpirt
+
+namespace gpirt {
+
+// ------------------------------------------------------------------ diagonal block, LDS resident ----
+// potf2_64_lds: the same 64 x 64 Cholesky, for a block that already sits in LDS (column-major, stride LS,
+// identity-padded beyond nb) -- the persistent panel kernel (panel.hip) hands its register accumulators
+// over this way instead of through global memory.  Organised for latency, 16 columns at a time:
+//   * wave 0 holds block column b with ONE ROW PER LANE (16 registers) and runs the 16 pivot steps with
+//     v_readlane broadcasts: no barrier and no LDS access inside the 16 steps;
+//   * the rank-16 update of the remaining 16 x 16 blocks is fp64 MFMA (one block = 4 instructions):
+//     first the blocks of column b + 1 (the only ones the next pivot steps need), then -- while wave 0
+//     already factors column b + 1 -- the rest, on waves 1..3.
+// 8 barriers in total.  L's lower triangle is stored to Aout (global) straight from wave 0's registers and
+// left in sD.  A non-positive pivot records k0 + (1-based column) in *info (first failure wins) and NaNs
+// propagate, like LAPACK dpotf2 + the old kernel.  All 256 threads must call it.
+template <int LS>
+__device__ __forceinline__ void potf2_lds_update_block(double* __restrict__ sD, int b, int R, int C)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, g = lane >> 4;
+    const int pi = 4 * (i & 3) + (i >> 2);
+    d4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = sD[(16 * C + 4 * g + r) * LS + 16 * R + i];
+    double a[4], bv[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        a[s] = -sD[(16 * b + 4 * g + s) * LS + 16 * C + pi];
+        bv[s] = sD[(16 * b + 4 * g + s) * LS + 16 * R + i];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], bv[s], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sD[(16 * C + 4 * g + r) * LS + 16 * R + i] = acc[r];
+}
+
+template <int LS>
+__device__ __forceinline__ void potf2_64_lds(double* __restrict__ sD, double* Aout, int64_t lda, int nb, int k0,
+                                             int* __restrict__ info)
+{
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    int fail = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        if (wave == 0) {
+            __builtin_amdgcn_s_setprio(3);
+            double x[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) x[c] = sD[(16 * b + c) * LS + lane];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const int p = 16 * b + c;
+                const double d = readlane_f64(x[c], p);
+                if (!(d > 0.0) && p < nb && fail == 0) fail = p + 1;
+                double rinv = rsqrt(d);
+                rinv = (d > 0.0) ? rinv : __builtin_nan("");
+                x[c] *= rinv;
+                // the next pivot's column first, so its readlane is not queued behind the others
+#pragma unroll
+                for (int c2 = c + 1; c2 < 16; ++c2) {
+                    const double l = readlane_f64(x[c], 16 * b + c2);
+                    x[c2] = fma(-x[c], l, x[c2]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const int p = 16 * b + c;
+                sD[p * LS + lane] = x[c];
+                if (lane >= p && lane < nb && p < nb)         // write-through: other work-groups read it next
+                    __hip_atomic_store(&Aout[lane + (int64_t)p * lda], x[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        } else if (b > 0) {
+            // rest of the previous block column's update (columns b + 1 ..), hidden behind wave 0's pivots
+            if (b == 1) {
+                if (wave == 1) potf2_lds_update_block<LS>(sD, 0, 2, 2);
+                if (wave == 2) potf2_lds_update_block<LS>(sD, 0, 3, 2);
+                if (wave == 3) potf2_lds_update_block<LS>(sD, 0, 3, 3);
+            } else if (b == 2) {
+                if (wave == 1) potf2_lds_update_block<LS>(sD, 1, 3, 3);
+            }
+        }
+        __syncthreads();
+        if (b < 3) {
+            // blocks (R, b + 1), R = b + 1 .. 3: one per wave, waves 1..3
+            const int R = b + wave;
+            if (wave >= 1 && R <= 3) potf2_lds_update_block<LS>(sD, b, R, b + 1);
+            __syncthreads();
+        }
+    }
+    if (wave == 0 && lane == 0 && fail != 0) atomicCAS(info, 0, k0 + fail);
+}
+
+}  // namespace gpirt

@@ -1,8 +1,9 @@
 // potrf.hip -- lower Cholesky of S = K + jitter*I : arma::chol(S,"lower") -> LAPACK dpotrf('L')
 // (src/gpirtMCMC.cpp:17,78,97), as a two-level blocked right-looking factorisation:
 //
-//   outer panels of NBO = 512 columns: trailing update  A22 -= P P^T  (lower blocks only) is an
-//       fp64-MFMA syrk with K = 512  (gemm_f64.hip, 128 x 128 tiles) -- n^3/3 of the flops;
+//   outer panels of NBO = 1024 columns: trailing update  A22 -= P P^T  (lower blocks only) is an
+//       fp64-MFMA syrk with K = 1024 (gemm_f64.hip, 128 x 128 tiles) -- the bulk of the n^3/3 flops
+//       (NBO 256..2048 were swept: total time is flat within 4 %, 1024 is best at n = 4096 and 8192);
 //   inside a panel, steps of NBI = 64 columns:
 //       potf2_64      one work-group factors the 64 x 64 diagonal block, register tiled;
 //       panel_trsm_64 X L_kk^T = A_panel by substitution, 16 rows per wavefront in the MFMA
@@ -26,7 +27,7 @@ namespace gpirt {
 namespace {
 
 constexpr int NBI = 64;
-constexpr int NBO = 512;
+constexpr int NBO = 768;
 
 // ------------------------------------------------------------------ diagonal block ---------
 __global__ __launch_bounds__(256) void potf2_64_kernel(double* __restrict__ A, int64_t lda, int nb,
@@ -101,11 +102,20 @@ __global__ void zero_upper_kernel(double* __restrict__ A, int64_t n, int64_t lda
 
 namespace {
 
+// GPIRT_PANEL=2 selects the launch-per-step panel (potf2 / panel_trsm / update gemm) instead of the
+// persistent left-looking kernel of panel.hip
+bool panel_persistent()
+{
+    static const bool on = !(getenv("GPIRT_PANEL") && atoi(getenv("GPIRT_PANEL")) == 2);
+    return on;
+}
+
 // inner loop of one outer panel: columns [K0, c1), every row below; 64-column steps
 int factor_panel(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t K0, int64_t c1,
                  bool first_diag_done = false)
 {
     static const bool fuse = !(getenv("GPIRT_FUSE_POTF2") && atoi(getenv("GPIRT_FUSE_POTF2")) == 2);
+    if (panel_persistent()) return launch_panel_ll(h, stream, A, n, lda, K0, c1);
     for (int64_t k0 = K0; k0 < c1; k0 += NBI) {
         const int nb = (int)((c1 - k0) < NBI ? (c1 - k0) : NBI);
         // only the first diagonal block of an outer panel needs its own potf2 launch: every later one is
@@ -149,7 +159,7 @@ int trailing(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t
     }
     static const bool fuse = !(getenv("GPIRT_FUSE_POTF2") && atoi(getenv("GPIRT_FUSE_POTF2")) == 2);
     if (fused_potf2) *fused_potf2 = false;
-    if (fused_potf2 && fuse && !gemm_trailing_uses_128(M, N)) {
+    if (fused_potf2 && fuse && !panel_persistent() && !gemm_trailing_uses_128(M, N)) {
         // 64-tile launch: work-group 0 also factors the first diagonal block of the next panel
         const int nb_next = (int)(N < NBI ? N : NBI);
         GP_TRY(launch_gemm_update_potf2(stream, M, N, K, A + lo + K0 * lda, lda, A + lo + lo * lda, lda, nb_next,

@@ -485,9 +485,14 @@ int gpirt_sampler_check(gpirt_sampler_t s)
     GP_ARG(s != nullptr);
     gpirt_handle_t h = s->h;
     hipStream_t st = h->stream;
-    GP_HIP(hipMemcpyAsync(h->h_info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, st));
+    GP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     GP_HIP(hipMemcpyAsync(s->h_flags, s->flags, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     GP_HIP(hipStreamSynchronize(st));
+    if (h->h_info[1] != 0) {
+        hipMemsetAsync(h->d_info + 1, 0, sizeof(int), st);
+        set_error("potrf panel kernel: a progress-counter wait expired (device hang guard)");
+        return GPIRT_E_HIP;
+    }
     if (*h->h_info > 0) {
         set_error("chol(): decomposition failed (leading minor of order %d is not positive definite)", *h->h_info);
         return *h->h_info;
@@ -601,7 +606,7 @@ int gpirt_mcmc(const double* h_y, int64_t n, int64_t m, const double* h_theta0, 
     double *snap_f = nullptr, *snap_small = nullptr;       // snap_small: [theta (n) | beta (2m)]
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_snap = nullptr, ev_flags = nullptr;
-    int* h_poll = nullptr;                                 // pinned: [potrf info, flag0, flag1]
+    int* h_poll = nullptr;                                 // pinned: [potrf info, flag0, flag1, panel guard]
     auto cleanup = [&]() {
         if (snap_f) hipFree(snap_f);
         if (snap_small) hipFree(snap_small);
@@ -643,12 +648,17 @@ int gpirt_mcmc(const double* h_y, int64_t n, int64_t m, const double* h_theta0, 
     auto post_flags = [&]() -> int {                        // async read-back of the sticky error words
         hipStream_t st = h->stream;
         if (hipMemcpyAsync(h_poll, h->d_info, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(h_poll + 3, h->d_info + 1, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipMemcpyAsync(h_poll + 1, s->flags, 2 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipEventRecord(ev_flags, st) != hipSuccess)
             return fail_hip("flag read-back");
         return 0;
     };
     auto inspect_flags = [&]() -> int {
+        if (h_poll[3] != 0) {
+            set_error("potrf panel kernel: a progress-counter wait expired (device hang guard)");
+            return GPIRT_E_HIP;
+        }
         if (h_poll[0] > 0) {
             set_error("chol(): decomposition failed (leading minor of order %d is not positive definite)", h_poll[0]);
             return h_poll[0];

@@ -3,13 +3,13 @@ import collections, csv, glob, json, os, shutil, sys
 raw = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/profiles_raw"
 tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
 KERNEL = "gemm_f64_kernel<false, true, 128, 8"
-stats = sorted(glob.glob(raw + "/stats/runc/*kernel_stats.csv"))[-1]
+stats = max(glob.glob(raw + "/stats/runc/*kernel_stats.csv"), key=os.path.getmtime)   # gpurun merges old calls' pid-named files too
 shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
 rows = list(csv.DictReader(open(stats)))
 bench = json.loads([l for l in open(raw + "/stats.log") if l.startswith("{")][-1])
 
 def pmc(name):
-    f = sorted(glob.glob(f"{raw}/{name}/runc/*counter_collection.csv"))[-1]
+    f = max(glob.glob(f"{raw}/{name}/runc/*counter_collection.csv"), key=os.path.getmtime)
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if KERNEL in r["Kernel_Name"]:
