@@ -194,9 +194,12 @@ __device__ __forceinline__ void store_strip(const d4 (&X)[4], double* A, int64_t
 __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* sT0 = smem;                               // two staging buffers for the "other" 64 x 64 operand
+    // Two 64 x 64 buffers (34 KB each): the "other" GEMM operand alternates between them, and whichever
+    // one the last chunk did not use then takes L_jj for the solve, X for the diagonal update and D for potf2.
+    // ~79 KB in all, so a 128-tile GEMM work-group of a concurrent trailing update still fits on the CU.
+    double* sT0 = smem;
     double* sT1 = smem + PB * S64_LS;
-    double* sM = smem + 2 * PB * S64_LS;              // L_jj for the solve; X for the diagonal update; D for potf2
+    double* sXT = smem + 2 * PB * S64_LS;             // potf2's multiplier copy
     __shared__ unsigned long long s_seen;
 
     const int t = threadIdx.x;
@@ -223,6 +226,7 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
             const int64_t orow0 = col0;               // the diagonal owner of column block j sits at rows col0..
             const unsigned long long* o_prog = p.prog + cb0 + j;
             unsigned long long have = 0;
+            double* sM = (j & 1) ? sT1 : sT0;         // free: the last chunk (k = j - 1) reads the other buffer
             const int tstep = j;
             PANEL_STAMP(0);
             const int jcols = (int)((p.c1 - col0) < PB ? (p.c1 - col0) : PB);   // < 64 only in the matrix's last block
@@ -295,8 +299,12 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
                 PANEL_STAMP(6);
                 strip64_update(D, T, sM);
                 // X[R,j] is published only now: its global stores drained behind the MFMAs, so the release
-                // fence is cheap, and the barrier inside publish() also frees sM for its next use
-                publish(my_prog, p.base + (unsigned long long)(j + 1));
+                // fence is cheaper, and the barrier inside publish() also frees sM for its next use.  The
+                // last one (j == Rr - 1) sits on the pivot chain: potf2_64_lds publishes it one barrier in.
+                if (j + 1 < Rr) publish(my_prog, p.base + (unsigned long long)(j + 1));
+                else __syncthreads();
+            } else {
+                __syncthreads();                      // the next step's first chunk may land in this buffer
             }
             PANEL_STAMP(3);
         }
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
             // potf2_64_lds factors them there, storing L to global on the way
             const int tstep = 39;
             PANEL_STAMP(0);
-            if (Rr == 0) __syncthreads();             // (otherwise the last publish() already fenced sM)
+            double* sM = sT0;                         // both buffers are free (barrier at the end of the last step)
 #pragma unroll
             for (int J = 0; J < 4; ++J)
 #pragma unroll
@@ -317,7 +325,8 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
                 }
             __syncthreads();
             PANEL_STAMP(2);
-            potf2_64_lds<S64_LS>(sM, A + row0 + row0 * lda, lda, dcols, (int)row0, p.info);
+            potf2_64_lds<S64_LS>(sM, sXT, A + row0 + row0 * lda, lda, dcols, (int)row0, p.info,
+                                 Rr > 0 ? my_prog : nullptr, p.base + (unsigned long long)Rr);
             PANEL_STAMP(3);
             publish(my_prog, p.base + (unsigned long long)(Rr + 1));
             PANEL_STAMP(1);
@@ -328,7 +337,7 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
 
 }  // namespace
 
-size_t panel_ll_smem_bytes() { return (size_t)(3 * PB * S64_LS) * sizeof(double); }
+size_t panel_ll_smem_bytes() { return (size_t)(2 * PB * S64_LS + PB * POTF2_XS) * sizeof(double); }
 
 // factor panel columns [K0, c1) (all rows below) with the persistent kernel
 int launch_panel_ll(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t K0, int64_t c1)

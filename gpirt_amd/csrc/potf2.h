@@ -133,14 +133,15 @@ namespace gpirt {
 // potf2_64_lds: the same 64 x 64 Cholesky, for a block that already sits in LDS (column-major, stride LS,
 // identity-padded beyond nb) -- the persistent panel kernel (panel.hip) hands its register accumulators
 // over this way instead of through global memory.  Organised for latency, 16 columns at a time:
-//   * wave 0 holds block column b with ONE ROW PER LANE (16 registers) and runs the 16 pivot steps with
-//     v_readlane broadcasts: no barrier and no LDS access inside the 16 steps;
+//   * wave 0 holds block column b with ONE ROW PER LANE (16 registers) and runs the 16 pivot steps without a
+//     barrier; two v_readlane pairs per column sit on the chain, the other multipliers are LDS broadcasts;
 //   * the rank-16 update of the remaining 16 x 16 blocks is fp64 MFMA (one block = 4 instructions):
 //     first the blocks of column b + 1 (the only ones the next pivot steps need), then -- while wave 0
 //     already factors column b + 1 -- the rest, on waves 1..3.
 // 8 barriers in total.  L's lower triangle is stored to Aout (global) straight from wave 0's registers and
 // left in sD.  A non-positive pivot records k0 + (1-based column) in *info (first failure wins) and NaNs
-// propagate, like LAPACK dpotf2 + the old kernel.  All 256 threads must call it.
+// propagate, like LAPACK dpotf2 + the old kernel.  All 256 threads must call it.  late_flag / late_value:
+// optional progress counter of the caller to raise once every wave's EARLIER global stores are visible.
 template <int LS>
 __device__ __forceinline__ void potf2_lds_update_block(double* __restrict__ sD, int b, int R, int C)
 {
@@ -162,10 +163,24 @@ __device__ __forceinline__ void potf2_lds_update_block(double* __restrict__ sD, 
     for (int r = 0; r < 4; ++r) sD[(16 * C + 4 * g + r) * LS + 16 * R + i] = acc[r];
 }
 
-template <int LS>
-__device__ __forceinline__ void potf2_64_lds(double* __restrict__ sD, double* Aout, int64_t lda, int nb, int k0,
-                                             int* __restrict__ info)
+// 1/sqrt(d) for the pivot chain: hardware estimate + one third-order correction (the same arithmetic as the
+// library rsqrt, minus its special-case select): d <= 0, NaN and Inf all come out as NaN/Inf and propagate.
+__device__ __forceinline__ double rsqrt_chain(double d)
 {
+    const double y0 = __builtin_amdgcn_rsq(d);
+    const double e = fma(-d * y0, y0, 1.0);
+    return fma(y0 * e, fma(e, 0.375, 0.5), y0);
+}
+
+constexpr int POTF2_XS = 18;      // row stride of the multiplier copy sXT (64 x 18 doubles of LDS)
+template <int LS>
+__device__ __forceinline__ void potf2_64_lds(double* __restrict__ sD, double* __restrict__ sXT, double* Aout,
+                                             int64_t lda, int nb, int k0, int* __restrict__ info,
+                                             unsigned long long* late_flag = nullptr, unsigned long long late_value = 0,
+                                             long long* dbg = nullptr)
+{
+    constexpr int XS = POTF2_XS;
+#define POTF2_STAMP(slot) do { if (dbg && threadIdx.x == 0) dbg[4 * b + (slot)] = wall_clock64(); } while (0)
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     int fail = 0;
@@ -173,38 +188,64 @@ __device__ __forceinline__ void potf2_64_lds(double* __restrict__ sD, double* Ao
     for (int b = 0; b < 4; ++b) {
         if (wave == 0) {
             __builtin_amdgcn_s_setprio(3);
+            POTF2_STAMP(0);
             double x[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) x[c] = sD[(16 * b + c) * LS + lane];
+            // Left-looking inside the block column, software-pipelined so that nothing but the pivot itself
+            // (readlane -> fma -> readlane -> rsqrt -> scale) is ever waited for:
+            //   * column c+1 collects the updates of columns 0 .. c-1 while pivot c is in flight; the multipliers
+            //     L[p+1][k] come from sXT (row-major copy of the finished columns; a uniform-address LDS read is
+            //     a broadcast, no SGPR traffic), k <= c-2 fetched a whole column earlier, k = c-1 by v_readlane;
+            //   * the reads for column c+2 are issued now and consumed in the next iteration.
+            double pre = x[0];
+            double mA[16], mB[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
                 const int p = 16 * b + c;
-                const double d = readlane_f64(x[c], p);
-                if (!(d > 0.0) && p < nb && fail == 0) fail = p + 1;
-                double rinv = rsqrt(d);
-                rinv = (d > 0.0) ? rinv : __builtin_nan("");
-                x[c] *= rinv;
-                // the next pivot's column first, so its readlane is not queued behind the others
+                if (c + 2 < 16) {                      // (a) multipliers of column c+2, k = 0 .. c-1
 #pragma unroll
-                for (int c2 = c + 1; c2 < 16; ++c2) {
-                    const double l = readlane_f64(x[c], 16 * b + c2);
-                    x[c2] = fma(-x[c], l, x[c2]);
+                    for (int k = 0; k < c; k += 2) {
+                        const double2 mm = *reinterpret_cast<const double2*>(&sXT[(p + 2) * XS + k]);
+                        mB[k] = mm.x;
+                        mB[k + 1] = mm.y;
+                    }
                 }
-            }
+                double acc = pre;                      // (b) the chain
+                if (c >= 1) acc = fma(-x[c - 1], readlane_f64(x[c - 1], p), acc);
+                const double d = readlane_f64(acc, p);
+                if (!(d > 0.0) && p < nb && fail == 0) fail = p + 1;
+                const double rinv = rsqrt_chain(d);
+                if (c + 1 < 16) {                      // (c) column c+1 minus columns 0 .. c-1
+                    double s0 = x[c + 1], s1 = 0.0;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const int p = 16 * b + c;
-                sD[p * LS + lane] = x[c];
-                if (lane >= p && lane < nb && p < nb)         // write-through: other work-groups read it next
-                    __hip_atomic_store(&Aout[lane + (int64_t)p * lda], x[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int k = 0; k + 1 < c; k += 2) {
+                        s0 = fma(-x[k], mA[k], s0);
+                        if (k + 2 < c) s1 = fma(-x[k + 1], mA[k + 1], s1);
+                    }
+                    if (c >= 1) s1 = fma(-x[c - 1], readlane_f64(x[c - 1], p + 1), s1);
+                    pre = s0 + s1;
+                }
+                x[c] = acc * rinv;                     // (d)
+                sXT[lane * XS + c] = x[c];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) mA[k] = mB[k];
             }
+            POTF2_STAMP(1);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) sD[(16 * b + c) * LS + lane] = x[c];
+            POTF2_STAMP(2);
             __builtin_amdgcn_s_setprio(0);
-        } else if (b > 0) {
+            // deferred publication (see below): every wave makes sure its earlier global stores have been
+            // accepted by the L2 (long done by now) before the first barrier
+            if (b == 0 && late_flag) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (b == 0) {
+            if (late_flag) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
             // rest of the previous block column's update (columns b + 1 ..), hidden behind wave 0's pivots
-            if (b == 1) {
-                if (wave == 1) potf2_lds_update_block<LS>(sD, 0, 2, 2);
+            if (b == 1) {                                  // (wave 3 is busy publishing, see below)
+                if (wave == 1) { potf2_lds_update_block<LS>(sD, 0, 2, 2); potf2_lds_update_block<LS>(sD, 0, 3, 3); }
                 if (wave == 2) potf2_lds_update_block<LS>(sD, 0, 3, 2);
-                if (wave == 3) potf2_lds_update_block<LS>(sD, 0, 3, 3);
             } else if (b == 2) {
                 if (wave == 1) potf2_lds_update_block<LS>(sD, 1, 3, 3);
             }
@@ -216,7 +257,29 @@ __device__ __forceinline__ void potf2_64_lds(double* __restrict__ sD, double* Ao
             if (wave >= 1 && R <= 3) potf2_lds_update_block<LS>(sD, b, R, b + 1);
             __syncthreads();
         }
+        // L's block column b goes out to global memory from LDS on waves 1..3 (write-through: other
+        // work-groups read it next), off wave 0's chain except for the last block column
+        // The caller's last result block (stored to global before the call) is published from here instead of
+        // before the call: all waves' stores are in the L2 (vmcnt(0) before the first barrier), wave 3 -- idle
+        // for the next block column -- writes the L2 back (release fence, ~2.5 us) and raises the counter,
+        // while wave 0 is already deep in the next pivots.
+        if (b == 0 && late_flag && wave == 3) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            if (lane == 0) __hip_atomic_store(late_flag, late_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (wave >= 1) {
+            const int u = (wave - 1) * 64 + lane;          // 0 .. 191
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const int idx = u + 192 * q;               // 16 columns x 64 rows = 1024 elements
+                const int r = idx & 63, c = 16 * b + (idx >> 6);
+                if (idx < 1024 && r >= c && r < nb && c < nb)
+                    __hip_atomic_store(&Aout[r + (int64_t)c * lda], sD[c * LS + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        POTF2_STAMP(3);
     }
+#undef POTF2_STAMP
     if (wave == 0 && lane == 0 && fail != 0) atomicCAS(info, 0, k0 + fail);
 }
 

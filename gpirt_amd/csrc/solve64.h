@@ -19,7 +19,7 @@
 
 namespace gpirt {
 
-constexpr int S64_LS = 84;     // LDS column stride (doubles): 4 columns apart = 16 (mod 32) 8-byte banks
+constexpr int S64_LS = 68;     // LDS column stride (doubles): 4 columns apart = 16 (mod 32) 8-byte banks; 34 KB per block
 
 // sM[c * S64_LS + r] = M[r][c] for r >= c (lower triangle incl. diagonal), zeros above.
 __device__ __forceinline__ void solve64_lower(d4 (&X)[4], const double* __restrict__ sM)
