@@ -118,18 +118,17 @@ __device__ __forceinline__ void store_tile(double* __restrict__ s, const double2
 
 // TA: A is stored K x M (op(A) = A^T)  -> K-contiguous.   !TA: stored M x K -> M-contiguous.
 // TB: B is stored N x K (op(B) = B^T)  -> N-contiguous.   !TB: stored K x N -> K-contiguous.
+// main loop of one block tile over the K range [kbeg, kend): acc += op(A)[tile rows, k] op(B)[k, tile cols]
 template <bool TA, bool TB, int T>
-__device__ __forceinline__ void gemm_tile(const GemmParams& p, const int bi, const int bj, double* smem)
+__device__ __forceinline__ void gemm_mainloop(const GemmParams& p, const int bi, const int bj, double* smem,
+                                              const int kbeg, const int kend,
+                                              d4 (&acc)[Cfg<T>::NT][Cfg<T>::NT])
 {
     constexpr int BM = T, BN = T, LDS_MN = Cfg<T>::LDS_MN, TILE_DOUBLES = Cfg<T>::TILE, NT = Cfg<T>::NT;
     constexpr int WT = T / 2;                // wave tile edge
     double* sA = smem;                       // [2][TILE]
     double* sB = smem + 2 * TILE_DOUBLES;    // [2][TILE]
     const int i0 = bi * BM, j0 = bj * BN;
-
-    int kbeg = 0, kend = p.K;
-    if (p.tri == TRI_A_LOWER) kend = min(p.K, i0 + BM);
-    if (p.tri == TRI_A_UPPER) kbeg = (i0 / BK) * BK;
 
     constexpr bool A_KC = TA, B_KC = !TB;
     const bool fullA = p.fastA && (i0 + BM <= p.M);
@@ -138,12 +137,6 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int bi, con
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const int l15 = lane & 15, l4 = lane >> 4;
-
-    d4 acc[NT][NT];
-#pragma unroll
-    for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int b = 0; b < NT; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
 
     const int nk = (kend - kbeg + BK - 1) / BK;
     double2 ra[Cfg<T>::PASSES], rb[Cfg<T>::PASSES];
@@ -190,7 +183,19 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int bi, con
         }
         __syncthreads();
     }
+}
 
+// C tile <- alpha * acc + beta * C (masked at the matrix edge and, for syrk, above the diagonal)
+template <int T>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const int bi, const int bj,
+                                              const d4 (&acc)[Cfg<T>::NT][Cfg<T>::NT])
+{
+    constexpr int BM = T, BN = T, NT = Cfg<T>::NT;
+    constexpr int WT = T / 2;
+    const int i0 = bi * BM, j0 = bj * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
     // epilogue: acc[tn][tm][r] = C[m = i0+wm*64+tm*16+l15][n = j0+wn*64+tn*16+l4+4r]
     // C is read in batches of 16 independent loads before anything is stored: a store followed by
     // a load of the same array would otherwise serialise 64 L2 round trips per thread.
@@ -226,6 +231,22 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int bi, con
             }
         }
     }
+}
+
+template <bool TA, bool TB, int T>
+__device__ __forceinline__ void gemm_tile(const GemmParams& p, const int bi, const int bj, double* smem)
+{
+    constexpr int NT = Cfg<T>::NT;
+    int kbeg = 0, kend = p.K;
+    if (p.tri == TRI_A_LOWER) kend = min(p.K, bi * T + T);
+    if (p.tri == TRI_A_UPPER) kbeg = ((bi * T) / BK) * BK;
+    d4 acc[NT][NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+    gemm_mainloop<TA, TB, T>(p, bi, bj, smem, kbeg, kend, acc);
+    gemm_epilogue<T>(p, bi, bj, acc);
 }
 
 // PAD only distinguishes instantiations by name (see launch_gemm_trailing); it adds PAD doubles of LDS.

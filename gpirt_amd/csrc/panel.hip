@@ -25,13 +25,13 @@
 #include "kernels.h"
 #include "solve64.h"
 #include "potf2.h"
+#include "flagsync.h"
 
 namespace gpirt {
 
 namespace {
 
 constexpr int PB = 64;                     // block size
-constexpr int SPIN_LIMIT = 1 << 22;        // polls (each with an s_sleep) before giving up: ~ seconds
 
 struct PanelArgs {
     double* A; int64_t lda; int64_t n;
@@ -48,47 +48,6 @@ struct PanelArgs {
     do {                                                                                          \
         if (p.trace && threadIdx.x == 0) p.trace[((int64_t)Rr * 40 + (tstep)) * 8 + (slot)] = wall_clock64(); \
     } while (0)
-
-__device__ __forceinline__ unsigned long long ld_prog(const unsigned long long* p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// All 256 threads call it.  Returns false when the wait expired (uniform across the work-group).
-// `have` caches the last value seen for this counter so later waits on smaller values cost nothing.
-// `urgent` (uniform): the waiter is the next diagonal owner -- it polls back to back; everybody else naps
-// between polls, which also keeps them from crowding the memory channel that holds the fresh block.
-__device__ __forceinline__ bool wait_prog(const unsigned long long* p, unsigned long long need,
-                                          unsigned long long& have, unsigned long long* s_seen, int* info,
-                                          bool urgent = false)
-{
-    if (have >= need) return true;
-    if (threadIdx.x == 0) {
-        unsigned long long v = ld_prog(p);
-        int spins = 0;
-        while (v < need && ++spins < SPIN_LIMIT) {
-            if (urgent) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(24);
-            v = ld_prog(p);
-        }
-        if (v < need) { atomicExch(info + 1, 1); v = 0; }
-        *s_seen = v;
-    }
-    __syncthreads();
-    const unsigned long long v = *s_seen;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop stale L1/L2 lines before reading the data
-    __syncthreads();                                  // s_seen may be rewritten by the next wait
-    if (v < need) return false;
-    have = v;
-    return true;
-}
-
-// make this work-group's global stores visible, then raise the row block's counter
-__device__ __forceinline__ void publish(unsigned long long* p, unsigned long long value)
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(p, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // Global accesses are written as (wave-uniform base) + (32-bit per-lane byte offset): the column part of
 // every address is scalar arithmetic, the lane offset is computed once, and out-of-range rows are clamped

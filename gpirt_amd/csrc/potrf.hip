@@ -1,16 +1,16 @@
 // potrf.hip -- lower Cholesky of S = K + jitter*I : arma::chol(S,"lower") -> LAPACK dpotrf('L')
-// (src/gpirtMCMC.cpp:17,78,97), as a two-level blocked right-looking factorisation:
+// (src/gpirtMCMC.cpp:17,78,97), as a blocked right-looking factorisation:
 //
 //   outer panels of NBO = 1024 columns: trailing update  A22 -= P P^T  (lower blocks only) is an
-//       fp64-MFMA syrk with K = 1024 (gemm_f64.hip, 128 x 128 tiles) -- the bulk of the n^3/3 flops
-//       (NBO 256..2048 were swept: total time is flat within 4 %, 1024 is best at n = 4096 and 8192);
-//   inside a panel, steps of NBI = 64 columns:
-//       potf2_64      one work-group factors the 64 x 64 diagonal block, register tiled;
-//       panel_trsm_64 X L_kk^T = A_panel by substitution, 16 rows per wavefront in the MFMA
-//                     accumulator layout (solve64.h): rows are independent, so this is perfectly
-//                     parallel over the n - k rows below the block;
-//       the panel's remaining columns are updated with a K = 64 MFMA gemm (masked to the lower
-//       triangle).
+//       fp64-MFMA syrk with K = 1024 (gemm_f64.hip, 128 x 128 tiles) -- the bulk of the n^3/3 flops;
+//   an outer panel is factored in sub-panels of NBP = 512 columns, each by ONE persistent kernel
+//       (panel.hip: left-looking per 64-row block, hand-offs through progress counters), with an MFMA
+//       update of the outer panel's remaining columns in between (K = 512).
+//   Measured at n = 8192 (NBO x NBP swept over 256..2048 x 256..512): flat within 3 % around 1024 x 512.
+//
+// The launch-per-step panel this replaced (potf2_64 / panel_trsm_64 / K = 64 update gemm, ~3 launches per
+// 64 columns, 51 us per step against 26 us now) is still here behind GPIRT_PANEL=2, as the reference the
+// persistent kernel is tested against.
 // Nothing above the diagonal is ever written; the strict upper triangle keeps whatever it held
 // (zeros in the sampler's persistent L buffer; the operator entry zero-fills it to honour
 // arma::chol's contract).  A non-positive pivot records LAPACK's info (1-based order of the
@@ -27,7 +27,8 @@ namespace gpirt {
 namespace {
 
 constexpr int NBI = 64;
-constexpr int NBO = 768;
+constexpr int NBO = 1024;
+constexpr int NBP = 512;      // widest panel handed to the persistent kernel in one piece
 
 // ------------------------------------------------------------------ diagonal block ---------
 __global__ __launch_bounds__(256) void potf2_64_kernel(double* __restrict__ A, int64_t lda, int nb,
@@ -102,6 +103,14 @@ __global__ void zero_upper_kernel(double* __restrict__ A, int64_t n, int64_t lda
 
 namespace {
 
+int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    const int x = atoi(v);
+    return x > 0 ? x : dflt;
+}
+
 // GPIRT_PANEL=2 selects the launch-per-step panel (potf2 / panel_trsm / update gemm) instead of the
 // persistent left-looking kernel of panel.hip
 bool panel_persistent()
@@ -115,7 +124,21 @@ int factor_panel(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int
                  bool first_diag_done = false)
 {
     static const bool fuse = !(getenv("GPIRT_FUSE_POTF2") && atoi(getenv("GPIRT_FUSE_POTF2")) == 2);
-    if (panel_persistent()) return launch_panel_ll(h, stream, A, n, lda, K0, c1);
+    if (panel_persistent()) {
+        // the persistent kernel is chain-bound up to ~512 columns and GEMM-bound beyond (one work-group per
+        // row block does all of that block's left-looking products): wider outer panels are cut into
+        // sub-panels of NBP columns with an MFMA update of the remaining columns in between
+        static const int nbp_env = env_int("GPIRT_NBP", NBP);
+        const int64_t nbp = (nbp_env / NBI) * NBI > 0 ? (nbp_env / NBI) * NBI : NBP;
+        for (int64_t k0 = K0; k0 < c1; k0 += nbp) {
+            const int64_t k1 = (k0 + nbp < c1) ? k0 + nbp : c1;
+            GP_TRY(launch_panel_ll(h, stream, A, n, lda, k0, k1));
+            if (k1 < c1)      // A[k1:n, k1:c1] -= A[k1:n, k0:k1] A[k1:c1, k0:k1]^T
+                GP_TRY(launch_gemm(h, stream, false, true, TRI_SYRK_LOWER, n - k1, c1 - k1, k1 - k0, -1.0,
+                                   A + k1 + k0 * lda, lda, A + k1 + k0 * lda, lda, 1.0, A + k1 + k1 * lda, lda));
+        }
+        return 0;
+    }
     for (int64_t k0 = K0; k0 < c1; k0 += NBI) {
         const int nb = (int)((c1 - k0) < NBI ? (c1 - k0) : NBI);
         // only the first diagonal block of an outer panel needs its own potf2 launch: every later one is
@@ -178,22 +201,16 @@ int trailing(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t
     return 0;
 }
 
-int env_int(const char* name, int dflt)
-{
-    const char* v = getenv(name);
-    if (!v || !*v) return dflt;
-    const int x = atoi(v);
-    return x > 0 ? x : dflt;
-}
 
 }  // namespace
 
 // Look-ahead schedule: the trailing update of panel p is split into the columns of panel p+1
 // (done first, on the main stream) and the rest; panel p+1 is then factored on a high-priority
-// side stream WHILE the rest of update p runs on the main stream.  Measured gain is small (~3 %):
-// the panel chain is fp64-VALU latency-bound and the fp64 MFMA shares the same FP64 pipes, so chain
-// kernels run ~6x slower while a trailing update is resident (profiles/r01_summary.md); CU masks
-// (hipExtStreamCreateWithCUMask) and single-occupancy GEMM variants were measured and made it worse.
+// side stream WHILE the rest of update p runs on the main stream.  The persistent panel kernel keeps
+// its LDS under 80 KB so that one 128-tile work-group of the update still fits on each of its CUs.
+// Measured gain ~6 % of the factorisation: the pivot chain is fp64-VALU latency-bound and slows down
+// (clocks, shared FP64 pipes) while the update runs; CU masks (hipExtStreamCreateWithCUMask) and
+// single-occupancy GEMM variants were measured and made it worse.
 int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda,
                        bool zero_upper, bool reset_info)
 {
