@@ -243,8 +243,9 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
                 store_block_lds(v, sM);
             }
             __syncthreads();
+            invert_diag16(sM);
             PANEL_STAMP(4);
-            solve64_lower(T, sM);
+            solve64_lower_inv(T, sM);
             PANEL_STAMP(5);
             store_strip(T, A, lda, n, row0, col0, jcols, false);
             if (is_diag) {

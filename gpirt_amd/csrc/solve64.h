@@ -87,6 +87,94 @@ __device__ __forceinline__ void solve64_lower(d4 (&X)[4], const double* __restri
     }
 }
 
+// ---- the same solve with the 16 x 16 diagonal blocks applied as explicit inverses ----------------------
+// solve64_lower spends ~3/4 of its time in the 16 group steps of the diagonal blocks (in-lane 4 x 4
+// substitution + ds_bpermute, a dependent chain the MFMA pipe only watches).  Inverting the four 16 x 16
+// diagonal blocks once per staged matrix (one wavefront, ~0.6 us) turns them into 4 MFMAs each:
+//     X_J = (T_J - sum_{I<J} X_I M_JI^T) W_J^T,   W_J = M_JJ^{-1}
+// 40 MFMAs per wavefront in all (1.1 us against 4.3 us measured for the substitution).  Only 16 x 16
+// blocks of the Cholesky factor are ever inverted: their condition is bounded by that of L itself
+// (sqrt(cond S) ~ 1e3 here), far below anything fp64 would notice; the off-diagonal coupling stays a true
+// substitution.
+
+// Replace the four diagonal 16 x 16 blocks of the staged lower-triangular matrix by their inverses (zeros
+// above the diagonal).  All 256 threads call it after the barrier that completes the staging; it ends with
+// a barrier.  Wavefront 0 works: lane = 16 * block + column j of W, rows i = 0..15 in sequence.
+__device__ __forceinline__ void invert_diag16(double* __restrict__ sM)
+{
+    const int lane = threadIdx.x & 63;
+    if ((threadIdx.x >> 6) == 0) {
+        const int blk = lane >> 4, j = lane & 15;
+        double* base = sM + (16 * blk) * S64_LS + 16 * blk;     // element (r, c) of the block: base[c * S64_LS + r]
+        // forward substitution on the unit vector e_j, column by column of M (right-looking): the updates
+        // of one step are independent of each other, and column k+1 of M is fetched (16-byte LDS reads,
+        // broadcast within the block's 16 lanes) while step k computes -- no LDS latency on the chain
+        double w[16], r[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const double d = base[i * S64_LS + i];
+            double x = __builtin_amdgcn_rcp(d);                  // 1/d: hardware estimate + two Newton steps
+            x = fma(fma(-d, x, 1.0), x, x);
+            r[i] = fma(fma(-d, x, 1.0), x, x);
+            w[i] = (i == j) ? 1.0 : 0.0;
+        }
+        double mc[16], mn[16];
+#pragma unroll
+        for (int i2 = 0; i2 < 16; i2 += 2) {
+            const double2 v = *reinterpret_cast<const double2*>(&base[0 * S64_LS + i2]);
+            mc[i2] = v.x;
+            mc[i2 + 1] = v.y;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (k + 1 < 16) {
+#pragma unroll
+                for (int i2 = 0; i2 < 16; i2 += 2)
+                    if (i2 + 1 > k + 1) {
+                        const double2 v = *reinterpret_cast<const double2*>(&base[(k + 1) * S64_LS + i2]);
+                        mn[i2] = v.x;
+                        mn[i2 + 1] = v.y;
+                    }
+            }
+            w[k] *= r[k];
+#pragma unroll
+            for (int i = k + 1; i < 16; ++i) w[i] = fma(-mc[i], w[k], w[i]);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mc[i] = mn[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) base[j * S64_LS + i] = w[i];
+    }
+    __syncthreads();
+}
+
+// sM as for solve64_lower, but with the diagonal 16 x 16 blocks already replaced by invert_diag16.
+__device__ __forceinline__ void solve64_lower_inv(d4 (&X)[4], const double* __restrict__ sM)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, g = lane >> 4;
+    const int pi = 4 * (i & 3) + (i >> 2);
+#pragma unroll
+    for (int J = 0; J < 4; ++J) {
+#pragma unroll
+        for (int I = 0; I < J; ++I) {
+            double a[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) a[s] = -sM[(16 * I + 4 * g + s) * S64_LS + 16 * J + pi];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                X[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], X[I][s], X[J], 0, 0, 0);
+        }
+        double a[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a[s] = sM[(16 * J + 4 * g + s) * S64_LS + 16 * J + pi];
+        d4 Y = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+        for (int s = 0; s < 4; ++s) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], X[J][s], Y, 0, 0, 0);
+        X[J] = Y;
+    }
+}
+
 // X_J -= T X_I for one 64 x 64 coefficient block T (sT[c * S64_LS + r] = T[r][c], full block):
 // the off-diagonal step between two 64-row blocks of a taller solve.  64 MFMAs per wavefront.
 __device__ __forceinline__ void strip64_update(d4 (&XJ)[4], const d4 (&XI)[4], const double* __restrict__ sT)

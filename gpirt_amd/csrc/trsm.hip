@@ -4,11 +4,10 @@
 // The reference runs these as LAPACK dtrtrs one vector at a time (2 m solves per iteration, L
 // re-read 2 m times); here all item columns go through one recursive blocked solve:
 //   split the rows in two, solve the first half, fold it into the second half with ONE fp64-MFMA
-//   gemm (K = half the rows, so the deep products carry the flops), recurse.  The 64-row leaves
-//   are true substitutions (no inverted blocks: S has condition ~1e6 by construction):
-//   one lane owns one right-hand-side column, its 64 entries live in registers, the 64 x 64
-//   diagonal block of L is broadcast from LDS, and the tile of B is transposed through LDS so
-//   global traffic stays coalesced.
+//   gemm (K = half the rows, so the deep products carry the flops), recurse.  The leaves run the
+//   MFMA-layout substitution of solve64.h: off-diagonal 16 x 16 coupling by MFMA, the 16 x 16 diagonal
+//   blocks through their inverses (formed on the fly in LDS; nothing larger than 16 x 16 is ever
+//   inverted: S has condition ~1e6 by construction).
 #include "common.h"
 #include "kernels.h"
 #include "solve64.h"
@@ -76,7 +75,8 @@ __global__ __launch_bounds__(256) void trsm_leaf_kernel(const double* __restrict
         }
     stage_block<BACK>(L, ldl, nb, 0, 0, true, sM);
     __syncthreads();
-    solve64_lower(X, sM);
+    invert_diag16(sM);
+    solve64_lower_inv(X, sM);
     if (live) {
 #pragma unroll
         for (int J = 0; J < 4; ++J)
@@ -131,7 +131,8 @@ __global__ __launch_bounds__(256) void trsm_leaf256_kernel(const double* __restr
             }
             stage_block<BACK>(L, ldl, nb, JB, JB, true, sbuf[buf]);
             __syncthreads();
-            solve64_lower(reinterpret_cast<d4(&)[4]>(X[4 * JB]), sbuf[buf]);
+            invert_diag16(sbuf[buf]);
+            solve64_lower_inv(reinterpret_cast<d4(&)[4]>(X[4 * JB]), sbuf[buf]);
             buf ^= 1;
         }
     }
