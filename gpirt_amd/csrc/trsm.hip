@@ -19,12 +19,15 @@ namespace {
 constexpr int NL = 64;          // leaf rows
 constexpr int CB = 64;          // right-hand-side columns per work-group
 
+// A 64 x 64 coefficient block goes global -> registers -> LDS:
+//   s[c * S64_LS + r] = M[64 rb + r][64 cb + c];  M = L (forward) or the flipped transpose (backward).
 template <bool BACK>
 __device__ __forceinline__ void stage_block(const double* __restrict__ L, int64_t ldl, int nb, int rb, int cb,
                                             bool diag, double* __restrict__ s)
 {
-    // s[c * S64_LS + r] = M[64 rb + r][64 cb + c];  M = L (forward) or the flipped transpose (backward).
     // All 16 loads of a thread are issued before the first LDS store (one memory round trip, not 16).
+    // (Fetching the next block into registers while this one computes was measured twice -- one and two
+    // blocks ahead -- and made every stage slower, not faster; the blocks come from L2 anyway.)
     const int t = threadIdx.x;
     double v[16];
 #pragma unroll
@@ -33,18 +36,18 @@ __device__ __forceinline__ void stage_block(const double* __restrict__ L, int64_
         int r, c;
         if (!BACK) { r = idx & (NL - 1); c = idx >> 6; } else { c = idx & (NL - 1); r = idx >> 6; }
         const int a = 64 * rb + r, b = 64 * cb + c;            // M[a][b]
-        double x = 0.0;
-        if (a < nb && b < nb && (!diag || a >= b))
-            x = BACK ? L[(int64_t)(nb - 1 - b) + (int64_t)(nb - 1 - a) * ldl] : L[(int64_t)a + (int64_t)b * ldl];
-        else if (diag && a == b) x = 1.0;                      // identity padding of a ragged last block
-        v[k] = x;
+        const bool in = a < nb && b < nb;
+        const int ac = in ? a : 0, bc = in ? b : 0;            // clamped: the load itself is unconditional
+        v[k] = BACK ? L[(int64_t)(nb - 1 - bc) + (int64_t)(nb - 1 - ac) * ldl] : L[(int64_t)ac + (int64_t)bc * ldl];
     }
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int idx = t + 256 * k;
         int r, c;
         if (!BACK) { r = idx & (NL - 1); c = idx >> 6; } else { c = idx & (NL - 1); r = idx >> 6; }
-        s[c * S64_LS + r] = v[k];
+        const int a = 64 * rb + r, b = 64 * cb + c;
+        const bool in = a < nb && b < nb && (!diag || a >= b);
+        s[c * S64_LS + r] = in ? v[k] : ((diag && a == b) ? 1.0 : 0.0);   // identity padding of a ragged last block
     }
 }
 
@@ -98,54 +101,113 @@ constexpr int NL4 = 256;
 
 template <bool BACK>
 __global__ __launch_bounds__(256) void trsm_leaf256_kernel(const double* __restrict__ L, int64_t ldl, int nb,
-                                                           double* __restrict__ B, int64_t ldb, int64_t nrhs)
+                                                           double* __restrict__ B, int64_t ldb, int64_t nrhs,
+                                                           long long* trace)
 {
+    // trace: optional 100 MHz stamps of work-group 0 (tools/micro/leaf_bench.hip), nullptr in the library
+#define LEAF_STAMP(slot) do { if (trace && blockIdx.x == 0 && threadIdx.x == 0) trace[slot] = wall_clock64(); } while (0)
+    LEAF_STAMP(0);
     __shared__ __attribute__((aligned(16))) double sbuf[2][NL * S64_LS];
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int i = lane & 15, g = lane >> 4;
-    const int64_t col = (int64_t)blockIdx.x * CB + wave * 16 + i;
-    const bool live = col < nrhs;
-    double* b = B + col * ldb;
     const int nblk = (nb + NL - 1) / NL;
+    const int64_t col0 = (int64_t)blockIdx.x * CB;
+    // The right-hand sides move between memory and the MFMA layout (lane = column, registers = rows) through
+    // LDS, 64 x 64 tiles at a time, so every global access runs along a column of B: 512 contiguous bytes per
+    // wavefront instead of 64 lanes x 8 bytes scattered over 64 cache lines.
+    //   tile element (e, cc): solve-order entry 64 JB + e of right-hand side col0 + cc, kept at s[cc * LS + e]
+    const int te = t & 63, tcq = t >> 6;               // this thread moves entries te of columns tcq + 4 k
     d4 X[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q)
+    for (int half = 0; half < 2; ++half) {
+        double xv[2][16];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int c = 16 * q + 4 * g + r;
-            const int p = BACK ? (nb - 1 - c) : c;
-            X[q][r] = (live && c < nb) ? b[p] : 0.0;
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int JB = 2 * half + h2;
+            const int c = 64 * JB + te;                // solve-order entry
+            const int prow = BACK ? (nb - 1 - c) : c;  // its row in memory
+            if (64 * JB + 64 <= nb && col0 + CB <= nrhs) {   // interior tile (uniform): plain loads, all in flight
+                const double* src = B + prow + (col0 + tcq) * ldb;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) xv[h2][k] = src[(int64_t)(4 * k) * ldb];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int64_t cc = col0 + tcq + 4 * k;
+                    const bool ok = (c < nb) && (cc < nrhs);
+                    const double x = B[(int64_t)(ok ? prow : 0) + (ok ? cc : col0) * ldb];
+                    xv[h2][k] = ok ? x : 0.0;
+                }
+            }
         }
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) sbuf[h2][(tcq + 4 * k) * S64_LS + te] = xv[h2][k];
+        __syncthreads();
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double2 lo = *reinterpret_cast<const double2*>(&sbuf[h2][(16 * wave + i) * S64_LS + 16 * q + 4 * g]);
+                const double2 hi = *reinterpret_cast<const double2*>(&sbuf[h2][(16 * wave + i) * S64_LS + 16 * q + 4 * g + 2]);
+                X[8 * half + 4 * h2 + q] = d4{ lo.x, lo.y, hi.x, hi.y };
+            }
+        __syncthreads();
+    }
+    // the (JB, IB) stages in execution order: row block JB takes its off-diagonal blocks IB < JB, then its
+    // diagonal block
     int buf = 0;
+    int stamp = 1;
 #pragma unroll
     for (int JB = 0; JB < 4; ++JB) {
         if (JB < nblk) {
 #pragma unroll
-            for (int IB = 0; IB < JB; ++IB) {
-                stage_block<BACK>(L, ldl, nb, JB, IB, false, sbuf[buf]);
+            for (int IB = 0; IB <= JB; ++IB) {
+                const bool diag = (IB == JB);
+                stage_block<BACK>(L, ldl, nb, JB, IB, diag, sbuf[buf]);
                 __syncthreads();
-                strip64_update(reinterpret_cast<d4(&)[4]>(X[4 * JB]), reinterpret_cast<const d4(&)[4]>(X[4 * IB]),
-                               sbuf[buf]);
+                LEAF_STAMP(stamp); ++stamp;
+                if (!diag) {
+                    strip64_update(reinterpret_cast<d4(&)[4]>(X[4 * JB]), reinterpret_cast<const d4(&)[4]>(X[4 * IB]),
+                                   sbuf[buf]);
+                } else {
+                    invert_diag16(sbuf[buf]);
+                    solve64_lower_inv(reinterpret_cast<d4(&)[4]>(X[4 * JB]), sbuf[buf]);
+                }
                 buf ^= 1;
             }
-            stage_block<BACK>(L, ldl, nb, JB, JB, true, sbuf[buf]);
-            __syncthreads();
-            invert_diag16(sbuf[buf]);
-            solve64_lower_inv(reinterpret_cast<d4(&)[4]>(X[4 * JB]), sbuf[buf]);
-            buf ^= 1;
         }
     }
-    if (live) {
+    LEAF_STAMP(stamp); ++stamp;
+    __syncthreads();                                   // the last stage has finished with both buffers
 #pragma unroll
-        for (int q = 0; q < 16; ++q)
+    for (int half = 0; half < 2; ++half) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = 16 * q + 4 * g + r;
-                const int p = BACK ? (nb - 1 - c) : c;
-                if (c < nb) b[p] = X[q][r];
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const d4 x = X[8 * half + 4 * h2 + q];
+                *reinterpret_cast<double2*>(&sbuf[h2][(16 * wave + i) * S64_LS + 16 * q + 4 * g]) = double2{ x[0], x[1] };
+                *reinterpret_cast<double2*>(&sbuf[h2][(16 * wave + i) * S64_LS + 16 * q + 4 * g + 2]) = double2{ x[2], x[3] };
             }
+        __syncthreads();
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int JB = 2 * half + h2;
+            const int c = 64 * JB + te;
+            const int prow = BACK ? (nb - 1 - c) : c;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int64_t cc = col0 + tcq + 4 * k;
+                if (c < nb && cc < nrhs) B[(int64_t)prow + cc * ldb] = sbuf[h2][(tcq + 4 * k) * S64_LS + te];
+            }
+        }
+        __syncthreads();
     }
+    LEAF_STAMP(stamp);
+#undef LEAF_STAMP
 }
 
 int trsm_rec(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t ldl, double* B,
@@ -156,10 +218,10 @@ int trsm_rec(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t ldl,
         const unsigned grid = (unsigned)((nrhs + CB - 1) / CB);
         if (!trans)
             hipLaunchKernelGGL(trsm_leaf256_kernel<false>, dim3(grid), dim3(256), 0, stream,
-                               L + r0 + r0 * ldl, ldl, (int)len, B + r0, ldb, nrhs);
+                               L + r0 + r0 * ldl, ldl, (int)len, B + r0, ldb, nrhs, (long long*)nullptr);
         else
             hipLaunchKernelGGL(trsm_leaf256_kernel<true>, dim3(grid), dim3(256), 0, stream,
-                               L + r0 + r0 * ldl, ldl, (int)len, B + r0, ldb, nrhs);
+                               L + r0 + r0 * ldl, ldl, (int)len, B + r0, ldb, nrhs, (long long*)nullptr);
         return 0;
     }
     if (len <= NL) {
