@@ -116,6 +116,8 @@ int gpirt_destroy(gpirt_handle_t h)
     if (h->h_info) hipHostFree(h->h_info);
     if (h->d_work) hipFree(h->d_work);
     if (h->d_prog) hipFree(h->d_prog);
+    if (h->d_trsm_winv) hipFree(h->d_trsm_winv);
+    if (h->d_trsm_tmp) hipFree(h->d_trsm_tmp);
     for (auto& pp : h->prof.pending) { hipEventDestroy(pp.e0); hipEventDestroy(pp.e1); }
     for (auto& pp : h->prof.free_pairs) { hipEventDestroy(pp.e0); hipEventDestroy(pp.e1); }
     if (h->side) hipStreamDestroy(h->side);

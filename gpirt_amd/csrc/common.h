@@ -72,6 +72,11 @@ struct gpirt_handle_s {
     size_t       prog_cap = 0;
     unsigned long long prog_seq = 0;
     long long*   panel_trace = nullptr;   // debug stamps (micro-benchmarks only)
+    // trsm.hip: inverses of L's 256 x 256 diagonal blocks (rebuilt per call) + a 256 x nrhs product buffer
+    double*      d_trsm_winv = nullptr;
+    size_t       trsm_winv_bytes = 0;
+    double*      d_trsm_tmp = nullptr;
+    size_t       trsm_tmp_bytes = 0;
 };
 
 namespace gpirt {

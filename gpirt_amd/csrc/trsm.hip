@@ -12,6 +12,8 @@
 #include "kernels.h"
 #include "solve64.h"
 
+#include <stdlib.h>
+
 namespace gpirt {
 
 namespace {
@@ -99,11 +101,15 @@ __global__ __launch_bounds__(256) void trsm_leaf_kernel(const double* __restrict
 // 4 leaf launches + 3 small gemm launches (and their 6 kernel boundaries) of the recursion.
 constexpr int NL4 = 256;
 
-template <bool BACK>
+// IDENT: the right-hand side is the identity (nothing is read from B) and blockIdx.y walks a batch of
+// diagonal blocks -- L advances by lstride, B by bstride per batch entry: the 256 x 256 inverses of trsm_rec.
+template <bool BACK, bool IDENT = false>
 __global__ __launch_bounds__(256) void trsm_leaf256_kernel(const double* __restrict__ L, int64_t ldl, int nb,
                                                            double* __restrict__ B, int64_t ldb, int64_t nrhs,
-                                                           long long* trace)
+                                                           long long* trace, int64_t lstride = 0, int64_t bstride = 0)
 {
+    L += (int64_t)blockIdx.y * lstride;
+    B += (int64_t)blockIdx.y * bstride;
     // trace: optional 100 MHz stamps of work-group 0 (tools/micro/leaf_bench.hip), nullptr in the library
 #define LEAF_STAMP(slot) do { if (trace && blockIdx.x == 0 && threadIdx.x == 0) trace[slot] = wall_clock64(); } while (0)
     LEAF_STAMP(0);
@@ -127,7 +133,10 @@ __global__ __launch_bounds__(256) void trsm_leaf256_kernel(const double* __restr
             const int JB = 2 * half + h2;
             const int c = 64 * JB + te;                // solve-order entry
             const int prow = BACK ? (nb - 1 - c) : c;  // its row in memory
-            if (64 * JB + 64 <= nb && col0 + CB <= nrhs) {   // interior tile (uniform): plain loads, all in flight
+            if (IDENT) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) xv[h2][k] = ((int64_t)c == col0 + tcq + 4 * k) ? 1.0 : 0.0;
+            } else if (64 * JB + 64 <= nb && col0 + CB <= nrhs) {   // interior tile (uniform): plain loads, all in flight
                 const double* src = B + prow + (col0 + tcq) * ldb;
 #pragma unroll
                 for (int k = 0; k < 16; ++k) xv[h2][k] = src[(int64_t)(4 * k) * ldb];
@@ -210,10 +219,27 @@ __global__ __launch_bounds__(256) void trsm_leaf256_kernel(const double* __restr
 #undef LEAF_STAMP
 }
 
+// rows of B <- the 256 x nrhs product parked in the workspace (ld 256)
+__global__ __launch_bounds__(256) void copy_back_kernel(const double* __restrict__ T, double* __restrict__ B, int64_t ldb,
+                                                        int64_t nrhs)
+{
+    const int64_t c = blockIdx.x;
+    if (c < nrhs) B[threadIdx.x + c * ldb] = T[threadIdx.x + c * NL4];
+}
+
+// winv != nullptr (forward solves only): the 256 x 256 inverses of L's full diagonal blocks, block b at
+// winv + b * 256 * 256 (ld 256); a full leaf is then the product W_b * B_b on all CUs (lower-triangular
+// GEMM into the workspace + copy back, 22 + 4 us) instead of the 48 us substitution on nrhs / 64 of them.
 int trsm_rec(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t ldl, double* B,
-             int64_t nrhs, int64_t ldb, bool trans, int64_t r0, int64_t r1)
+             int64_t nrhs, int64_t ldb, bool trans, int64_t r0, int64_t r1, const double* winv = nullptr)
 {
     const int64_t len = r1 - r0;
+    if (winv && len == NL4 && (r0 % NL4) == 0) {
+        GP_TRY(launch_gemm(h, stream, false, false, TRI_A_LOWER, NL4, nrhs, NL4, 1.0, winv + (r0 / NL4) * (NL4 * NL4), NL4,
+                           B + r0, ldb, 0.0, h->d_trsm_tmp, NL4));
+        hipLaunchKernelGGL(copy_back_kernel, dim3((unsigned)nrhs), dim3(256), 0, stream, h->d_trsm_tmp, B + r0, ldb, nrhs);
+        return 0;
+    }
     if (len <= NL4 && len > NL) {
         const unsigned grid = (unsigned)((nrhs + CB - 1) / CB);
         if (!trans)
@@ -239,11 +265,11 @@ int trsm_rec(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t ldl,
     if (half >= len) half = ((len / 2 + NL - 1) / NL) * NL;
     const int64_t mid = r0 + half;
     if (!trans) {
-        GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, r0, mid));
+        GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, r0, mid, winv));
         // B[mid:r1, :] -= L[mid:r1, r0:mid] * B[r0:mid, :]
         GP_TRY(launch_gemm(h, stream, false, false, TRI_NONE, r1 - mid, nrhs, mid - r0, -1.0,
                            L + mid + r0 * ldl, ldl, B + r0, ldb, 1.0, B + mid, ldb));
-        GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, mid, r1));
+        GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, mid, r1, winv));
     } else {
         GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, mid, r1));
         // B[r0:mid, :] -= L[mid:r1, r0:mid]^T * B[mid:r1, :]
@@ -260,7 +286,35 @@ int launch_trsm_lower(gpirt_handle_t h, hipStream_t stream, const double* L, int
                       double* B, int64_t nrhs, int64_t ldb, bool trans)
 {
     if (n <= 0 || nrhs <= 0) return 0;
-    GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, 0, n));
+    // GPIRT_TRSM_INV=2 keeps every leaf a substitution
+    static const bool use_inv = !(getenv("GPIRT_TRSM_INV") && atoi(getenv("GPIRT_TRSM_INV")) == 2);
+    const double* winv = nullptr;
+    const int64_t nfull = n / NL4;
+    if (use_inv && !trans && nfull >= 2 && nrhs >= 256) {
+        // invert the full 256 x 256 diagonal blocks: one batched launch of the fused leaf on identity
+        // right-hand sides (4 work-groups per block), ~50 us for the whole matrix
+        const size_t wbytes = (size_t)nfull * NL4 * NL4 * sizeof(double), tbytes = (size_t)NL4 * (size_t)nrhs * sizeof(double);
+        if (h->trsm_winv_bytes < wbytes || h->trsm_tmp_bytes < tbytes) {
+            GP_HIP(hipStreamSynchronize(stream));
+            if (h->trsm_winv_bytes < wbytes) {
+                if (h->d_trsm_winv) GP_HIP(hipFree(h->d_trsm_winv));
+                h->d_trsm_winv = nullptr; h->trsm_winv_bytes = 0;
+                GP_HIP(hipMalloc(&h->d_trsm_winv, wbytes));
+                h->trsm_winv_bytes = wbytes;
+            }
+            if (h->trsm_tmp_bytes < tbytes) {
+                if (h->d_trsm_tmp) GP_HIP(hipFree(h->d_trsm_tmp));
+                h->d_trsm_tmp = nullptr; h->trsm_tmp_bytes = 0;
+                GP_HIP(hipMalloc(&h->d_trsm_tmp, tbytes));
+                h->trsm_tmp_bytes = tbytes;
+            }
+        }
+        hipLaunchKernelGGL((trsm_leaf256_kernel<false, true>), dim3(NL4 / CB, (unsigned)nfull), dim3(256), 0, stream,
+                           L, ldl, NL4, h->d_trsm_winv, (int64_t)NL4, (int64_t)NL4, (long long*)nullptr,
+                           (int64_t)NL4 * (ldl + 1), (int64_t)NL4 * NL4);
+        winv = h->d_trsm_winv;
+    }
+    GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, 0, n, winv));
     GP_HIP(hipGetLastError());
     return 0;
 }
