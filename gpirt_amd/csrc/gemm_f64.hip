@@ -49,6 +49,7 @@ struct GemmParams {
     int tri;
     int mblocks, nblocks;
     int fastA, fastB;     // operand base/ld are 16-byte friendly
+    int64_t sA, sB, sC;   // batch strides (elements): blockIdx.y selects the problem (0 for a single GEMM)
     // fused epilogue (FUSE kernels only): work-group 0 factors this 64 x 64 block after its tile
     double* fz_A; int64_t fz_lda; int fz_nb; int fz_k0; int* fz_info;
 };
@@ -257,6 +258,9 @@ template <bool TA, bool TB, int T, int PAD = 0, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p)
 {
     __shared__ __attribute__((aligned(16))) double smem[4 * Cfg<T>::TILE + PAD];
+    p.A += (int64_t)blockIdx.y * p.sA;
+    p.B += (int64_t)blockIdx.y * p.sB;
+    p.C += (int64_t)blockIdx.y * p.sC;
     int bi, bj;
     if (p.tri == TRI_SYRK_LOWER) {
         // block columns bj = 0..nblocks-1, each holding block rows bj..mblocks-1 (M >= N trapezoid)
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p)
 }  // namespace
 
 template <int T>
-static int launch_gemm_t(hipStream_t stream, bool ta, bool tb, GemmParams p);
+static int launch_gemm_t(hipStream_t stream, bool ta, bool tb, GemmParams p, int batch = 1);
 
 // The Cholesky trailing update gets its own instantiations of the NT / syrk-lower 128-tile kernel
 // (PAD = 8: same code, +64 B of LDS) so kernel traces and PMC profiles can tell it apart by name
@@ -332,6 +336,7 @@ int launch_gemm_update_potf2(hipStream_t stream, int64_t M, int64_t N, int64_t K
     p.mblocks = (p.M + T - 1) / T;
     p.nblocks = (p.N + T - 1) / T;
     p.fz_A = C; p.fz_lda = ldc; p.fz_nb = nb_next; p.fz_k0 = k0_next; p.fz_info = info;
+    p.sA = p.sB = p.sC = 0;
     const int64_t grid = (int64_t)p.nblocks * p.mblocks - (int64_t)p.nblocks * (p.nblocks - 1) / 2;
     hipLaunchKernelGGL((gemm_f64_kernel<false, true, 64, 0, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
     GP_HIP(hipGetLastError());
@@ -345,7 +350,7 @@ bool gemm_trailing_uses_128(int64_t M, int64_t N)
 }
 
 template <int T>
-static int launch_gemm_t(hipStream_t stream, bool ta, bool tb, GemmParams p)
+static int launch_gemm_t(hipStream_t stream, bool ta, bool tb, GemmParams p, int batch)
 {
     p.mblocks = (p.M + T - 1) / T;
     p.nblocks = (p.N + T - 1) / T;
@@ -353,13 +358,33 @@ static int launch_gemm_t(hipStream_t stream, bool ta, bool tb, GemmParams p)
     if (p.tri == TRI_SYRK_LOWER) grid = (int64_t)p.nblocks * p.mblocks - (int64_t)p.nblocks * (p.nblocks - 1) / 2;
     else if (p.tri == TRI_A_LOWER || p.tri == TRI_A_UPPER) grid = (int64_t)((p.mblocks + 1) / 2) * p.nblocks;
     else grid = (int64_t)p.mblocks * p.nblocks;
-    dim3 g((unsigned)grid), b(256);
+    dim3 g((unsigned)grid, (unsigned)batch), b(256);
     if (!ta && tb)       hipLaunchKernelGGL((gemm_f64_kernel<false, true, T>),  g, b, 0, stream, p);
     else if (!ta && !tb) hipLaunchKernelGGL((gemm_f64_kernel<false, false, T>), g, b, 0, stream, p);
     else if (ta && !tb)  hipLaunchKernelGGL((gemm_f64_kernel<true, false, T>),  g, b, 0, stream, p);
     else                 hipLaunchKernelGGL((gemm_f64_kernel<true, true, T>),   g, b, 0, stream, p);
     GP_HIP(hipGetLastError());
     return 0;
+}
+
+// `batch` independent products of one shape (TRI_NONE / TRI_A_* only), operands `stride*` elements apart
+int launch_gemm_batched(hipStream_t stream, bool ta, bool tb, int tri, int64_t M, int64_t N, int64_t K, double alpha,
+                        const double* A, int64_t lda, int64_t strideA, const double* B, int64_t ldb, int64_t strideB,
+                        double beta, double* C, int64_t ldc, int64_t strideC, int batch)
+{
+    if (M <= 0 || N <= 0 || batch <= 0) return 0;
+    if (tri == TRI_SYRK_LOWER || tri == TRI_SYRK_LOWER_TRAILING) { set_error("batched gemm: no syrk mode"); return GPIRT_E_ARG; }
+    GemmParams p;
+    p.A = A; p.B = B; p.C = C;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.M = (int)M; p.N = (int)N; p.K = (int)K;
+    p.alpha = alpha; p.beta = beta; p.tri = tri;
+    p.mblocks = p.nblocks = 0;
+    p.fz_A = nullptr; p.fz_lda = 0; p.fz_nb = 0; p.fz_k0 = 0; p.fz_info = nullptr;
+    p.sA = strideA; p.sB = strideB; p.sC = strideC;
+    p.fastA = (((uintptr_t)A & 15) == 0) && (lda % 2 == 0) && (strideA % 2 == 0);
+    p.fastB = (((uintptr_t)B & 15) == 0) && (ldb % 2 == 0) && (strideB % 2 == 0);
+    return launch_gemm_t<64>(stream, ta, tb, p, batch);
 }
 
 int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri, int64_t M,
@@ -375,6 +400,7 @@ int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri,
     p.alpha = alpha; p.beta = beta; p.tri = tri;
     p.mblocks = p.nblocks = 0;
     p.fz_A = nullptr; p.fz_lda = 0; p.fz_nb = 0; p.fz_k0 = 0; p.fz_info = nullptr;
+    p.sA = p.sB = p.sC = 0;
     p.fastA = (((uintptr_t)A & 15) == 0) && (lda % 2 == 0);
     p.fastB = (((uintptr_t)B & 15) == 0) && (ldb % 2 == 0);
     if (tri == TRI_SYRK_LOWER_TRAILING) {

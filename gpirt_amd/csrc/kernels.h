@@ -15,6 +15,10 @@ int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri,
                 int64_t N, int64_t K, double alpha, const double* A, int64_t lda, const double* B,
                 int64_t ldb, double beta, double* C, int64_t ldc);
 
+int launch_gemm_batched(hipStream_t stream, bool ta, bool tb, int tri, int64_t M, int64_t N, int64_t K, double alpha,
+                        const double* A, int64_t lda, int64_t strideA, const double* B, int64_t ldb, int64_t strideB,
+                        double beta, double* C, int64_t ldc, int64_t strideC, int batch);
+
 // se_kernel.hip
 int launch_se_kernel(hipStream_t stream, const double* x1, int64_t n1, const double* x2, int64_t n2,
                      double* out, int64_t ld, double jitter);

@@ -102,14 +102,16 @@ __global__ __launch_bounds__(256) void trsm_leaf_kernel(const double* __restrict
 constexpr int NL4 = 256;
 
 // IDENT: the right-hand side is the identity (nothing is read from B) and blockIdx.y walks a batch of
-// diagonal blocks -- L advances by lstride, B by bstride per batch entry: the 256 x 256 inverses of trsm_rec.
+// diagonal blocks -- L advances by lstride per entry, B by bstride per PAIR of entries plus bhalf for the odd
+// one (the two diagonal quarters of a 512 x 512 inverse): the block inverses of trsm_rec.
 template <bool BACK, bool IDENT = false>
 __global__ __launch_bounds__(256) void trsm_leaf256_kernel(const double* __restrict__ L, int64_t ldl, int nb,
                                                            double* __restrict__ B, int64_t ldb, int64_t nrhs,
-                                                           long long* trace, int64_t lstride = 0, int64_t bstride = 0)
+                                                           long long* trace, int64_t lstride = 0, int64_t bstride = 0,
+                                                           int64_t bhalf = 0)
 {
     L += (int64_t)blockIdx.y * lstride;
-    B += (int64_t)blockIdx.y * bstride;
+    B += (int64_t)(blockIdx.y >> 1) * bstride + (int64_t)(blockIdx.y & 1) * bhalf;
     // trace: optional 100 MHz stamps of work-group 0 (tools/micro/leaf_bench.hip), nullptr in the library
 #define LEAF_STAMP(slot) do { if (trace && blockIdx.x == 0 && threadIdx.x == 0) trace[slot] = wall_clock64(); } while (0)
     LEAF_STAMP(0);
@@ -219,26 +221,42 @@ __global__ __launch_bounds__(256) void trsm_leaf256_kernel(const double* __restr
 #undef LEAF_STAMP
 }
 
-// rows of B <- the 256 x nrhs product parked in the workspace (ld 256)
-__global__ __launch_bounds__(256) void copy_back_kernel(const double* __restrict__ T, double* __restrict__ B, int64_t ldb,
-                                                        int64_t nrhs)
+// rows of B <- the rows x nrhs product parked in the workspace (ld = rows; rows = 256 or 512)
+__global__ __launch_bounds__(256) void copy_back_kernel(const double* __restrict__ T, int rows, double* __restrict__ B,
+                                                        int64_t ldb, int64_t nrhs)
 {
     const int64_t c = blockIdx.x;
-    if (c < nrhs) B[threadIdx.x + c * ldb] = T[threadIdx.x + c * NL4];
+    if (c >= nrhs) return;
+    for (int r = threadIdx.x; r < rows; r += 256) B[r + c * ldb] = T[r + c * (int64_t)rows];
 }
 
-// winv != nullptr (forward solves only): the 256 x 256 inverses of L's full diagonal blocks, block b at
-// winv + b * 256 * 256 (ld 256); a full leaf is then the product W_b * B_b on all CUs (lower-triangular
-// GEMM into the workspace + copy back, 22 + 4 us) instead of the 48 us substitution on nrhs / 64 of them.
+constexpr int NI = 512;         // edge of the explicitly inverted diagonal blocks
+
+// Forward solves with winv != nullptr: the inverses of L's diagonal blocks, 512 x 512 block b at
+// winv + b * 512 * 512 (ld 512, lower triangle; npair of them), plus -- when an odd full 256-row block is left
+// over -- its 256 x 256 inverse in slot npair.  A 512-aligned leaf is then the product W_b * B_b on all CUs
+// (lower-triangular GEMM into the workspace + copy back, ~44 us) instead of two 48 us substitutions on
+// nrhs / 64 of them with a GEMM in between; 256-row leaves use the diagonal quarters the same way.
 int trsm_rec(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t ldl, double* B,
-             int64_t nrhs, int64_t ldb, bool trans, int64_t r0, int64_t r1, const double* winv = nullptr)
+             int64_t nrhs, int64_t ldb, bool trans, int64_t r0, int64_t r1, const double* winv = nullptr,
+             int64_t npair = 0, bool odd = false)
 {
     const int64_t len = r1 - r0;
-    if (winv && len == NL4 && (r0 % NL4) == 0) {
-        GP_TRY(launch_gemm(h, stream, false, false, TRI_A_LOWER, NL4, nrhs, NL4, 1.0, winv + (r0 / NL4) * (NL4 * NL4), NL4,
-                           B + r0, ldb, 0.0, h->d_trsm_tmp, NL4));
-        hipLaunchKernelGGL(copy_back_kernel, dim3((unsigned)nrhs), dim3(256), 0, stream, h->d_trsm_tmp, B + r0, ldb, nrhs);
-        return 0;
+    if (winv) {
+        const double* W = nullptr;
+        if (len == NI && (r0 % NI) == 0 && r0 / NI < npair) {
+            W = winv + (r0 / NI) * (int64_t)(NI * NI);
+        } else if (len == NL4 && (r0 % NL4) == 0) {
+            if (r0 / NI < npair) W = winv + (r0 / NI) * (int64_t)(NI * NI) + ((r0 % NI) ? (int64_t)NL4 * (NI + 1) : 0);
+            else if (odd && r0 == npair * NI) W = winv + npair * (int64_t)(NI * NI);
+        }
+        if (W) {
+            GP_TRY(launch_gemm(h, stream, false, false, TRI_A_LOWER, len, nrhs, len, 1.0, W, NI, B + r0, ldb, 0.0,
+                               h->d_trsm_tmp, len));
+            hipLaunchKernelGGL(copy_back_kernel, dim3((unsigned)nrhs), dim3(256), 0, stream, h->d_trsm_tmp, (int)len,
+                               B + r0, ldb, nrhs);
+            return 0;
+        }
     }
     if (len <= NL4 && len > NL) {
         const unsigned grid = (unsigned)((nrhs + CB - 1) / CB);
@@ -265,11 +283,11 @@ int trsm_rec(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t ldl,
     if (half >= len) half = ((len / 2 + NL - 1) / NL) * NL;
     const int64_t mid = r0 + half;
     if (!trans) {
-        GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, r0, mid, winv));
+        GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, r0, mid, winv, npair, odd));
         // B[mid:r1, :] -= L[mid:r1, r0:mid] * B[r0:mid, :]
         GP_TRY(launch_gemm(h, stream, false, false, TRI_NONE, r1 - mid, nrhs, mid - r0, -1.0,
                            L + mid + r0 * ldl, ldl, B + r0, ldb, 1.0, B + mid, ldb));
-        GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, mid, r1, winv));
+        GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, mid, r1, winv, npair, odd));
     } else {
         GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, mid, r1));
         // B[r0:mid, :] -= L[mid:r1, r0:mid]^T * B[mid:r1, :]
@@ -289,11 +307,16 @@ int launch_trsm_lower(gpirt_handle_t h, hipStream_t stream, const double* L, int
     // GPIRT_TRSM_INV=2 keeps every leaf a substitution
     static const bool use_inv = !(getenv("GPIRT_TRSM_INV") && atoi(getenv("GPIRT_TRSM_INV")) == 2);
     const double* winv = nullptr;
-    const int64_t nfull = n / NL4;
+    const int64_t nfull = n / NL4, npair = nfull / 2;
+    const bool odd = (nfull & 1) != 0;
     if (use_inv && !trans && nfull >= 2 && nrhs >= 256) {
-        // invert the full 256 x 256 diagonal blocks: one batched launch of the fused leaf on identity
-        // right-hand sides (4 work-groups per block), ~50 us for the whole matrix
-        const size_t wbytes = (size_t)nfull * NL4 * NL4 * sizeof(double), tbytes = (size_t)NL4 * (size_t)nrhs * sizeof(double);
+        // 1. the full 256 x 256 diagonal blocks: ONE batched launch of the fused leaf on identity right-hand
+        //    sides (4 work-groups per block, ~50 us for the whole matrix), written straight into the diagonal
+        //    quarters of the 512 x 512 slots;
+        // 2. the lower-left quarter of each slot,  -W2 (L21 W1),  as two batched 256^3 MFMA products.
+        const size_t wbytes = (size_t)(npair + 1) * NI * NI * sizeof(double);
+        size_t tbytes = (size_t)NI * (size_t)nrhs * sizeof(double);
+        if (tbytes < (size_t)npair * NL4 * NL4 * sizeof(double)) tbytes = (size_t)npair * NL4 * NL4 * sizeof(double);
         if (h->trsm_winv_bytes < wbytes || h->trsm_tmp_bytes < tbytes) {
             GP_HIP(hipStreamSynchronize(stream));
             if (h->trsm_winv_bytes < wbytes) {
@@ -309,12 +332,23 @@ int launch_trsm_lower(gpirt_handle_t h, hipStream_t stream, const double* L, int
                 h->trsm_tmp_bytes = tbytes;
             }
         }
+        double* W = h->d_trsm_winv;
         hipLaunchKernelGGL((trsm_leaf256_kernel<false, true>), dim3(NL4 / CB, (unsigned)nfull), dim3(256), 0, stream,
-                           L, ldl, NL4, h->d_trsm_winv, (int64_t)NL4, (int64_t)NL4, (long long*)nullptr,
-                           (int64_t)NL4 * (ldl + 1), (int64_t)NL4 * NL4);
-        winv = h->d_trsm_winv;
+                           L, ldl, NL4, W, (int64_t)NI, (int64_t)NL4, (long long*)nullptr,
+                           (int64_t)NL4 * (ldl + 1), (int64_t)NI * NI, (int64_t)NL4 * (NI + 1));
+        if (npair > 0) {
+            // T_b = L21 W1
+            GP_TRY(launch_gemm_batched(stream, false, false, TRI_NONE, NL4, NL4, NL4, 1.0,
+                                       L + NL4, ldl, (int64_t)NI * (ldl + 1), W, NI, (int64_t)NI * NI,
+                                       0.0, h->d_trsm_tmp, NL4, (int64_t)NL4 * NL4, (int)npair));
+            // W21 = -W2 T_b
+            GP_TRY(launch_gemm_batched(stream, false, false, TRI_A_LOWER, NL4, NL4, NL4, -1.0,
+                                       W + (int64_t)NL4 * (NI + 1), NI, (int64_t)NI * NI, h->d_trsm_tmp, NL4,
+                                       (int64_t)NL4 * NL4, 0.0, W + NL4, NI, (int64_t)NI * NI, (int)npair));
+        }
+        winv = W;
     }
-    GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, 0, n, winv));
+    GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, 0, n, winv, npair, odd));
     GP_HIP(hipGetLastError());
     return 0;
 }
