@@ -85,7 +85,9 @@ def test_potrf_not_positive_definite_raises(handle):
         handle.potrf_lower(to_device(S))
 
 
-@pytest.mark.parametrize("n,m", [(100, 7), (300, 130), (1024, 256)])
+# (512, 256) .. (1339, 300): forward solves whose full 256-row leaves go through block inverses -- an even
+# and an odd number of 256-blocks, 512-aligned and unaligned leaves, a ragged tail
+@pytest.mark.parametrize("n,m", [(100, 7), (300, 130), (1024, 256), (512, 256), (768, 257), (1339, 300), (1792, 256)])
 def test_trmm_trsm(handle, oracle, n, m):
     from gpirt_amd.ops import to_device, to_host
     theta = _theta_grid(n, 5)
