@@ -123,6 +123,7 @@ int gpirt_destroy(gpirt_handle_t h)
     if (h->side) hipStreamDestroy(h->side);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
+    if (h->ev_mid) hipEventDestroy(h->ev_mid);
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
     return 0;

@@ -226,18 +226,35 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
         GP_HIP(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, hi_pri));
         GP_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        GP_HIP(hipEventCreateWithFlags(&h->ev_mid, hipEventDisableTiming));
     }
+    const int64_t nbp_la = (env_int("GPIRT_NBP", NBP) / NBI) * NBI > 0 ? (env_int("GPIRT_NBP", NBP) / NBI) * NBI : NBP;
     GP_TRY(factor_panel(h, stream, A, n, lda, 0, nbo < n ? nbo : n));
     for (int64_t K0 = 0; K0 < n; K0 += nbo) {
         const int64_t c1 = (K0 + nbo < n) ? K0 + nbo : n;
         if (c1 >= n) break;
         const int64_t c2 = (c1 + nbo < n) ? c1 + nbo : n;
         bool diag_done = false;
-        GP_TRY(trailing(h, stream, A, n, lda, K0, c1, c1, c2, &diag_done)); // columns of the next panel
+        // with persistent sub-panels and look-ahead, only the first sub-panel's columns gate the side stream
+        const int64_t cA = (c1 + nbp_la < c2) ? c1 + nbp_la : c2;
+        const bool split = la && c2 < n && panel_persistent() && cA < c2;
+        GP_TRY(trailing(h, stream, A, n, lda, K0, c1, c1, split ? cA : c2, split ? nullptr : &diag_done));
         if (la && c2 < n) {
             GP_HIP(hipEventRecord(h->ev_fork, stream));
             GP_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-            GP_TRY(factor_panel(h, h->side, A, n, lda, c1, c2, diag_done)); // next panel, side stream
+            if (split) {
+                // the side stream starts on the first sub-panel as soon as ITS columns are up to date; the
+                // other columns of the outer panel are brought up to date behind it on the main stream
+                GP_TRY(factor_panel(h, h->side, A, n, lda, c1, cA));
+                GP_TRY(trailing(h, stream, A, n, lda, K0, c1, cA, c2));
+                GP_HIP(hipEventRecord(h->ev_mid, stream));
+                GP_HIP(hipStreamWaitEvent(h->side, h->ev_mid, 0));
+                GP_TRY(launch_gemm(h, h->side, false, true, TRI_SYRK_LOWER, n - cA, c2 - cA, cA - c1, -1.0,
+                                   A + cA + c1 * lda, lda, A + cA + c1 * lda, lda, 1.0, A + cA + cA * lda, lda));
+                GP_TRY(factor_panel(h, h->side, A, n, lda, cA, c2));
+            } else {
+                GP_TRY(factor_panel(h, h->side, A, n, lda, c1, c2, diag_done)); // next panel, side stream
+            }
             GP_TRY(trailing(h, stream, A, n, lda, K0, c1, c2, n));        // the rest, concurrently
             GP_HIP(hipEventRecord(h->ev_join, h->side));
             GP_HIP(hipStreamWaitEvent(stream, h->ev_join, 0));
