@@ -12,7 +12,9 @@
 //     lane, broadcast once (ds_bpermute from the owning 16-lane group) and folded into the other
 //     columns with 16 FMAs per lane; coefficients and pivot reciprocals are in registers before
 //     the dependent chain starts, so no step waits on LDS or on a division.
-// True substitution throughout (no inverted blocks): S = K + 1e-3 I has condition ~1e6 here.
+// solve64_lower is a true substitution throughout (kept for the launch-per-step Cholesky panel);
+// solve64_lower_inv below applies the 16 x 16 diagonal blocks through their inverses and is what the
+// persistent panel kernel and the trsm leaves run.  S = K + 1e-3 I has condition ~1e6 here.
 #pragma once
 
 #include "common.h"
