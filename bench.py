@@ -89,7 +89,9 @@ def main():
     ap.add_argument("--respondents", "--n", dest="n", type=int, default=8192)
     ap.add_argument("--items", "--m", dest="m", type=int, default=1024)
     ap.add_argument("--chol", default="replicated", choices=["replicated", "bcast"])
-    ap.add_argument("--fstar", default="fused", choices=["double_solve", "fused"])
+    ap.add_argument("--fstar", default="lowrank", choices=["double_solve", "fused", "lowrank"],
+                    help="double_solve: src/draw-fstar.cpp as written; fused: mean = (L^-1 k*)^T (L^-1 f); lowrank: fused + the "
+                         "rank-64 Chebyshev factorisation of K(theta, theta*) (exact to 1e-15), 64 + m right-hand sides")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
@@ -129,7 +131,8 @@ def main():
 
     def factory(y_loc, th, pm, ps, st, item0, m_total):
         return Sampler(handle, y_loc, th, pm, ps, st, rng="item", seed=20240, theta_stabilise=True,
-                       fstar_fused=(args.fstar == "fused"), item0=item0, m_total=m_total)
+                       fstar_fused=(args.fstar != "double_solve"), kstar_rank=(64 if args.fstar == "lowrank" else 0),
+                       item0=item0, m_total=m_total)
 
     ss = ShardedSampler(factory, y, theta0, dist=dist if world > 1 else None, chol=args.chol)
     ss.init()

@@ -39,6 +39,7 @@ template <int T> struct Cfg {
     static constexpr int TILE = (BK * (T + 16) > T * LDS_K) ? BK * (T + 16) : T * LDS_K;
     static constexpr int NT = T / 32;                     // MFMA tiles per wave per dimension
     static constexpr int PASSES = T / 32;                 // double2 loads per thread per operand tile
+    static constexpr int DEPTH = (T == 64) ? 4 : 1;       // K-steps in flight between global memory and LDS
 };
 
 struct GemmParams {
@@ -50,6 +51,7 @@ struct GemmParams {
     int mblocks, nblocks;
     int fastA, fastB;     // operand base/ld are 16-byte friendly
     int64_t sA, sB, sC;   // batch strides (elements): blockIdx.y selects the problem (0 for a single GEMM)
+    int ksplit;           // > 0: blockIdx.y selects the K range [y * ksplit, (y + 1) * ksplit) of ONE product (split-K)
     // fused epilogue (FUSE kernels only): work-group 0 factors this 64 x 64 block after its tile
     double* fz_A; int64_t fz_lda; int fz_nb; int fz_k0; int* fz_info;
 };
@@ -140,49 +142,63 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, const int bi,
     const int l15 = lane & 15, l4 = lane >> 4;
 
     const int nk = (kend - kbeg + BK - 1) / BK;
-    double2 ra[Cfg<T>::PASSES], rb[Cfg<T>::PASSES];
+    // Register ring of D K-steps between global memory and LDS: the tile of K-step kt + D is requested while
+    // K-step kt computes.  D = 1 for the 128-tile (its 128 accumulator registers leave room for one stage and
+    // two work-groups per CU hide the rest); D = 4 for the 64-tile, whose launches are often too small to put
+    // more than one work-group on a CU -- its K-step (16 MFMAs per wave, 0.43 us) is then far shorter than an
+    // L2 / MALL round trip and the loop ran at memory latency, 1.2 us per K-step.
+    constexpr int D = Cfg<T>::DEPTH;
+    double2 ra[D][Cfg<T>::PASSES], rb[D][Cfg<T>::PASSES];
+    auto request = [&](int kt, double2 (&qa)[Cfg<T>::PASSES], double2 (&qb)[Cfg<T>::PASSES]) {
+        const int k0 = kbeg + kt * BK;
+        const bool kfull = (k0 + BK <= p.K);
+        load_tile<A_KC, T>(p.A, p.lda, i0, p.M, k0, p.K, fullA && kfull, qa);
+        load_tile<B_KC, T>(p.B, p.ldb, j0, p.N, k0, p.K, fullB && kfull, qb);
+    };
     if (nk > 0) {
-        const bool kfull = (kbeg + BK <= p.K);
-        load_tile<A_KC, T>(p.A, p.lda, i0, p.M, kbeg, p.K, fullA && kfull, ra);
-        load_tile<B_KC, T>(p.B, p.ldb, j0, p.N, kbeg, p.K, fullB && kfull, rb);
-        store_tile<A_KC, T>(sA, ra);
-        store_tile<B_KC, T>(sB, rb);
+        request(0, ra[0], rb[0]);
+        store_tile<A_KC, T>(sA, ra[0]);
+        store_tile<B_KC, T>(sB, rb[0]);
+#pragma unroll
+        for (int d = 1; d < D; ++d)
+            if (d < nk) request(d, ra[d % D], rb[d % D]);      // slots 1 .. D-1 hold K-steps 1 .. D-1
     }
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        const bool more = (kt + 1 < nk);
-        if (more) {
-            const int k0 = kbeg + (kt + 1) * BK;
-            const bool kfull = (k0 + BK <= p.K);
-            load_tile<A_KC, T>(p.A, p.lda, i0, p.M, k0, p.K, fullA && kfull, ra);
-            load_tile<B_KC, T>(p.B, p.ldb, j0, p.N, k0, p.K, fullB && kfull, rb);
-        }
-        const double* cA = sA + buf * TILE_DOUBLES;
-        const double* cB = sB + buf * TILE_DOUBLES;
+    for (int kt0 = 0; kt0 < nk; kt0 += D) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            double a[NT], b[NT];
+        for (int d = 0; d < D; ++d) {
+            const int kt = kt0 + d;                            // ring slot of K-step j is j % D; kt % D == d here
+            if (kt < nk) {
+                const int buf = kt & 1;
+                const bool more = (kt + 1 < nk);
+                if (kt + D < nk) request(kt + D, ra[d], rb[d]);     // slot d held K-step kt: already in LDS
+                const double* cA = sA + buf * TILE_DOUBLES;
+                const double* cB = sB + buf * TILE_DOUBLES;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int mi = wm * WT + t * 16 + l15;
-                const int ni = wn * WT + t * 16 + l15;
-                const int kq = kk * 4 + l4;
-                a[t] = A_KC ? cA[mi * LDS_K + kq] : cA[kq * LDS_MN + mi];
-                b[t] = B_KC ? cB[ni * LDS_K + kq] : cB[kq * LDS_MN + ni];
+                for (int kk = 0; kk < 4; ++kk) {
+                    double a[NT], b[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int mi = wm * WT + t * 16 + l15;
+                        const int ni = wn * WT + t * 16 + l15;
+                        const int kq = kk * 4 + l4;
+                        a[t] = A_KC ? cA[mi * LDS_K + kq] : cA[kq * LDS_MN + mi];
+                        b[t] = B_KC ? cB[ni * LDS_K + kq] : cB[kq * LDS_MN + ni];
+                    }
+#pragma unroll
+                    for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+                        for (int tm = 0; tm < NT; ++tm)
+                            acc[tn][tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[tn], a[tm], acc[tn][tm], 0, 0, 0);
+                }
+                if (more) {   // (writing LDS ahead of this step's MFMAs was measured: 20 % slower)
+                    store_tile<A_KC, T>(sA + (buf ^ 1) * TILE_DOUBLES, ra[(d + 1) % D]);
+                    store_tile<B_KC, T>(sB + (buf ^ 1) * TILE_DOUBLES, rb[(d + 1) % D]);
+                }
+                __syncthreads();
             }
-#pragma unroll
-            for (int tn = 0; tn < NT; ++tn)
-#pragma unroll
-                for (int tm = 0; tm < NT; ++tm)
-                    acc[tn][tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[tn], a[tm], acc[tn][tm], 0, 0, 0);
         }
-        if (more) {
-            store_tile<A_KC, T>(sA + (buf ^ 1) * TILE_DOUBLES, ra);
-            store_tile<B_KC, T>(sB + (buf ^ 1) * TILE_DOUBLES, rb);
-        }
-        __syncthreads();
     }
 }
 
@@ -241,6 +257,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int bi, con
     int kbeg = 0, kend = p.K;
     if (p.tri == TRI_A_LOWER) kend = min(p.K, bi * T + T);
     if (p.tri == TRI_A_UPPER) kbeg = ((bi * T) / BK) * BK;
+    if (p.ksplit > 0) { kbeg = (int)blockIdx.y * p.ksplit; kend = min(p.K, kbeg + p.ksplit); }
     d4 acc[NT][NT];
 #pragma unroll
     for (int a = 0; a < NT; ++a)
@@ -336,7 +353,7 @@ int launch_gemm_update_potf2(hipStream_t stream, int64_t M, int64_t N, int64_t K
     p.mblocks = (p.M + T - 1) / T;
     p.nblocks = (p.N + T - 1) / T;
     p.fz_A = C; p.fz_lda = ldc; p.fz_nb = nb_next; p.fz_k0 = k0_next; p.fz_info = info;
-    p.sA = p.sB = p.sC = 0;
+    p.sA = p.sB = p.sC = 0; p.ksplit = 0;
     const int64_t grid = (int64_t)p.nblocks * p.mblocks - (int64_t)p.nblocks * (p.nblocks - 1) / 2;
     hipLaunchKernelGGL((gemm_f64_kernel<false, true, 64, 0, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
     GP_HIP(hipGetLastError());
@@ -381,10 +398,48 @@ int launch_gemm_batched(hipStream_t stream, bool ta, bool tb, int tri, int64_t M
     p.alpha = alpha; p.beta = beta; p.tri = tri;
     p.mblocks = p.nblocks = 0;
     p.fz_A = nullptr; p.fz_lda = 0; p.fz_nb = 0; p.fz_k0 = 0; p.fz_info = nullptr;
-    p.sA = strideA; p.sB = strideB; p.sC = strideC;
+    p.sA = strideA; p.sB = strideB; p.sC = strideC; p.ksplit = 0;
     p.fastA = (((uintptr_t)A & 15) == 0) && (lda % 2 == 0) && (strideA % 2 == 0);
     p.fastB = (((uintptr_t)B & 15) == 0) && (ldb % 2 == 0) && (strideB % 2 == 0);
     return launch_gemm_t<64>(stream, ta, tb, p, batch);
+}
+
+// Split-K: C_q = alpha * op(A)[:, Kq] op(B)[Kq, :] for the `nsplit` consecutive K ranges Kq, written to
+// Cpart + q * strideC.  For products whose M x N is far too small to fill the chip but whose K is long
+// (draw_fstar's B^T [B | W], 64 x 1088 x 8192); the caller adds the parts in a fixed order.
+__global__ __launch_bounds__(256) void sum_parts_kernel(const double* __restrict__ part, int64_t count, int64_t stride,
+                                                        int nparts, double* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    double acc = 0.0;
+    for (int q = 0; q < nparts; ++q) acc += part[i + q * stride];
+    out[i] = acc;
+}
+
+int launch_gemm_splitk(hipStream_t stream, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double alpha,
+                       const double* A, int64_t lda, const double* B, int64_t ldb, double* Cpart, int64_t ldc,
+                       int64_t strideC, int nsplit, double* Cout)
+{
+    if (M <= 0 || N <= 0 || nsplit <= 0) return 0;
+    GemmParams p;
+    p.A = A; p.B = B; p.C = Cpart;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.M = (int)M; p.N = (int)N; p.K = (int)K;
+    p.alpha = alpha; p.beta = 0.0; p.tri = TRI_NONE;
+    p.mblocks = p.nblocks = 0;
+    p.fz_A = nullptr; p.fz_lda = 0; p.fz_nb = 0; p.fz_k0 = 0; p.fz_info = nullptr;
+    p.sA = p.sB = 0; p.sC = strideC;
+    p.ksplit = (int)((((K + nsplit - 1) / nsplit) + BK - 1) / BK * BK);
+    const int parts = (int)((K + p.ksplit - 1) / p.ksplit);
+    p.fastA = (((uintptr_t)A & 15) == 0) && (lda % 2 == 0);
+    p.fastB = (((uintptr_t)B & 15) == 0) && (ldb % 2 == 0);
+    GP_TRY(launch_gemm_t<64>(stream, ta, tb, p, parts));
+    const int64_t count = ldc * N;      // parts are dense ldc x N images
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, Cpart, count,
+                       strideC, parts, Cout);
+    GP_HIP(hipGetLastError());
+    return 0;
 }
 
 int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri, int64_t M,
@@ -400,7 +455,7 @@ int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri,
     p.alpha = alpha; p.beta = beta; p.tri = tri;
     p.mblocks = p.nblocks = 0;
     p.fz_A = nullptr; p.fz_lda = 0; p.fz_nb = 0; p.fz_k0 = 0; p.fz_info = nullptr;
-    p.sA = p.sB = p.sC = 0;
+    p.sA = p.sB = p.sC = 0; p.ksplit = 0;
     p.fastA = (((uintptr_t)A & 15) == 0) && (lda % 2 == 0);
     p.fastB = (((uintptr_t)B & 15) == 0) && (ldb % 2 == 0);
     if (tri == TRI_SYRK_LOWER_TRAILING) {

@@ -19,6 +19,11 @@ int launch_gemm_batched(hipStream_t stream, bool ta, bool tb, int tri, int64_t M
                         const double* A, int64_t lda, int64_t strideA, const double* B, int64_t ldb, int64_t strideB,
                         double beta, double* C, int64_t ldc, int64_t strideC, int batch);
 
+// split-K product for tiny M x N with long K; parts land in Cpart (+ q * strideC, each ldc x N), their sum in Cout
+int launch_gemm_splitk(hipStream_t stream, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double alpha,
+                       const double* A, int64_t lda, const double* B, int64_t ldb, double* Cpart, int64_t ldc,
+                       int64_t strideC, int nsplit, double* Cout);
+
 // se_kernel.hip
 int launch_se_kernel(hipStream_t stream, const double* x1, int64_t n1, const double* x2, int64_t n2,
                      double* out, int64_t ld, double jitter);
@@ -61,6 +66,7 @@ int launch_ll_bar(hipStream_t stream, const double* f, const double* y, const do
 
 // fstar.hip
 int launch_colnorm_s(hipStream_t stream, const double* tmp, int64_t n, int64_t N, int64_t ld, double* s);
+int launch_lowrank_s(hipStream_t stream, const double* V, int64_t N, int r, const double* G, int64_t ldg, double* s);
 struct FstarEpiArgs {
     const double* mean; const double* mu_star; const double* s; double* out;
     int64_t N, m;

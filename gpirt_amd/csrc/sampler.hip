@@ -23,6 +23,8 @@ using namespace gpirt;
 
 namespace {
 
+constexpr int KSPLIT = 16;       // K ranges of the split-K product B^T [B | W] in the low-rank draw_fstar
+
 enum { ST_DRAW_F = 0, ST_FSTAR, ST_THETA_GEMM, ST_THETA_SAMPLE, ST_BETA, ST_FACTOR, ST_COUNT };
 const char* const kStageNames[ST_COUNT] = { "draw_f", "draw_fstar", "theta_gemm", "theta_sample",
                                             "draw_beta", "factor" };
@@ -40,6 +42,9 @@ struct gpirt_sampler_s {
            *fstar = nullptr, *L = nullptr, *tstar = nullptr, *kstar = nullptr, *rhs = nullptr,
            *mean = nullptr, *s = nullptr, *Gpm = nullptr, *logpost = nullptr, *irf_sum = nullptr,
            *pm = nullptr, *ps = nullptr, *step = nullptr;
+    // low-rank K* (opt.reserved[2] = r > 0): Chebyshev nodes, interpolation matrix V (N x r), split-K parts
+    int kr = 0;
+    double *knodes = nullptr, *kV = nullptr, *kparts = nullptr, *kP = nullptr;
     int *ess_k = nullptr, *flags = nullptr;    // flags[0] = err, flags[1] = degenerate theta count
     int *fstar_off = nullptr;                  // R-stream replay: consumption offsets of draw_fstar
     int *h_flags = nullptr;                    // pinned
@@ -163,6 +168,28 @@ int do_draw_fstar(gpirt_sampler_s* s, uint32_t iter)
     double* tmp = s->rhs;                    // n x N : L^-1 kstar
     double* W = s->rhs + (size_t)n * N;      // n x m : L^-1 f, then L^-T L^-1 f
     const bool fused = s->opt.fstar_fused != 0;
+    if (s->kr > 0) {
+        // K*^T = U V^T exactly (see gpirt_sampler_create), so with B = L^-1 U and W = L^-1 f:
+        //   ||L^-1 k*_j||^2 = v_j^T (B^T B) v_j          (src/draw-fstar.cpp:19-20)
+        //   k*_j^T S^-1 f   = v_j^T (B^T W)              (:24-25, fused form)
+        // r + m right-hand sides instead of N + m, and the N x n x m product shrinks to r x n x (r + m).
+        const int r = s->kr;
+        double* Bu = s->rhs;                                  // n x r
+        double* Wl = s->rhs + (size_t)n * r;                  // n x m
+        GP_TRY(launch_se_kernel(st, s->theta, n, s->knodes, r, Bu, n, 0.0));
+        GP_HIP(hipMemcpyAsync(Wl, s->f, sizeof(double) * (size_t)n * m, hipMemcpyDeviceToDevice, st));
+        GP_TRY(launch_trsm_lower(h, st, s->L, n, n, s->rhs, r + m, n, false));
+        GP_TRY(launch_gemm_splitk(st, true, false, r, r + m, n, 1.0, Bu, n, s->rhs, n, s->kparts, r,
+                                  (int64_t)r * (r + m), KSPLIT, s->kP));        // [B^T B | B^T W], r x (r + m)
+        GP_TRY(launch_lowrank_s(st, s->kV, N, r, s->kP, r, s->s));
+        GP_TRY(launch_gemm(h, st, false, false, TRI_NONE, N, m, r, 1.0, s->kV, N, s->kP + (size_t)r * r, r, 0.0,
+                           s->mean, N));
+        FstarEpiArgs a{};
+        a.mean = s->mean; a.mu_star = s->mu_star; a.s = s->s; a.out = s->fstar; a.N = N; a.m = m;
+        a.seed = s->opt.seed; a.iter = iter; a.item0 = (uint32_t)s->opt.item0; a.err = s->flags;
+        if (stream_mode(s)) { a.U = s->U; a.pos = s->pos; a.cap = s->U_cap; a.off_scratch = s->fstar_off; }
+        return launch_fstar_epilogue(st, a);
+    }
     if (fused) {
         GP_TRY(launch_se_kernel(st, s->theta, n, s->tstar, N, tmp, n, 0.0));                   // :17
     } else {
@@ -267,6 +294,16 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
     GP_A(s->pm, 2 * m);      GP_A(s->ps, 2 * m);       GP_A(s->step, 2 * m);
     GP_A(s->ess_k, m);       GP_A(s->flags, 4);
     if (!s->opt.fstar_fused) GP_A(s->kstar, n * N + 2);
+    s->kr = s->opt.reserved[2];
+    if (s->kr != 0) {
+        if (!s->opt.fstar_fused || s->kr < 16 || s->kr > 128 || (s->kr % 16) != 0) {
+            set_error("kstar_rank must be a multiple of 16 in 16..128 and needs fstar_fused");
+            gpirt_sampler_destroy(s);
+            return GPIRT_E_ARG;
+        }
+        GP_A(s->knodes, s->kr); GP_A(s->kV, N * s->kr);
+        GP_A(s->kparts, (size_t)KSPLIT * s->kr * (s->kr + m)); GP_A(s->kP, (size_t)s->kr * (s->kr + m));
+    }
     if (stream_mode(s)) {
         // consumption of draw_beta per item: rnorm (2 unless step == 0) + runif (1), twice
         std::vector<uint64_t> off((size_t)m);
@@ -309,6 +346,42 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
     hipMemcpyAsync(s->ps, h_ps, sizeof(double) * (size_t)(2 * m), hipMemcpyHostToDevice, st);
     hipMemcpyAsync(s->step, h_step, sizeof(double) * (size_t)(2 * m), hipMemcpyHostToDevice, st);
     hipMemcpyAsync(s->tstar, ts.data(), sizeof(double) * (size_t)N, hipMemcpyHostToDevice, st);
+    std::vector<double> nodes, V;
+    if (s->kr > 0) {
+        // Chebyshev interpolation of  t -> exp(-(theta - t)^2 / 2)  on the grid's interval [-5, 5]:
+        //   K(theta_i, t_j) = sum_k K(theta_i, c_k) V[j][k],  V = barycentric Lagrange basis at the r first-kind
+        // Chebyshev points c_k, evaluated at the 1001 grid points in long double.  The integrand is entire and
+        // the interval is 10 length-scales wide: r = 56 already reaches 1.3e-15 max-abs error (Lebesgue
+        // constant 3.6), so K*^T (n x 1001) is replaced by its exact rank-r factorisation U V^T, U = K(theta, c).
+        const int r = s->kr;
+        const long double pi = 3.141592653589793238462643383279502884L;
+        std::vector<long double> c((size_t)r), w((size_t)r);
+        nodes.resize((size_t)r); V.assign((size_t)(N * r), 0.0);
+        for (int k = 0; k < r; ++k) {
+            const long double a = (2 * k + 1) * pi / (2 * r);
+            c[(size_t)k] = 5.0L * cosl(a);
+            w[(size_t)k] = ((k & 1) ? -1.0L : 1.0L) * sinl(a);
+            nodes[(size_t)k] = (double)c[(size_t)k];
+        }
+        for (int64_t j = 0; j < N; ++j) {
+            const long double t = (long double)ts[(size_t)j];
+            int hit = -1;
+            long double den = 0.0L;
+            for (int k = 0; k < r; ++k) {
+                const long double d = t - (long double)nodes[(size_t)k];     // the nodes as the device will see them
+                if (d == 0.0L) { hit = k; break; }
+                den += w[(size_t)k] / d;
+            }
+            for (int k = 0; k < r; ++k) {
+                long double v;
+                if (hit >= 0) v = (k == hit) ? 1.0L : 0.0L;
+                else v = (w[(size_t)k] / (t - (long double)nodes[(size_t)k])) / den;
+                V[(size_t)(j + k * N)] = (double)v;
+            }
+        }
+        hipMemcpyAsync(s->knodes, nodes.data(), sizeof(double) * (size_t)r, hipMemcpyHostToDevice, st);
+        hipMemcpyAsync(s->kV, V.data(), sizeof(double) * (size_t)(N * r), hipMemcpyHostToDevice, st);
+    }
     hipMemsetAsync(s->L, 0, sizeof(double) * (size_t)(n * n), st);         // strict upper stays zero
     hipMemsetAsync(s->irf_sum, 0, sizeof(double) * (size_t)(N * m), st);   // :42
     hipMemsetAsync(s->flags, 0, 4 * sizeof(int), st);

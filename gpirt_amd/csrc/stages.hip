@@ -43,6 +43,29 @@ __global__ __launch_bounds__(256) void colnorm_s_kernel(const double* __restrict
     if (threadIdx.x == 0) s[blockIdx.x] = 1.0 - sqrt(q);
 }
 
+// s_j = 1 - sqrt(v_j^T G v_j), G = B^T B (r x r, ld ldg): draw-fstar.cpp:20 through the rank-r form of K*
+__global__ __launch_bounds__(128) void lowrank_s_kernel(const double* __restrict__ V, int64_t N, int r,
+                                                        const double* __restrict__ G, int64_t ldg, double* __restrict__ s)
+{
+    __shared__ double sv[128], red[128];
+    const int64_t j = blockIdx.x;
+    const int k = threadIdx.x;
+    sv[k] = (k < r) ? V[j + (int64_t)k * N] : 0.0;
+    __syncthreads();
+    double t = 0.0;
+    if (k < r) {
+        for (int l = 0; l < r; ++l) t += G[k + (int64_t)l * ldg] * sv[l];
+        t *= sv[k];
+    }
+    red[k] = t;
+    __syncthreads();
+    for (int w = 64; w > 0; w >>= 1) {
+        if (k < w) red[k] += red[k + w];
+        __syncthreads();
+    }
+    if (k == 0) s[j] = 1.0 - sqrt(red[0]);
+}
+
 // exclusive count of RNG-consuming grid points (s_i > 0 and finite) -- R-stream replay only
 __global__ void fstar_offsets_kernel(const double* __restrict__ s, int N, int* __restrict__ off)
 {
@@ -284,6 +307,14 @@ int launch_colnorm_s(hipStream_t stream, const double* tmp, int64_t n, int64_t N
 {
     if (N <= 0) return 0;
     hipLaunchKernelGGL(colnorm_s_kernel, dim3((unsigned)N), dim3(256), 0, stream, tmp, n, ld, s);
+    GP_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_lowrank_s(hipStream_t stream, const double* V, int64_t N, int r, const double* G, int64_t ldg, double* s)
+{
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(lowrank_s_kernel, dim3((unsigned)N), dim3(128), 0, stream, V, N, r, G, ldg, s);
     GP_HIP(hipGetLastError());
     return 0;
 }

@@ -25,7 +25,8 @@ def _ptr(a):
     return a.ctypes.data_as(_dp)
 
 
-def _options(rng, seed, theta_stabilise, fstar_fused, device, item0=0, m_total=0, kernel_fp32=False) -> Options:
+def _options(rng, seed, theta_stabilise, fstar_fused, device, item0=0, m_total=0, kernel_fp32=False,
+             kstar_rank=0) -> Options:
     o = _lib.default_options()
     o.rng_kind = RNG_RSTREAM if rng == "reference" else RNG_ITEM
     o.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
@@ -35,6 +36,7 @@ def _options(rng, seed, theta_stabilise, fstar_fused, device, item0=0, m_total=0
     o.item0 = int(item0)
     o.m_total = int(m_total)
     o.reserved[1] = int(bool(kernel_fp32))
+    o.reserved[2] = int(kstar_rank)
     return o
 
 
@@ -102,7 +104,7 @@ class Sampler:
 
     def __init__(self, handle, y, theta_init, beta_prior_means=None, beta_prior_sds=None,
                  beta_proposal_sds=None, *, rng="item", seed=1, rstream=None, theta_stabilise=True,
-                 fstar_fused=False, item0=0, m_total=0, kernel_fp32=False):
+                 fstar_fused=False, item0=0, m_total=0, kernel_fp32=False, kstar_rank=0):
         self.lib = _lib.load()
         self.handle = handle
         y = _f64(y)
@@ -113,7 +115,7 @@ class Sampler:
         st = _f64(np.full((2, m), 0.1) if beta_proposal_sds is None else beta_proposal_sds)
         theta0 = np.ascontiguousarray(theta_init, dtype=np.float64)
         self.rs = rstream
-        o = _options(rng, seed, theta_stabilise, fstar_fused, handle.device, item0, m_total, kernel_fp32)
+        o = _options(rng, seed, theta_stabilise, fstar_fused, handle.device, item0, m_total, kernel_fp32, kstar_rank)
         s = C.c_void_p()
         check(self.lib.gpirt_sampler_create(C.byref(s), handle.ptr, _ptr(y), self.n, m, _ptr(theta0), _ptr(pm),
                                             _ptr(ps), _ptr(st), C.byref(o),

@@ -169,7 +169,11 @@ typedef struct gpirt_options {
     int64_t  item0;
     int64_t  m_total;
     int      reserved[8];     /* reserved[1] = 1: build K(theta,theta) with single-precision exp() before the
-                               * fp64 factorisation (BASELINE config C5; parity then only statistical) */
+                               * fp64 factorisation (BASELINE config C5; parity then only statistical)
+                               * reserved[2] = r (16..128, multiple of 16; needs fstar_fused): draw_fstar works
+                               * with the rank-r Chebyshev factorisation K(theta, theta*) = K(theta, c) V^T of
+                               * src/draw-fstar.cpp:17 (exact to 1.3e-15 for r >= 56) and solves r + m
+                               * right-hand sides instead of 1001 + m; 0 = every grid column is solved */
 } gpirt_options;
 
 void gpirt_default_options(gpirt_options* o);
