@@ -116,6 +116,7 @@ int gpirt_destroy(gpirt_handle_t h)
     if (h->h_info) hipHostFree(h->h_info);
     if (h->d_work) hipFree(h->d_work);
     if (h->d_prog) hipFree(h->d_prog);
+    if (h->d_splitk) hipFree(h->d_splitk);
     if (h->d_trsm_winv) hipFree(h->d_trsm_winv);
     if (h->d_trsm_tmp) hipFree(h->d_trsm_tmp);
     for (auto& pp : h->prof.pending) { hipEventDestroy(pp.e0); hipEventDestroy(pp.e1); }

@@ -72,11 +72,16 @@ struct gpirt_handle_s {
     size_t       prog_cap = 0;
     unsigned long long prog_seq = 0;
     long long*   panel_trace = nullptr;   // debug stamps (micro-benchmarks only)
+    // gemm_f64.hip: parts of automatically split-K products
+    double*      d_splitk = nullptr;
+    size_t       splitk_bytes = 0;
     // trsm.hip: inverses of L's 256 x 256 diagonal blocks (rebuilt per call) + a 256 x nrhs product buffer
     double*      d_trsm_winv = nullptr;
     size_t       trsm_winv_bytes = 0;
     double*      d_trsm_tmp = nullptr;
     size_t       trsm_tmp_bytes = 0;
+    const double* trsm_winv_L = nullptr;  // the factor the inverses belong to (launch_trsm_lower, reuse_inverses)
+    int64_t      trsm_winv_n = 0, trsm_winv_ld = 0;
 };
 
 namespace gpirt {

@@ -407,19 +407,23 @@ int launch_gemm_batched(hipStream_t stream, bool ta, bool tb, int tri, int64_t M
 // Split-K: C_q = alpha * op(A)[:, Kq] op(B)[Kq, :] for the `nsplit` consecutive K ranges Kq, written to
 // Cpart + q * strideC.  For products whose M x N is far too small to fill the chip but whose K is long
 // (draw_fstar's B^T [B | W], 64 x 1088 x 8192); the caller adds the parts in a fixed order.
-__global__ __launch_bounds__(256) void sum_parts_kernel(const double* __restrict__ part, int64_t count, int64_t stride,
-                                                        int nparts, double* __restrict__ out)
+// out (ldo) = beta * out + sum of the parts (each M x N, leading dimension M), added in index order
+__global__ __launch_bounds__(256) void sum_parts_kernel(const double* __restrict__ part, int64_t M, int64_t N,
+                                                        int64_t stride, int nparts, double beta, double* __restrict__ out,
+                                                        int64_t ldo)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= count) return;
+    if (i >= M * N) return;
     double acc = 0.0;
     for (int q = 0; q < nparts; ++q) acc += part[i + q * stride];
-    out[i] = acc;
+    const int64_t r = i % M, c = i / M;
+    double* o = out + r + c * ldo;
+    *o = (beta != 0.0) ? beta * (*o) + acc : acc;
 }
 
 int launch_gemm_splitk(hipStream_t stream, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double alpha,
                        const double* A, int64_t lda, const double* B, int64_t ldb, double* Cpart, int64_t ldc,
-                       int64_t strideC, int nsplit, double* Cout)
+                       int64_t strideC, int nsplit, double* Cout, int64_t ldout, double beta_out)
 {
     if (M <= 0 || N <= 0 || nsplit <= 0) return 0;
     GemmParams p;
@@ -435,9 +439,9 @@ int launch_gemm_splitk(hipStream_t stream, bool ta, bool tb, int64_t M, int64_t 
     p.fastA = (((uintptr_t)A & 15) == 0) && (lda % 2 == 0);
     p.fastB = (((uintptr_t)B & 15) == 0) && (ldb % 2 == 0);
     GP_TRY(launch_gemm_t<64>(stream, ta, tb, p, parts));
-    const int64_t count = ldc * N;      // parts are dense ldc x N images
-    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, Cpart, count,
-                       strideC, parts, Cout);
+    if (ldc != M) { set_error("split-K parts must be dense (ldc == M)"); return GPIRT_E_ARG; }
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, stream, Cpart, M, N,
+                       strideC, parts, beta_out, Cout, ldout);
     GP_HIP(hipGetLastError());
     return 0;
 }
@@ -446,7 +450,6 @@ int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri,
                 int64_t N, int64_t K, double alpha, const double* A, int64_t lda, const double* B,
                 int64_t ldb, double beta, double* C, int64_t ldc)
 {
-    (void)h;
     if (M <= 0 || N <= 0) return 0;
     GemmParams p;
     p.A = A; p.B = B; p.C = C;
@@ -471,6 +474,29 @@ int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri,
     if (tri == TRI_A_LOWER || tri == TRI_A_UPPER) blocks128 *= 2;     // paired: one work-group per CU suffices
     static const int t128_min = getenv("GPIRT_T128_MIN") ? atoi(getenv("GPIRT_T128_MIN")) : 448;
     if (blocks128 >= t128_min) return launch_gemm_t<128>(stream, ta, tb, p);
+    // Few tiles and a long K: a lone work-group per CU runs its K loop at LDS / barrier latency (~1.1 us per
+    // K-step against 0.43 us of MFMA), so the K range is cut into `split` parts computed side by side and added
+    // in a fixed order (GPIRT_SPLITK=2 switches it off).  Main stream only: the parts share one workspace.
+    static const bool splitk_on = !(getenv("GPIRT_SPLITK") && atoi(getenv("GPIRT_SPLITK")) == 2);
+    const int64_t tiles64 = ((M + 63) / 64) * ((N + 63) / 64);
+    if (splitk_on && h != nullptr && stream == h->stream && tri == TRI_NONE && tiles64 <= 320 && K >= 256) {
+        int64_t split = 640 / tiles64;
+        if (split > K / 64) split = K / 64;
+        if (split > 16) split = 16;
+        if (split >= 2) {
+            const size_t need = (size_t)split * (size_t)M * (size_t)N * sizeof(double);
+            if (h->splitk_bytes < need) {
+                GP_HIP(hipStreamSynchronize(stream));
+                if (h->side) GP_HIP(hipStreamSynchronize(h->side));
+                if (h->d_splitk) GP_HIP(hipFree(h->d_splitk));
+                h->d_splitk = nullptr; h->splitk_bytes = 0;
+                GP_HIP(hipMalloc(&h->d_splitk, need));
+                h->splitk_bytes = need;
+            }
+            return launch_gemm_splitk(stream, ta, tb, M, N, K, alpha, A, lda, B, ldb, h->d_splitk, M, M * N, (int)split,
+                                      C, ldc, beta);
+        }
+    }
     return launch_gemm_t<64>(stream, ta, tb, p);
 }
 

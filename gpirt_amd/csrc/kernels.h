@@ -19,10 +19,11 @@ int launch_gemm_batched(hipStream_t stream, bool ta, bool tb, int tri, int64_t M
                         const double* A, int64_t lda, int64_t strideA, const double* B, int64_t ldb, int64_t strideB,
                         double beta, double* C, int64_t ldc, int64_t strideC, int batch);
 
-// split-K product for tiny M x N with long K; parts land in Cpart (+ q * strideC, each ldc x N), their sum in Cout
+// split-K product for small M x N with long K: parts land in Cpart (+ q * strideC, each M x N with ldc == M),
+// then Cout (ldout) = beta_out * Cout + their sum
 int launch_gemm_splitk(hipStream_t stream, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double alpha,
                        const double* A, int64_t lda, const double* B, int64_t ldb, double* Cpart, int64_t ldc,
-                       int64_t strideC, int nsplit, double* Cout);
+                       int64_t strideC, int nsplit, double* Cout, int64_t ldout, double beta_out);
 
 // se_kernel.hip
 int launch_se_kernel(hipStream_t stream, const double* x1, int64_t n1, const double* x2, int64_t n2,
@@ -40,7 +41,7 @@ int launch_panel_ll(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, 
 
 // trsm.hip
 int launch_trsm_lower(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t n, int64_t ldl,
-                      double* B, int64_t nrhs, int64_t ldb, bool trans);
+                      double* B, int64_t nrhs, int64_t ldb, bool trans, bool reuse_inverses = false);
 
 // rng.hip
 int launch_item_uniforms(hipStream_t stream, uint64_t seed, uint32_t iter, uint32_t stage,

@@ -169,21 +169,24 @@ int do_draw_fstar(gpirt_sampler_s* s, uint32_t iter)
     double* W = s->rhs + (size_t)n * N;      // n x m : L^-1 f, then L^-T L^-1 f
     const bool fused = s->opt.fstar_fused != 0;
     if (s->kr > 0) {
-        // K*^T = U V^T exactly (see gpirt_sampler_create), so with B = L^-1 U and W = L^-1 f:
+        // K*^T = U V^T exactly (see gpirt_sampler_create), so with B = L^-1 U and C = L^-T B = S^-1 U:
         //   ||L^-1 k*_j||^2 = v_j^T (B^T B) v_j          (src/draw-fstar.cpp:19-20)
-        //   k*_j^T S^-1 f   = v_j^T (B^T W)              (:24-25, fused form)
-        // r + m right-hand sides instead of N + m, and the N x n x m product shrinks to r x n x (r + m).
+        //   k*_j^T S^-1 f   = v_j^T (C^T f)              (:7, :24-25)
+        // Two solves with r right-hand sides each (forward, then transposed with the same block inverses)
+        // replace the solve with N + m; the N x n x m product shrinks to r x n x (r + m).
         const int r = s->kr;
-        double* Bu = s->rhs;                                  // n x r
-        double* Wl = s->rhs + (size_t)n * r;                  // n x m
+        double* Bu = s->rhs;                                  // n x r : U, then B
+        double* Cu = s->rhs + (size_t)n * r;                  // n x r : B, then C
         GP_TRY(launch_se_kernel(st, s->theta, n, s->knodes, r, Bu, n, 0.0));
-        GP_HIP(hipMemcpyAsync(Wl, s->f, sizeof(double) * (size_t)n * m, hipMemcpyDeviceToDevice, st));
-        GP_TRY(launch_trsm_lower(h, st, s->L, n, n, s->rhs, r + m, n, false));
-        GP_TRY(launch_gemm_splitk(st, true, false, r, r + m, n, 1.0, Bu, n, s->rhs, n, s->kparts, r,
-                                  (int64_t)r * (r + m), KSPLIT, s->kP));        // [B^T B | B^T W], r x (r + m)
-        GP_TRY(launch_lowrank_s(st, s->kV, N, r, s->kP, r, s->s));
-        GP_TRY(launch_gemm(h, st, false, false, TRI_NONE, N, m, r, 1.0, s->kV, N, s->kP + (size_t)r * r, r, 0.0,
-                           s->mean, N));
+        GP_TRY(launch_trsm_lower(h, st, s->L, n, n, Bu, r, n, false));
+        GP_HIP(hipMemcpyAsync(Cu, Bu, sizeof(double) * (size_t)n * r, hipMemcpyDeviceToDevice, st));
+        GP_TRY(launch_trsm_lower(h, st, s->L, n, n, Cu, r, n, true, true));
+        double* G = s->kP;                                    // r x r
+        double* Q = s->kP + (size_t)r * r;                    // r x m
+        GP_TRY(launch_gemm_splitk(st, true, false, r, r, n, 1.0, Bu, n, Bu, n, s->kparts, r, (int64_t)r * r, KSPLIT, G, r, 0.0));
+        GP_TRY(launch_gemm_splitk(st, true, false, r, m, n, 1.0, Cu, n, s->f, n, s->kparts, r, (int64_t)r * m, KSPLIT, Q, r, 0.0));
+        GP_TRY(launch_lowrank_s(st, s->kV, N, r, G, r, s->s));
+        GP_TRY(launch_gemm(h, st, false, false, TRI_NONE, N, m, r, 1.0, s->kV, N, Q, r, 0.0, s->mean, N));
         FstarEpiArgs a{};
         a.mean = s->mean; a.mu_star = s->mu_star; a.s = s->s; a.out = s->fstar; a.N = N; a.m = m;
         a.seed = s->opt.seed; a.iter = iter; a.item0 = (uint32_t)s->opt.item0; a.err = s->flags;

@@ -251,8 +251,11 @@ int trsm_rec(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t ldl,
             else if (odd && r0 == npair * NI) W = winv + npair * (int64_t)(NI * NI);
         }
         if (W) {
-            GP_TRY(launch_gemm(h, stream, false, false, TRI_A_LOWER, len, nrhs, len, 1.0, W, NI, B + r0, ldb, 0.0,
-                               h->d_trsm_tmp, len));
+            // few right-hand sides: W_b as a dense operand (its upper-right quarter is zero), so the product is
+            // eligible for the split-K path of launch_gemm; many: skip the structural zeros instead
+            // (the transposed solve multiplies by W_b^T: the same stored block, read transposed)
+            GP_TRY(launch_gemm(h, stream, trans, false, (trans || nrhs <= 1280) ? TRI_NONE : TRI_A_LOWER, len, nrhs, len,
+                               1.0, W, NI, B + r0, ldb, 0.0, h->d_trsm_tmp, len));
             hipLaunchKernelGGL(copy_back_kernel, dim3((unsigned)nrhs), dim3(256), 0, stream, h->d_trsm_tmp, (int)len,
                                B + r0, ldb, nrhs);
             return 0;
@@ -289,19 +292,21 @@ int trsm_rec(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t ldl,
                            L + mid + r0 * ldl, ldl, B + r0, ldb, 1.0, B + mid, ldb));
         GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, mid, r1, winv, npair, odd));
     } else {
-        GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, mid, r1));
+        GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, mid, r1, winv, npair, odd));
         // B[r0:mid, :] -= L[mid:r1, r0:mid]^T * B[mid:r1, :]
         GP_TRY(launch_gemm(h, stream, true, false, TRI_NONE, mid - r0, nrhs, r1 - mid, -1.0,
                            L + mid + r0 * ldl, ldl, B + mid, ldb, 1.0, B + r0, ldb));
-        GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, r0, mid));
+        GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, r0, mid, winv, npair, odd));
     }
     return 0;
 }
 
 }  // namespace
 
+// reuse_inverses: the block inverses built by the previous call on this handle are still those of L (same L,
+// n and ldl, not modified since) -- the sampler's second solve of a draw_fstar skips rebuilding them.
 int launch_trsm_lower(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t n, int64_t ldl,
-                      double* B, int64_t nrhs, int64_t ldb, bool trans)
+                      double* B, int64_t nrhs, int64_t ldb, bool trans, bool reuse_inverses)
 {
     if (n <= 0 || nrhs <= 0) return 0;
     // GPIRT_TRSM_INV=2 keeps every leaf a substitution
@@ -309,7 +314,10 @@ int launch_trsm_lower(gpirt_handle_t h, hipStream_t stream, const double* L, int
     const double* winv = nullptr;
     const int64_t nfull = n / NL4, npair = nfull / 2;
     const bool odd = (nfull & 1) != 0;
-    if (use_inv && !trans && nfull >= 2 && nrhs >= 256) {
+    const bool have = reuse_inverses && h->trsm_winv_L == L && h->trsm_winv_n == n && h->trsm_winv_ld == ldl;
+    if (use_inv && nfull >= 2 && nrhs >= 64 && have) {
+        winv = h->d_trsm_winv;
+    } else if (use_inv && nfull >= 2 && nrhs >= 64) {
         // 1. the full 256 x 256 diagonal blocks: ONE batched launch of the fused leaf on identity right-hand
         //    sides (4 work-groups per block, ~50 us for the whole matrix), written straight into the diagonal
         //    quarters of the 512 x 512 slots;
@@ -323,6 +331,7 @@ int launch_trsm_lower(gpirt_handle_t h, hipStream_t stream, const double* L, int
                 if (h->d_trsm_winv) GP_HIP(hipFree(h->d_trsm_winv));
                 h->d_trsm_winv = nullptr; h->trsm_winv_bytes = 0;
                 GP_HIP(hipMalloc(&h->d_trsm_winv, wbytes));
+                GP_HIP(hipMemsetAsync(h->d_trsm_winv, 0, wbytes, stream));   // upper-right quarters stay zero for good
                 h->trsm_winv_bytes = wbytes;
             }
             if (h->trsm_tmp_bytes < tbytes) {
@@ -347,6 +356,18 @@ int launch_trsm_lower(gpirt_handle_t h, hipStream_t stream, const double* L, int
                                        (int64_t)NL4 * NL4, 0.0, W + NL4, NI, (int64_t)NI * NI, (int)npair));
         }
         winv = W;
+        h->trsm_winv_L = L; h->trsm_winv_n = n; h->trsm_winv_ld = ldl;
+    }
+    if (winv) {
+        // the leaf products park a 512 x nrhs block in the workspace
+        const size_t tb = (size_t)NI * (size_t)nrhs * sizeof(double);
+        if (h->trsm_tmp_bytes < tb) {
+            GP_HIP(hipStreamSynchronize(stream));
+            if (h->d_trsm_tmp) GP_HIP(hipFree(h->d_trsm_tmp));
+            h->d_trsm_tmp = nullptr; h->trsm_tmp_bytes = 0;
+            GP_HIP(hipMalloc(&h->d_trsm_tmp, tb));
+            h->trsm_tmp_bytes = tb;
+        }
     }
     GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, 0, n, winv, npair, odd));
     GP_HIP(hipGetLastError());
