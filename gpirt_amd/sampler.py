@@ -42,7 +42,8 @@ def _options(rng, seed, theta_stabilise, fstar_fused, device, item0=0, m_total=0
 
 def gpirtMCMC(data, sample_iterations, burn_iterations, vote_codes=None, beta_prior_means=None,
               beta_prior_sds=None, beta_proposal_sds=None, theta_init=None, *, rng="reference",
-              seed=1, rstream=None, theta_stabilise=False, fstar_fused=False, device=None, progress=False):
+              seed=1, rstream=None, theta_stabilise=False, fstar_fused=False, kstar_rank=0, device=None,
+              progress=False):
     """Drop-in for the reference's gpirtMCMC() (R/gpirtMCMC.R:85-105) on one MI355X.
 
     Positional arguments, defaults and the returned dict (theta (S+1) x n, beta 2 x m x (S+1),
@@ -51,6 +52,8 @@ def gpirtMCMC(data, sample_iterations, burn_iterations, vote_codes=None, beta_pr
       rng="reference": replay R's Mersenne-Twister stream (`rstream`, or RStream(seed), stands in
                        for R's .Random.seed); draw-for-draw comparable with the reference;
       rng="item":      counter-based per-item sub-streams keyed by `seed` (batched, shardable).
+    fstar_fused / kstar_rank: algebraically identical, cheaper forms of draw_fstar:
+      the mean as (L^-1 k*)^T (L^-1 f), and K(theta, theta*) through its exact rank-r Chebyshev factorisation.
     """
     from .ops import RStream
 
@@ -81,7 +84,7 @@ def gpirtMCMC(data, sample_iterations, burn_iterations, vote_codes=None, beta_pr
     be = np.empty((2, m, S + 1), order="F")
     ff = np.empty((n, m, S + 1), order="F")
     irf = np.empty((NGRID, m), order="F")
-    o = _options(rng, seed, theta_stabilise, fstar_fused, device)
+    o = _options(rng, seed, theta_stabilise, fstar_fused, device, kstar_rank=kstar_rank)
 
     def _tick(ctx, it, total):                                       # src/gpirtMCMC.cpp:64-66
         if progress:

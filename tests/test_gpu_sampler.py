@@ -36,14 +36,16 @@ def test_mcmc_reference_rng_matches_oracle(handle, oracle, n, m, S, B):
     assert mti == mti_ref and np.array_equal(mt, mt_ref)
 
 
-@pytest.mark.parametrize("n,m,S,B,fused", [(64, 9, 3, 1, False), (200, 20, 2, 2, False), (200, 20, 2, 2, True)])
-def test_mcmc_item_rng_matches_oracle(handle, oracle, n, m, S, B, fused):
+# rank 64: draw_fstar through the Chebyshev factorisation of K(theta, theta*) -- the oracle solves all 1001 columns
+@pytest.mark.parametrize("n,m,S,B,fused,rank", [(64, 9, 3, 1, False, 0), (200, 20, 2, 2, False, 0), (200, 20, 2, 2, True, 0),
+                                                (200, 20, 2, 2, True, 64), (600, 12, 2, 1, True, 64)])
+def test_mcmc_item_rng_matches_oracle(handle, oracle, n, m, S, B, fused, rank):
     from gpirt_amd import gpirtMCMC
     from gpirt_amd.synthetic import make_responses
     y, th0 = make_responses(n, m, seed=3 + n)
     seed = 4242
     res = gpirtMCMC(y, S, B, vote_codes=dict(yea=[1], nay=[-1], missing=[None]), theta_init=th0, rng="item",
-                    seed=seed, theta_stabilise=True, fstar_fused=fused)
+                    seed=seed, theta_stabilise=True, fstar_fused=fused, kstar_rank=rank)
     ref = oracle.gpirt_mcmc(oracle.ItemStream(seed), y, th0, S, B, theta_stabilise=True, fstar_fused=fused)
     _check(res, ref)
 
@@ -236,3 +238,24 @@ def test_two_runs_are_bit_identical(handle):
         for xa, xb in zip(sa, sb):
             assert np.isfinite(xa).all()
             assert np.array_equal(xa, xb), f"iteration {it} differs between two identical runs"
+
+
+@pytest.mark.parametrize("n,m,rank", [(1339, 40, 64), (2048, 24, 48)])
+def test_lowrank_kstar_equals_full_solve(handle, n, m, rank):
+    """draw_fstar with K(theta, theta*) = K(theta, c) V^T (r Chebyshev nodes, two solves with r right-hand sides,
+    forward and transposed, through the 512-block inverses) against the solve of all 1001 + m columns: same
+    theta, f, L and RNG keys, so f* must agree to rounding (1e-9 is the tolerance of every f* comparison)."""
+    from gpirt_amd.sampler import Sampler
+    from gpirt_amd.synthetic import make_responses
+    y, th0 = make_responses(n, m, seed=3)
+    out = []
+    for r in (0, rank):
+        s = Sampler(handle, y, th0, rng="item", seed=5, theta_stabilise=True, fstar_fused=True, kstar_rank=r)
+        s.init()
+        for _ in range(2):
+            s.step()
+        s.check()
+        out.append(np.array(s.get("fstar")))
+        s.close()
+    assert np.isfinite(out[0]).all() and np.isfinite(out[1]).all()
+    assert np.abs(out[0] - out[1]).max() <= 1e-9
