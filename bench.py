@@ -182,6 +182,26 @@ def main():
     ss.engine.check()
     stage_ms = {k: round(v, 3) for k, v in stage_ms.items()}
 
+    # the same iteration with draw_fstar as the reference words it (every one of the 1001 grid columns solved,
+    # then L^-T L^-1 f per item): reported beside `value`, never as it
+    alt = None
+    if world == 1 and args.fstar == "lowrank":
+        alt = {}
+        for form, kw in (("fused", dict(fstar_fused=True)), ("double_solve", dict(fstar_fused=False))):
+            s2 = Sampler(handle, y, theta0, rng="item", seed=20240, theta_stabilise=True, **kw)
+            s2.init()
+            for _ in range(max(1, args.warmup)):
+                s2.step()
+            s2.check()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                s2.step()
+            torch.cuda.synchronize()
+            alt[form] = round(args.steps / (time.perf_counter() - t1), 3)
+            s2.check()
+            s2.close()
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         achieved = (tr_flops / (tr_ms * 1e-3) / 1e12) if tr_ms > 0 else 0.0
@@ -213,6 +233,12 @@ def main():
                 "parallelism": f"items sharded over {world} GPU(s); chol {args.chol}; all-reduce of the "
                                f"{1001}x{n} partial log-posterior per iteration" if world > 1 else "single GPU",
                 "stage_ms": stage_ms,
+                "draw_fstar_form": {"double_solve": "src/draw-fstar.cpp:17-25 as written",
+                                    "fused": "mean = (L^-1 k*)^T (L^-1 f)",
+                                    "lowrank": "fused + K(theta, theta*) = K(theta, c) V^T, 64 Chebyshev nodes (max-abs error "
+                                               "1.3e-15; f* within 2e-11 of the full solve): 2 x 64 right-hand sides instead "
+                                               "of 1001 + m"}[args.fstar],
+                "iterations_per_s_other_forms": alt,
                 "item_sharded_stages": ["draw_f", "draw_fstar", "theta_gemm", "draw_beta"],
             },
             "roofline": {
