@@ -93,6 +93,8 @@ def main():
                     help="double_solve: src/draw-fstar.cpp as written; fused: mean = (L^-1 k*)^T (L^-1 f); lowrank: fused + the "
                          "rank-64 Chebyshev factorisation of K(theta, theta*) (exact to 1e-15), 64 + m right-hand sides")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-forms", action="store_true",
+                    help="skip the extra (untimed for `value`) runs with the other draw_fstar forms")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--single-device", action="store_true",
@@ -185,7 +187,7 @@ def main():
     # the same iteration with draw_fstar as the reference words it (every one of the 1001 grid columns solved,
     # then L^-T L^-1 f per item): reported beside `value`, never as it
     alt = None
-    if world == 1 and args.fstar == "lowrank":
+    if world == 1 and args.fstar == "lowrank" and not args.no_alt_forms:
         alt = {}
         for form, kw in (("fused", dict(fstar_fused=True)), ("double_solve", dict(fstar_fused=False))):
             s2 = Sampler(handle, y, theta0, rng="item", seed=20240, theta_stabilise=True, **kw)

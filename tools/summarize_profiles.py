@@ -31,7 +31,7 @@ json.dump({"kernel": KERNEL + ", false> (potrf trailing update)", "hbm_bytes_per
           open("profiles/trailing_traffic.json", "w"), indent=1)
 rl = bench["roofline"]
 with open(f"profiles/{tag}_summary.md", "w") as f:
-    f.write(f"# Round {tag[1:]} profiles (MI355X, ROCm 7.2, `python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline` under rocprofv3)\n\n")
+    f.write(f"# Round {tag[1:]} profiles (MI355X, ROCm 7.2, `python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alt-forms` under rocprofv3)\n\n")
     f.write(f"Raw per-kernel statistics: `profiles/{tag}_kernel_stats.csv` (rocprofv3 --kernel-trace --stats); collected by `tools/collect_profiles.sh`, summarised by `tools/summarize_profiles.py`.\n\n")
     f.write(f"bench.py line of the profiled run: {bench['value']:.2f} it/s, {bench['ms_per_step']:.2f} ms/step, stages {bench['config']['stage_ms']}\n\n")
     f.write(f"## Dominant kernel: potrf trailing update `{KERNEL}, false>` (fp64 MFMA syrk, lower blocks)\n\n")
