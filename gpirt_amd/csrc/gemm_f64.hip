@@ -446,6 +446,21 @@ int launch_gemm_splitk(hipStream_t stream, bool ta, bool tb, int64_t M, int64_t 
     return 0;
 }
 
+// number of K ranges launch_gemm will cut this product into (1 = not split).  A split product reads A and B
+// completely before its result is written by the summing kernel, so C may then alias an operand.
+int gemm_split_count(gpirt_handle_t h, hipStream_t stream, int tri, int64_t M, int64_t N, int64_t K)
+{
+    static const bool splitk_on = !(getenv("GPIRT_SPLITK") && atoi(getenv("GPIRT_SPLITK")) == 2);
+    static const int t128_min = getenv("GPIRT_T128_MIN") ? atoi(getenv("GPIRT_T128_MIN")) : 448;
+    const int64_t tiles64 = ((M + 63) / 64) * ((N + 63) / 64);
+    if (!splitk_on || h == nullptr || stream != h->stream || tri != TRI_NONE || tiles64 > 320 || K < 256) return 1;
+    if (((M + 127) / 128) * ((N + 127) / 128) >= t128_min) return 1;
+    int64_t split = 640 / tiles64;
+    if (split > K / 64) split = K / 64;
+    if (split > 16) split = 16;
+    return split >= 2 ? (int)split : 1;
+}
+
 int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri, int64_t M,
                 int64_t N, int64_t K, double alpha, const double* A, int64_t lda, const double* B,
                 int64_t ldb, double beta, double* C, int64_t ldc)
@@ -477,12 +492,8 @@ int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri,
     // Few tiles and a long K: a lone work-group per CU runs its K loop at LDS / barrier latency (~1.1 us per
     // K-step against 0.43 us of MFMA), so the K range is cut into `split` parts computed side by side and added
     // in a fixed order (GPIRT_SPLITK=2 switches it off).  Main stream only: the parts share one workspace.
-    static const bool splitk_on = !(getenv("GPIRT_SPLITK") && atoi(getenv("GPIRT_SPLITK")) == 2);
-    const int64_t tiles64 = ((M + 63) / 64) * ((N + 63) / 64);
-    if (splitk_on && h != nullptr && stream == h->stream && tri == TRI_NONE && tiles64 <= 320 && K >= 256) {
-        int64_t split = 640 / tiles64;
-        if (split > K / 64) split = K / 64;
-        if (split > 16) split = 16;
+    {
+        const int split = gemm_split_count(h, stream, tri, M, N, K);
         if (split >= 2) {
             const size_t need = (size_t)split * (size_t)M * (size_t)N * sizeof(double);
             if (h->splitk_bytes < need) {
@@ -493,7 +504,7 @@ int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri,
                 GP_HIP(hipMalloc(&h->d_splitk, need));
                 h->splitk_bytes = need;
             }
-            return launch_gemm_splitk(stream, ta, tb, M, N, K, alpha, A, lda, B, ldb, h->d_splitk, M, M * N, (int)split,
+            return launch_gemm_splitk(stream, ta, tb, M, N, K, alpha, A, lda, B, ldb, h->d_splitk, M, M * N, split,
                                       C, ldc, beta);
         }
     }

@@ -19,6 +19,7 @@ int launch_gemm_batched(hipStream_t stream, bool ta, bool tb, int tri, int64_t M
                         const double* A, int64_t lda, int64_t strideA, const double* B, int64_t ldb, int64_t strideB,
                         double beta, double* C, int64_t ldc, int64_t strideC, int batch);
 
+int gemm_split_count(gpirt_handle_t h, hipStream_t stream, int tri, int64_t M, int64_t N, int64_t K);
 // split-K product for small M x N with long K: parts land in Cpart (+ q * strideC, each M x N with ldc == M),
 // then Cout (ldout) = beta_out * Cout + their sum
 int launch_gemm_splitk(hipStream_t stream, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double alpha,

@@ -254,8 +254,13 @@ int trsm_rec(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t ldl,
             // few right-hand sides: W_b as a dense operand (its upper-right quarter is zero), so the product is
             // eligible for the split-K path of launch_gemm; many: skip the structural zeros instead
             // (the transposed solve multiplies by W_b^T: the same stored block, read transposed)
-            GP_TRY(launch_gemm(h, stream, trans, false, (trans || nrhs <= 1280) ? TRI_NONE : TRI_A_LOWER, len, nrhs, len,
-                               1.0, W, NI, B + r0, ldb, 0.0, h->d_trsm_tmp, len));
+            const int tri = (trans || nrhs <= 1280) ? TRI_NONE : TRI_A_LOWER;
+            if (gemm_split_count(h, stream, tri, len, nrhs, len) >= 2) {
+                // split over K: the parts are complete before the sum is written, so it can land in B itself
+                return launch_gemm(h, stream, trans, false, tri, len, nrhs, len, 1.0, W, NI, B + r0, ldb, 0.0, B + r0, ldb);
+            }
+            GP_TRY(launch_gemm(h, stream, trans, false, tri, len, nrhs, len, 1.0, W, NI, B + r0, ldb, 0.0,
+                               h->d_trsm_tmp, len));
             hipLaunchKernelGGL(copy_back_kernel, dim3((unsigned)nrhs), dim3(256), 0, stream, h->d_trsm_tmp, (int)len,
                                B + r0, ldb, nrhs);
             return 0;
