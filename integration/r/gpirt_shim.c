@@ -55,6 +55,8 @@ SEXP _gpirt_gpirtMCMC(SEXP ySEXP, SEXP thetaSEXP, SEXP sample_iterationsSEXP, SE
     gpirt_default_options(&opt);
     opt.theta_stabilise = asLogical(GetOption1(install("gpirt.hip.theta_stabilise"))) == TRUE;
     opt.fstar_fused = asLogical(GetOption1(install("gpirt.hip.fstar_fused"))) == TRUE;
+    opt.reserved[2] = opt.fstar_fused ? asInteger(GetOption1(install("gpirt.hip.kstar_rank"))) : 0;
+    if (opt.reserved[2] == NA_INTEGER) opt.reserved[2] = 0;
 
     /* options(gpirt.hip.rng = "item") selects the batched counter-based contract; the default
      * replays R's own stream so results are draw-for-draw those of the RcppArmadillo build */
