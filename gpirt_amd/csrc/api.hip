@@ -125,6 +125,7 @@ int gpirt_destroy(gpirt_handle_t h)
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->ev_mid) hipEventDestroy(h->ev_mid);
+    if (h->ev_a) hipEventDestroy(h->ev_a);
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
     return 0;

@@ -66,7 +66,7 @@ struct gpirt_handle_s {
     gpirt::Prof  prof;
     // look-ahead Cholesky: high-priority side stream for the panel chain + fork/join events
     hipStream_t  side = nullptr;
-    hipEvent_t   ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr;
+    hipEvent_t   ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr, ev_a = nullptr;
     // persistent panel kernel (panel.hip): one progress counter per 64-row block, epoch-tagged
     unsigned long long* d_prog = nullptr;
     size_t       prog_cap = 0;
