@@ -119,6 +119,7 @@ int gpirt_destroy(gpirt_handle_t h)
     if (h->d_splitk) hipFree(h->d_splitk);
     if (h->d_trsm_winv) hipFree(h->d_trsm_winv);
     if (h->d_trsm_tmp) hipFree(h->d_trsm_tmp);
+    if (h->d_trsm_wquad) hipFree(h->d_trsm_wquad);
     for (auto& pp : h->prof.pending) { hipEventDestroy(pp.e0); hipEventDestroy(pp.e1); }
     for (auto& pp : h->prof.free_pairs) { hipEventDestroy(pp.e0); hipEventDestroy(pp.e1); }
     if (h->side) hipStreamDestroy(h->side);

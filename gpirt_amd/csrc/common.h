@@ -80,6 +80,9 @@ struct gpirt_handle_s {
     size_t       trsm_winv_bytes = 0;
     double*      d_trsm_tmp = nullptr;
     size_t       trsm_tmp_bytes = 0;
+    double*      d_trsm_wquad = nullptr;  // 1024 x 1024 inverses for thin solves (built with the 512 ones)
+    size_t       trsm_wquad_bytes = 0;
+    int64_t      trsm_quads = 0;
     const double* trsm_winv_L = nullptr;  // the factor the inverses belong to (launch_trsm_lower, reuse_inverses)
     int64_t      trsm_winv_n = 0, trsm_winv_ld = 0;
 };

@@ -231,6 +231,23 @@ __global__ __launch_bounds__(256) void copy_back_kernel(const double* __restrict
 }
 
 constexpr int NI = 512;         // edge of the explicitly inverted diagonal blocks
+constexpr int NQ = 1024;        // ... and of the larger ones built from pairs of them for thin solves
+
+// W1024 slot q (ld 1024): the two 512 x 512 inverses on the diagonal, zeros above; the lower-left quarter is
+// written afterwards by the batched products  -W_b (L_ba W_a)
+__global__ __launch_bounds__(256) void assemble_quad_kernel(const double* __restrict__ W512, double* __restrict__ W1024)
+{
+    const int64_t q = blockIdx.y;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;          // over 1024 x 512: column c, rows of one half
+    const int c = (int)(idx / NQ), r = (int)(idx % NQ);
+    if (c >= NQ) return;
+    double* dst = W1024 + q * (int64_t)NQ * NQ + r + (int64_t)c * NQ;
+    if (c < NI) {
+        if (r < NI) *dst = W512[(2 * q) * (int64_t)NI * NI + r + (int64_t)c * NI];
+    } else {
+        *dst = (r < NI) ? 0.0 : W512[(2 * q + 1) * (int64_t)NI * NI + (r - NI) + (int64_t)(c - NI) * NI];
+    }
+}
 
 // Forward solves with winv != nullptr: the inverses of L's diagonal blocks, 512 x 512 block b at
 // winv + b * 512 * 512 (ld 512, lower triangle; npair of them), plus -- when an odd full 256-row block is left
@@ -239,9 +256,15 @@ constexpr int NI = 512;         // edge of the explicitly inverted diagonal bloc
 // nrhs / 64 of them with a GEMM in between; 256-row leaves use the diagonal quarters the same way.
 int trsm_rec(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t ldl, double* B,
              int64_t nrhs, int64_t ldb, bool trans, int64_t r0, int64_t r1, const double* winv = nullptr,
-             int64_t npair = 0, bool odd = false)
+             int64_t npair = 0, bool odd = false, const double* wquad = nullptr, int64_t nquad = 0)
 {
     const int64_t len = r1 - r0;
+    if (wquad && len == NQ && (r0 % NQ) == 0 && r0 / NQ < nquad &&
+        gemm_split_count(h, stream, TRI_NONE, len, nrhs, len) >= 2) {
+        // thin solve: one product with the 1024 x 1024 inverse (split over K, so it may land in B itself)
+        return launch_gemm(h, stream, trans, false, TRI_NONE, len, nrhs, len, 1.0, wquad + (r0 / NQ) * (int64_t)NQ * NQ, NQ,
+                           B + r0, ldb, 0.0, B + r0, ldb);
+    }
     if (winv) {
         const double* W = nullptr;
         if (len == NI && (r0 % NI) == 0 && r0 / NI < npair) {
@@ -291,17 +314,17 @@ int trsm_rec(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t ldl,
     if (half >= len) half = ((len / 2 + NL - 1) / NL) * NL;
     const int64_t mid = r0 + half;
     if (!trans) {
-        GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, r0, mid, winv, npair, odd));
+        GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, r0, mid, winv, npair, odd, wquad, nquad));
         // B[mid:r1, :] -= L[mid:r1, r0:mid] * B[r0:mid, :]
         GP_TRY(launch_gemm(h, stream, false, false, TRI_NONE, r1 - mid, nrhs, mid - r0, -1.0,
                            L + mid + r0 * ldl, ldl, B + r0, ldb, 1.0, B + mid, ldb));
-        GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, mid, r1, winv, npair, odd));
+        GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, mid, r1, winv, npair, odd, wquad, nquad));
     } else {
-        GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, mid, r1, winv, npair, odd));
+        GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, mid, r1, winv, npair, odd, wquad, nquad));
         // B[r0:mid, :] -= L[mid:r1, r0:mid]^T * B[mid:r1, :]
         GP_TRY(launch_gemm(h, stream, true, false, TRI_NONE, mid - r0, nrhs, r1 - mid, -1.0,
                            L + mid + r0 * ldl, ldl, B + mid, ldb, 1.0, B + r0, ldb));
-        GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, r0, mid, winv, npair, odd));
+        GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, r0, mid, winv, npair, odd, wquad, nquad));
     }
     return 0;
 }
@@ -319,6 +342,7 @@ int launch_trsm_lower(gpirt_handle_t h, hipStream_t stream, const double* L, int
     const double* winv = nullptr;
     const int64_t nfull = n / NL4, npair = nfull / 2;
     const bool odd = (nfull & 1) != 0;
+    const bool thin = nrhs <= 256;
     const bool have = reuse_inverses && h->trsm_winv_L == L && h->trsm_winv_n == n && h->trsm_winv_ld == ldl;
     if (use_inv && nfull >= 2 && nrhs >= 64 && have) {
         winv = h->d_trsm_winv;
@@ -330,6 +354,7 @@ int launch_trsm_lower(gpirt_handle_t h, hipStream_t stream, const double* L, int
         const size_t wbytes = (size_t)(npair + 1) * NI * NI * sizeof(double);
         size_t tbytes = (size_t)NI * (size_t)nrhs * sizeof(double);
         if (tbytes < (size_t)npair * NL4 * NL4 * sizeof(double)) tbytes = (size_t)npair * NL4 * NL4 * sizeof(double);
+        if (thin && tbytes < (size_t)(npair / 2) * NI * NI * sizeof(double)) tbytes = (size_t)(npair / 2) * NI * NI * sizeof(double);
         if (h->trsm_winv_bytes < wbytes || h->trsm_tmp_bytes < tbytes) {
             GP_HIP(hipStreamSynchronize(stream));
             if (h->trsm_winv_bytes < wbytes) {
@@ -362,6 +387,30 @@ int launch_trsm_lower(gpirt_handle_t h, hipStream_t stream, const double* L, int
         }
         winv = W;
         h->trsm_winv_L = L; h->trsm_winv_n = n; h->trsm_winv_ld = ldl;
+        h->trsm_quads = 0;
+        if (thin && npair >= 2) {
+            // 3. thin solves (few right-hand sides are launch-bound, not flop-bound): pairs of 512-blocks are
+            //    merged into 1024 x 1024 inverses, halving the number of leaves and dropping a recursion level
+            const int64_t nq = npair / 2;
+            const size_t qbytes = (size_t)nq * NQ * NQ * sizeof(double);
+            if (h->trsm_wquad_bytes < qbytes) {
+                GP_HIP(hipStreamSynchronize(stream));
+                if (h->d_trsm_wquad) GP_HIP(hipFree(h->d_trsm_wquad));
+                h->d_trsm_wquad = nullptr; h->trsm_wquad_bytes = 0;
+                GP_HIP(hipMalloc(&h->d_trsm_wquad, qbytes));
+                h->trsm_wquad_bytes = qbytes;
+            }
+            double* Wq = h->d_trsm_wquad;
+            hipLaunchKernelGGL(assemble_quad_kernel, dim3((unsigned)((int64_t)NQ * NQ / 256), (unsigned)nq), dim3(256), 0, stream, W, Wq);
+            // T = L_ba W_a (512^3, W_a lower triangular), then the lower-left quarter  -W_b T
+            GP_TRY(launch_gemm_batched(stream, false, false, TRI_NONE, NI, NI, NI, 1.0,
+                                       L + NI, ldl, (int64_t)NQ * (ldl + 1), Wq, NQ, (int64_t)NQ * NQ,
+                                       0.0, h->d_trsm_tmp, NI, (int64_t)NI * NI, (int)nq));
+            GP_TRY(launch_gemm_batched(stream, false, false, TRI_A_LOWER, NI, NI, NI, -1.0,
+                                       Wq + (int64_t)NI * (NQ + 1), NQ, (int64_t)NQ * NQ, h->d_trsm_tmp, NI,
+                                       (int64_t)NI * NI, 0.0, Wq + NI, NQ, (int64_t)NQ * NQ, (int)nq));
+            h->trsm_quads = nq;
+        }
     }
     if (winv) {
         // the leaf products park a 512 x nrhs block in the workspace
@@ -374,7 +423,9 @@ int launch_trsm_lower(gpirt_handle_t h, hipStream_t stream, const double* L, int
             h->trsm_tmp_bytes = tb;
         }
     }
-    GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, 0, n, winv, npair, odd));
+    const bool use_quads = winv && thin && h->trsm_quads > 0;
+    GP_TRY(trsm_rec(h, stream, L, ldl, B, nrhs, ldb, trans, 0, n, winv, npair, odd, use_quads ? h->d_trsm_wquad : nullptr,
+                    use_quads ? h->trsm_quads : 0));
     GP_HIP(hipGetLastError());
     return 0;
 }
