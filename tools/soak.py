@@ -14,7 +14,7 @@ iters = int(sys.argv[3]) if len(sys.argv) > 3 else 150
 y, th0 = make_responses(n, m, seed=7)
 h = Handle()
 def run():
-    s = Sampler(h, y, th0, rng="item", seed=11, theta_stabilise=True, fstar_fused=True)
+    s = Sampler(h, y, th0, rng="item", seed=11, theta_stabilise=True, fstar_fused=True, kstar_rank=64)
     s.init()
     digs = []
     for it in range(iters):
