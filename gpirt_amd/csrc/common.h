@@ -192,4 +192,16 @@ __device__ inline double block_sum_256(double v, double* smem /* >= 4 doubles */
     return r;
 }
 
+// the same for 512-thread blocks (8 wavefronts)
+__device__ inline double block_sum_512(double v, double* smem /* >= 8 doubles */)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) smem[w] = v;
+    __syncthreads();
+    return ((smem[0] + smem[1]) + (smem[2] + smem[3])) + ((smem[4] + smem[5]) + (smem[6] + smem[7]));
+}
+
 }  // namespace gpirt

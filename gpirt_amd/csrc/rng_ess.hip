@@ -132,13 +132,14 @@ __global__ __launch_bounds__(256) void ess_kernel(EssArgs a)
     }
 }
 
-// Register-resident variant for n <= 256 * EPT: each lane keeps its EPT entries of f, nu, mu and y in
+// Register-resident variant for n <= NTH * EPT: each lane keeps its EPT entries of f, nu, mu and y in
 // registers, so the (2 + k) likelihood passes of a column touch memory once; arithmetic is identical
 // to ess_kernel (same per-element expression, same reduction tree).
-template <int EPT>
-__global__ __launch_bounds__(256) void ess_kernel_reg(EssArgs a)
+template <int EPT, int NTH>
+__global__ __launch_bounds__(NTH) void ess_kernel_reg(EssArgs a)
 {
-    __shared__ double red[4];
+    __shared__ double red[8];
+    auto block_sum = [&](double v) { return NTH == 256 ? block_sum_256(v, red) : block_sum_512(v, red); };
     const int64_t j = blockIdx.x;
     const int64_t n = a.n;
     double* fj = a.f + j * n;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void ess_kernel_reg(EssArgs a)
     double F[EPT], V[EPT], M[EPT], Y[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
-        const int64_t i = threadIdx.x + 256 * e;
+        const int64_t i = threadIdx.x + NTH * e;
         const bool in = i < n;
         F[e] = in ? fj[i] : 0.0;
         V[e] = in ? nj[i] : 0.0;
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256) void ess_kernel_reg(EssArgs a)
 #pragma unroll
     for (int e = 0; e < EPT; ++e)
         if (Y[e] == Y[e]) acc += ll_term(Y[e] * (F[e] + M[e]));
-    const double ll0 = -block_sum_256(acc, red);
+    const double ll0 = -block_sum(acc);
     const double u = item_uniform(a.seed, a.iter, GPIRT_ST_F_ESS, item, uidx++);
     const double log_y = ll0 + log(u);                                     // draw-f.cpp:28-29
     double eps_min = 0.0, eps_max = GP_2PI;
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256) void ess_kernel_reg(EssArgs a)
 #pragma unroll
         for (int e = 0; e < EPT; ++e)
             if (Y[e] == Y[e]) acc += ll_term(Y[e] * ((F[e] * c + V[e] * s) + M[e]));   // :43
-        const double llp = -block_sum_256(acc, red);
+        const double llp = -block_sum(acc);
         if (llp > log_y) break;                                            // :45-47
         if (llp != llp) { bad = true; break; }
         if (eps < 0.0) eps_min = eps; else eps_max = eps;                  // :50-55
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256) void ess_kernel_reg(EssArgs a)
     }
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
-        const int64_t i = threadIdx.x + 256 * e;
+        const int64_t i = threadIdx.x + NTH * e;
         if (i < n) fj[i] = F[e] * c + V[e] * s;
     }
     if (threadIdx.x == 0) {
@@ -240,9 +241,9 @@ int launch_ess(hipStream_t stream, const EssArgs& a)
 {
     if (a.m <= 0) return 0;
     if (a.U == nullptr && a.n <= 256 * 8)
-        hipLaunchKernelGGL(ess_kernel_reg<8>, dim3((unsigned)a.m), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((ess_kernel_reg<8, 256>), dim3((unsigned)a.m), dim3(256), 0, stream, a);
     else if (a.U == nullptr && a.n <= 256 * 32)
-        hipLaunchKernelGGL(ess_kernel_reg<32>, dim3((unsigned)a.m), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((ess_kernel_reg<16, 512>), dim3((unsigned)a.m), dim3(512), 0, stream, a);
     else
         hipLaunchKernelGGL(ess_kernel, dim3((unsigned)a.m), dim3(256), 0, stream, a);
     GP_HIP(hipGetLastError());
