@@ -24,6 +24,7 @@
 #include "potf2.h"
 
 #include <stdlib.h>
+#include <type_traits>
 
 namespace gpirt {
 
@@ -202,6 +203,167 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, const int bi,
     }
 }
 
+// ---- interior tiles: the branch-free main loop ------------------------------------------------------------
+// Every operand tile of the K range is complete and 16-byte aligned: loads are `uniform base + per-lane
+// 32-bit offset` (the base advances on the scalar unit), nothing is predicated, and the K-step is ordered so
+// that the wave's non-MFMA work sits in the shadow of its own MFMAs:
+//   fragments of sub-step 0  ->  tile kt+1: registers -> LDS (other buffer)  ->  tile kt+2: global -> registers
+//   ->  64 MFMAs  ->  barrier.
+// One register stage gives a full K-step of lead because it is emptied at the START of the step.
+template <bool KCONTIG, int T>
+__device__ __forceinline__ uint32_t fast_lane_offset(int64_t ld)
+{
+    const int t = threadIdx.x;
+    constexpr int TPC = T / 2;
+    return KCONTIG ? (uint32_t)((((t & 7) * 2) + (int64_t)(t >> 3) * ld) * 8)
+                   : (uint32_t)((((t % TPC) * 2) + (int64_t)(t / TPC) * ld) * 8);
+}
+template <bool KCONTIG, int T>
+__device__ __forceinline__ void load_tile_fast(const double* __restrict__ G, int64_t ld, uint32_t voff,
+                                               double2 (&reg)[Cfg<T>::PASSES])
+{
+    constexpr int CPP = 256 / (T / 2);
+#pragma unroll
+    for (int pass = 0; pass < Cfg<T>::PASSES; ++pass) {
+        const double* base = G + (int64_t)((KCONTIG ? 32 : CPP) * pass) * ld;     // uniform
+        typedef double d2v __attribute__((ext_vector_type(2)));
+        const d2v v = *reinterpret_cast<const d2v*>(reinterpret_cast<const char*>(base) + voff);
+        reg[pass].x = v.x; reg[pass].y = v.y;
+    }
+}
+
+template <bool KCONTIG, int T>
+__device__ __forceinline__ void load_pass_fast(const double* __restrict__ G, int64_t ld, uint32_t voff, double2& reg,
+                                               const int pass)
+{
+    constexpr int CPP = 256 / (T / 2);
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    const double* base = G + (int64_t)((KCONTIG ? 32 : CPP) * pass) * ld;     // uniform
+    const d2v v = *reinterpret_cast<const d2v*>(reinterpret_cast<const char*>(base) + voff);
+    reg.x = v.x; reg.y = v.y;
+}
+template <bool KCONTIG, int T>
+__device__ __forceinline__ void store_pass(double* __restrict__ s, const double2& reg, const int pass)
+{
+    const int t = threadIdx.x;
+    constexpr int TPC = T / 2, CPP = 256 / TPC, LDS_MN = Cfg<T>::LDS_MN;
+    if (!KCONTIG) *reinterpret_cast<double2*>(&s[((t / TPC) + CPP * pass) * LDS_MN + (t % TPC) * 2]) = reg;
+    else          *reinterpret_cast<double2*>(&s[((t >> 3) + 32 * pass) * LDS_K + (t & 7) * 2]) = reg;
+}
+
+template <bool TA, bool TB, int T>
+__device__ __forceinline__ void gemm_mainloop_fast(const GemmParams& p, const int bi, const int bj, double* smem,
+                                                   const int kbeg, const int nk, d4 (&acc)[Cfg<T>::NT][Cfg<T>::NT])
+{
+    constexpr int LDS_MN = Cfg<T>::LDS_MN, TILE_DOUBLES = Cfg<T>::TILE, NT = Cfg<T>::NT;
+    constexpr int WT = T / 2;
+    constexpr bool A_KC = TA, B_KC = !TB;
+    double* sA = smem;
+    double* sB = smem + 2 * TILE_DOUBLES;
+    const int i0 = bi * T, j0 = bj * T;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    const double* gA = A_KC ? p.A + kbeg + (int64_t)i0 * p.lda : p.A + i0 + (int64_t)kbeg * p.lda;
+    const double* gB = B_KC ? p.B + kbeg + (int64_t)j0 * p.ldb : p.B + j0 + (int64_t)kbeg * p.ldb;
+    const int64_t stepA = A_KC ? (int64_t)BK : (int64_t)BK * p.lda;
+    const int64_t stepB = B_KC ? (int64_t)BK : (int64_t)BK * p.ldb;
+    const uint32_t voffA = fast_lane_offset<A_KC, T>(p.lda);
+    const uint32_t voffB = fast_lane_offset<B_KC, T>(p.ldb);
+    // fragment read offsets (doubles) of this lane inside a tile image, sub-step 0, MFMA tile 0
+    const int fa = A_KC ? (wm * WT + l15) * LDS_K + l4 : l4 * LDS_MN + wm * WT + l15;
+    const int fb = B_KC ? (wn * WT + l15) * LDS_K + l4 : l4 * LDS_MN + wn * WT + l15;
+    constexpr int FA_T = A_KC ? 16 * LDS_K : 16, FA_K = A_KC ? 4 : 4 * LDS_MN;
+    constexpr int FB_T = B_KC ? 16 * LDS_K : 16, FB_K = B_KC ? 4 : 4 * LDS_MN;
+
+    double2 ra[Cfg<T>::PASSES], rb[Cfg<T>::PASSES];
+    load_tile_fast<A_KC, T>(gA, p.lda, voffA, ra);
+    load_tile_fast<B_KC, T>(gB, p.ldb, voffB, rb);
+    gA += stepA; gB += stepB;
+    store_tile<A_KC, T>(sA, ra);
+    store_tile<B_KC, T>(sB, rb);
+    if (nk > 1) {
+        load_tile_fast<A_KC, T>(gA, p.lda, voffA, ra);
+        load_tile_fast<B_KC, T>(gB, p.ldb, voffB, rb);
+        gA += stepA; gB += stepB;
+    }
+    __syncthreads();
+
+    // One K-step, written in issue order with scheduling fences (SB) so the compiler keeps it:
+    //   fragments of sub-step 0                                         (4 LDS reads)
+    //   the 16 MFMAs of the PREVIOUS step's sub-step 3 (fragments were read before the barrier), one memory
+    //     instruction behind each: 8 LDS writes (tile kt+1 -> other buffer), then 8 global loads (tile kt+2)
+    //   sub-steps 0, 1, 2: fragments of the next sub-step, then 16 MFMAs
+    //   barrier                                                          (sub-step 3 is issued after it)
+    // so the LDS latency after the barrier, the LDS writes and the global loads all sit behind MFMAs of the same
+    // wave.  FIRST: no previous step.  STORE / LOAD: tile kt+1 / kt+2 exist.
+    double a3[NT], b3[NT];
+    auto mfma16 = [&](const double (&fa_)[NT], const double (&fb_)[NT], const int i) {
+        acc[i >> 2][i & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb_[i >> 2], fa_[i & 3], acc[i >> 2][i & 3], 0, 0, 0);
+    };
+    auto frags = [&](const double* cA, const double* cB, const int kk, double (&fa_)[NT], double (&fb_)[NT]) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { fa_[t] = cA[kk * FA_K + t * FA_T]; fb_[t] = cB[kk * FB_K + t * FB_T]; }
+    };
+    constexpr int P = Cfg<T>::PASSES;
+    static_assert(2 * P <= 8, "memory instructions are paired with the first MFMAs of a 16-MFMA group");
+    auto kstep = [&](const int buf, auto first, auto store_next, auto load_next) {
+        constexpr bool FIRST = decltype(first)::value, STORE = decltype(store_next)::value, LOAD = decltype(load_next)::value;
+        const double* cA = sA + buf * TILE_DOUBLES + fa;
+        const double* cB = sB + buf * TILE_DOUBLES + fb;
+        double* nA = sA + (buf ^ 1) * TILE_DOUBLES;
+        double* nB = sB + (buf ^ 1) * TILE_DOUBLES;
+        double a0[NT], b0[NT], a1[NT], b1[NT], a2[NT], b2[NT];
+        frags(cA, cB, 0, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (!FIRST) mfma16(a3, b3, i);
+            if (STORE && i < P) store_pass<A_KC, T>(nA, ra[i], i);
+            if (STORE && i >= P && i < 2 * P) store_pass<B_KC, T>(nB, rb[i - P], i - P);
+            if (LOAD && i >= 8 && i < 8 + P) load_pass_fast<A_KC, T>(gA, p.lda, voffA, ra[i - 8], i - 8);
+            if (LOAD && i >= 8 + P && i < 8 + 2 * P) load_pass_fast<B_KC, T>(gB, p.ldb, voffB, rb[i - 8 - P], i - 8 - P);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (LOAD) { gA += stepA; gB += stepB; }
+        frags(cA, cB, 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mfma16(a0, b0, i);
+        __builtin_amdgcn_sched_barrier(0);
+        frags(cA, cB, 2, a2, b2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mfma16(a1, b1, i);
+        __builtin_amdgcn_sched_barrier(0);
+        frags(cA, cB, 3, a3, b3);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mfma16(a2, b2, i);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+    // steps 0 .. nk-1; the steady-state loop is one basic block
+    if (nk >= 3) {
+        kstep(0, yes{}, yes{}, yes{});
+        int kt = 1;
+        for (; kt + 2 < nk; ++kt) kstep(kt & 1, no{}, yes{}, yes{});
+        kstep(kt & 1, no{}, yes{}, no{}); ++kt;
+        kstep(kt & 1, no{}, no{}, no{});
+    } else if (nk == 2) {
+        kstep(0, yes{}, yes{}, no{});
+        kstep(1, no{}, no{}, no{});
+    } else {
+        kstep(0, yes{}, no{}, no{});
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mfma16(a3, b3, i);
+}
+
 // C tile <- alpha * acc + beta * C (masked at the matrix edge and, for syrk, above the diagonal)
 template <int T>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const int bi, const int bj,
@@ -263,7 +425,10 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int bi, con
     for (int a = 0; a < NT; ++a)
 #pragma unroll
         for (int b = 0; b < NT; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
-    gemm_mainloop<TA, TB, T>(p, bi, bj, smem, kbeg, kend, acc);
+    const bool fast = (T == 128) && p.fastA && p.fastB && (bi * T + T <= p.M) && (bj * T + T <= p.N) && kend <= p.K &&
+                      kend > kbeg && ((kend - kbeg) % BK) == 0;
+    if (fast) gemm_mainloop_fast<TA, TB, T>(p, bi, bj, smem, kbeg, (kend - kbeg) / BK, acc);
+    else gemm_mainloop<TA, TB, T>(p, bi, bj, smem, kbeg, kend, acc);
     gemm_epilogue<T>(p, bi, bj, acc);
 }
 

@@ -23,6 +23,26 @@ __global__ __launch_bounds__(256) void kc(double* out, int iters)
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// The same with the MFMAs written as inline assembly, accumulators pinned in VGPRs: the compiler's versions above
+// shuffle accumulators between AGPRs and VGPRs around every visit (v_accvgpr moves), which is what their
+// "chain length" dependence measures.  This one is the honest ceiling for a stream of MFMAs.
+template <int NACC, int CH>
+__global__ __launch_bounds__(256) void ka(double* out, int iters)
+{
+    d4 acc[NACC];
+    for (int i = 0; i < NACC; ++i) acc[i] = d4{ 0.0, 0.0, 0.0, 0.0 };
+    double a = threadIdx.x * 1e-3, b = blockIdx.x * 1e-3;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i)
+#pragma unroll
+            for (int c = 0; c < CH; ++c) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+    }
+    double s = 0;
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 template <int NACC>
 __global__ __launch_bounds__(256) void k(double* out, int iters)
 {
@@ -74,6 +94,30 @@ int main()
         if (run(kc<16, 4>, 4, "16 acc x 4 in a row")) return 1;
         if (run(kc<16, 8>, 8, "16 acc x 8 in a row")) return 1;
         if (run(kc<16, 16>, 16, "16 acc x 16 in a row")) return 1;
+    }
+    // (c2) inline-assembly MFMAs, accumulators pinned
+    {
+        const int iters = 6000;
+        auto run3 = [&](auto kern, int grid, int nacc, int ch, const char* name) -> int {
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, d, 10);
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0, 0));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, d, iters);
+            CK(hipEventRecord(e1, 0));
+            CK(hipDeviceSynchronize());
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            const double flops = (double)grid * 4 * iters * (double)nacc * ch * 2048.0;
+            printf("asm, %s, %d work-groups: %7.2f ms: %6.1f TFLOP/s\n", name, grid, ms, flops / ms / 1e9);
+            return 0;
+        };
+        if (run3(ka<16, 1>, 256, 16, 1, "16 acc x 1")) return 1;
+        if (run3(ka<16, 4>, 256, 16, 4, "16 acc x 4")) return 1;
+        if (run3(ka<16, 16>, 256, 16, 16, "16 acc x 16")) return 1;
+        if (run3(ka<16, 1>, 512, 16, 1, "16 acc x 1")) return 1;
+        if (run3(ka<8, 1>, 512, 8, 1, " 8 acc x 1")) return 1;
+        if (run3(ka<4, 1>, 512, 4, 1, " 4 acc x 1")) return 1;
+        if (run3(ka<2, 1>, 512, 2, 1, " 2 acc x 1")) return 1;
+        if (run3(ka<1, 1>, 512, 1, 1, " 1 acc x 1")) return 1;
     }
     // (d) the same with two waves per SIMD (8 accumulators per wave, 512 work-groups)
     {
