@@ -333,14 +333,16 @@ int gpirt_draw_theta(gpirt_handle_t h, const double* d_y, const double* d_fstar,
     GP_ARG(h && d_y && d_fstar && d_theta_out && n >= 0 && m >= 0);
     const int64_t N = GPIRT_NGRID;
     // workspace: Ypm (n x 2m) | Gpm (N x 2m, padded) | logpost (N x n)
-    const size_t need = (size_t)n * 2 * m + (size_t)N * 2 * m + 2 + (size_t)N * n + 16;
+    const int64_t Np = (N + 127) / 128 * 128;     // rows of Gpm incl. padding to whole 128-row tiles
+    const size_t need = (size_t)n * 2 * m + (size_t)Np * 2 * m + 2 + (size_t)N * n + 16;
     GP_TRY(ensure_work(h, need * sizeof(double)));
     double* Ypm = h->d_work;
     double* Gpm = Ypm + (size_t)n * 2 * m;
-    double* lp = Gpm + (size_t)N * 2 * m + (((size_t)N * 2 * m) & 1);
+    double* lp = Gpm + (size_t)Np * 2 * m;
+    GP_HIP(hipMemsetAsync(Gpm, 0, sizeof(double) * (size_t)Np * 2 * m, h->stream));
     GP_TRY(launch_indicators(h->stream, d_y, n, m, Ypm));
-    GP_TRY(launch_loglik_terms(h->stream, d_fstar, N, m, Gpm));
-    GP_TRY(launch_gemm(h, h->stream, false, true, TRI_NONE, N, n, 2 * m, 1.0, Gpm, N, Ypm, n, 0.0, lp, N));
+    GP_TRY(launch_loglik_terms(h->stream, d_fstar, N, m, Gpm, Np));
+    GP_TRY(launch_gemm(h, h->stream, false, true, TRI_NONE, N, n, 2 * m, 1.0, Gpm, Np, Ypm, n, 0.0, lp, N, Np));
     if (d_degenerate) GP_HIP(hipMemsetAsync(d_degenerate, 0, sizeof(int), h->stream));
     ThetaArgs a{};
     a.logpost = lp; a.N = N; a.n = n; a.stabilise = stabilise; a.seed = seed; a.iter = iter;

@@ -41,12 +41,14 @@ template <int T> struct Cfg {
     static constexpr int NT = T / 32;                     // MFMA tiles per wave per dimension
     static constexpr int PASSES = T / 32;                 // double2 loads per thread per operand tile
     static constexpr int DEPTH = (T == 64) ? 4 : 1;       // K-steps in flight between global memory and LDS
+    static constexpr int FDEPTH = (T == 64) ? 4 : 1;      // the same for the branch-free loop of interior tiles
 };
 
 struct GemmParams {
     const double* A; const double* B; double* C;
     int64_t lda, ldb, ldc;
     int M, N, K;
+    int Mr;               // rows of op(A) that may be READ (>= M: padded operand), 0 = M
     double alpha, beta;
     int tri;
     int mblocks, nblocks;
@@ -277,91 +279,116 @@ __device__ __forceinline__ void gemm_mainloop_fast(const GemmParams& p, const in
     constexpr int FA_T = A_KC ? 16 * LDS_K : 16, FA_K = A_KC ? 4 : 4 * LDS_MN;
     constexpr int FB_T = B_KC ? 16 * LDS_K : 16, FB_K = B_KC ? 4 : 4 * LDS_MN;
 
-    double2 ra[Cfg<T>::PASSES], rb[Cfg<T>::PASSES];
-    load_tile_fast<A_KC, T>(gA, p.lda, voffA, ra);
-    load_tile_fast<B_KC, T>(gB, p.ldb, voffB, rb);
+    // Register ring of D stages between global memory and LDS: tile j waits in slot j % D.  Step kt moves tile
+    // kt+1 from its slot to the other LDS buffer and requests tile kt+1+D into the slot it just emptied, so a
+    // tile has D K-steps to arrive (D = 1 for the 128-tile: 64 MFMAs = 1.7 us per step; D = 4 for the 64-tile,
+    // whose step is 16 MFMAs).
+    constexpr int D = Cfg<T>::FDEPTH, P = Cfg<T>::PASSES, NM = NT * NT;
+    double2 ra[D][P], rb[D][P];
+    load_tile_fast<A_KC, T>(gA, p.lda, voffA, ra[0]);
+    load_tile_fast<B_KC, T>(gB, p.ldb, voffB, rb[0]);
     gA += stepA; gB += stepB;
-    store_tile<A_KC, T>(sA, ra);
-    store_tile<B_KC, T>(sB, rb);
-    if (nk > 1) {
-        load_tile_fast<A_KC, T>(gA, p.lda, voffA, ra);
-        load_tile_fast<B_KC, T>(gB, p.ldb, voffB, rb);
-        gA += stepA; gB += stepB;
-    }
+    store_tile<A_KC, T>(sA, ra[0]);
+    store_tile<B_KC, T>(sB, rb[0]);
+#pragma unroll
+    for (int j = 1; j <= D; ++j)
+        if (j < nk) {
+            load_tile_fast<A_KC, T>(gA, p.lda, voffA, ra[j % D]);
+            load_tile_fast<B_KC, T>(gB, p.ldb, voffB, rb[j % D]);
+            gA += stepA; gB += stepB;
+        }
     __syncthreads();
 
-    // One K-step, written in issue order with scheduling fences (SB) so the compiler keeps it:
-    //   fragments of sub-step 0                                         (4 LDS reads)
-    //   the 16 MFMAs of the PREVIOUS step's sub-step 3 (fragments were read before the barrier), one memory
-    //     instruction behind each: 8 LDS writes (tile kt+1 -> other buffer), then 8 global loads (tile kt+2)
-    //   sub-steps 0, 1, 2: fragments of the next sub-step, then 16 MFMAs
-    //   barrier                                                          (sub-step 3 is issued after it)
-    // so the LDS latency after the barrier, the LDS writes and the global loads all sit behind MFMAs of the same
-    // wave.  FIRST: no previous step.  STORE / LOAD: tile kt+1 / kt+2 exist.
+    // One K-step, written in issue order with scheduling fences so the compiler keeps it.  Four groups of NM
+    // MFMAs: the PREVIOUS step's sub-step 3 (its fragments were read before the barrier), then sub-steps 0, 1, 2;
+    // ahead of each group the fragments of the following sub-step are requested; behind the first 4P MFMAs sits
+    // one memory instruction each -- 2P LDS writes (tile kt+1), then 2P global loads (tile kt+1+D); barrier.
+    // So the LDS latency after the barrier, the LDS writes and the global loads all sit behind MFMAs of the same
+    // wave.  FIRST: no previous step.  STEADY: tiles kt+1 and kt+1+D exist (no conditions: one basic block).
     double a3[NT], b3[NT];
-    auto mfma16 = [&](const double (&fa_)[NT], const double (&fb_)[NT], const int i) {
-        acc[i >> 2][i & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb_[i >> 2], fa_[i & 3], acc[i >> 2][i & 3], 0, 0, 0);
+    auto mfma = [&](const double (&fa_)[NT], const double (&fb_)[NT], const int i) {
+        acc[i / NT][i % NT] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb_[i / NT], fa_[i % NT], acc[i / NT][i % NT], 0, 0, 0);
     };
     auto frags = [&](const double* cA, const double* cB, const int kk, double (&fa_)[NT], double (&fb_)[NT]) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) { fa_[t] = cA[kk * FA_K + t * FA_T]; fb_[t] = cB[kk * FB_K + t * FB_T]; }
     };
-    constexpr int P = Cfg<T>::PASSES;
-    static_assert(2 * P <= 8, "memory instructions are paired with the first MFMAs of a 16-MFMA group");
-    auto kstep = [&](const int buf, auto first, auto store_next, auto load_next) {
-        constexpr bool FIRST = decltype(first)::value, STORE = decltype(store_next)::value, LOAD = decltype(load_next)::value;
+    static_assert(4 * P <= 4 * NM, "one memory instruction per MFMA of the step at most");
+    auto kstep = [&](const int buf, auto slot_c, auto first, auto steady, const bool st, const bool ld) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        constexpr bool FIRST = decltype(first)::value, STEADY = decltype(steady)::value;
         const double* cA = sA + buf * TILE_DOUBLES + fa;
         const double* cB = sB + buf * TILE_DOUBLES + fb;
         double* nA = sA + (buf ^ 1) * TILE_DOUBLES;
         double* nB = sB + (buf ^ 1) * TILE_DOUBLES;
-        double a0[NT], b0[NT], a1[NT], b1[NT], a2[NT], b2[NT];
-        frags(cA, cB, 0, a0, b0);
+        double f0a[NT], f0b[NT], f1a[NT], f1b[NT], f2a[NT], f2b[NT];
+        // memory instruction number c of the step (behind MFMA number c)
+        auto memop = [&](const int c) {
+            if (c < P)          { if (STEADY || st) store_pass<A_KC, T>(nA, ra[SLOT][c], c); }
+            else if (c < 2 * P) { if (STEADY || st) store_pass<B_KC, T>(nB, rb[SLOT][c - P], c - P); }
+            else if (c < 3 * P) { if (STEADY || ld) load_pass_fast<A_KC, T>(gA, p.lda, voffA, ra[SLOT][c - 2 * P], c - 2 * P); }
+            else if (c < 4 * P) { if (STEADY || ld) load_pass_fast<B_KC, T>(gB, p.ldb, voffB, rb[SLOT][c - 3 * P], c - 3 * P); }
+        };
+        frags(cA, cB, 0, f0a, f0b);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if (!FIRST) mfma16(a3, b3, i);
-            if (STORE && i < P) store_pass<A_KC, T>(nA, ra[i], i);
-            if (STORE && i >= P && i < 2 * P) store_pass<B_KC, T>(nB, rb[i - P], i - P);
-            if (LOAD && i >= 8 && i < 8 + P) load_pass_fast<A_KC, T>(gA, p.lda, voffA, ra[i - 8], i - 8);
-            if (LOAD && i >= 8 + P && i < 8 + 2 * P) load_pass_fast<B_KC, T>(gB, p.ldb, voffB, rb[i - 8 - P], i - 8 - P);
+        for (int i = 0; i < NM; ++i) {
+            if (!FIRST) mfma(a3, b3, i);
+            memop(i);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (LOAD) { gA += stepA; gB += stepB; }
-        frags(cA, cB, 1, a1, b1);
+        frags(cA, cB, 1, f1a, f1b);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) mfma16(a0, b0, i);
+        for (int i = 0; i < NM; ++i) {
+            mfma(f0a, f0b, i);
+            if (NM + i < 4 * P) { memop(NM + i); __builtin_amdgcn_sched_barrier(0); }
+        }
         __builtin_amdgcn_sched_barrier(0);
-        frags(cA, cB, 2, a2, b2);
+        frags(cA, cB, 2, f2a, f2b);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) mfma16(a1, b1, i);
+        for (int i = 0; i < NM; ++i) {
+            mfma(f1a, f1b, i);
+            if (2 * NM + i < 4 * P) { memop(2 * NM + i); __builtin_amdgcn_sched_barrier(0); }
+        }
         __builtin_amdgcn_sched_barrier(0);
+        if (STEADY || ld) { gA += stepA; gB += stepB; }
         frags(cA, cB, 3, a3, b3);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) mfma16(a2, b2, i);
+        for (int i = 0; i < NM; ++i) mfma(f2a, f2b, i);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
     };
     using yes = std::integral_constant<bool, true>;
     using no = std::integral_constant<bool, false>;
-    // steps 0 .. nk-1; the steady-state loop is one basic block
-    if (nk >= 3) {
-        kstep(0, yes{}, yes{}, yes{});
-        int kt = 1;
-        for (; kt + 2 < nk; ++kt) kstep(kt & 1, no{}, yes{}, yes{});
-        kstep(kt & 1, no{}, yes{}, no{}); ++kt;
-        kstep(kt & 1, no{}, no{}, no{});
-    } else if (nk == 2) {
-        kstep(0, yes{}, yes{}, no{});
-        kstep(1, no{}, no{}, no{});
-    } else {
-        kstep(0, yes{}, no{}, no{});
-    }
+    // step kt uses ring slot (kt + 1) % D; a step outside the steady state picks its instantiation by slot
+    auto edge_step = [&](const int kt) {
+        const bool st = kt + 1 < nk, ld = kt + 1 + D < nk;
+        const int slot = (kt + 1) % D;
+        if (D == 1 || slot == 0)      kstep(kt & 1, std::integral_constant<int, 0>{}, no{}, no{}, st, ld);
+        else if (slot == 1)           kstep(kt & 1, std::integral_constant<int, 1 % D>{}, no{}, no{}, st, ld);
+        else if (slot == 2)           kstep(kt & 1, std::integral_constant<int, 2 % D>{}, no{}, no{}, st, ld);
+        else                          kstep(kt & 1, std::integral_constant<int, 3 % D>{}, no{}, no{}, st, ld);
+    };
+    static_assert(D == 1 || D == 4, "edge_step enumerates the slots of a ring of 1 or 4");
+    kstep(0, std::integral_constant<int, 1 % D>{}, yes{}, no{}, 1 < nk, 1 + D < nk);
+    int kt = 1;
+    // steady state, unrolled over the ring: steps kt .. kt+D-1 all have tiles kt+1 .. kt+2D in range
+    for (; kt + 2 * D < nk; kt += D) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) mfma16(a3, b3, i);
+        for (int u = 0; u < D; ++u) {
+            if (u == 0)      kstep((kt + 0) & 1, std::integral_constant<int, (2 + 0) % D>{}, no{}, yes{}, true, true);
+            else if (u == 1) kstep((kt + 1) & 1, std::integral_constant<int, (2 + 1) % D>{}, no{}, yes{}, true, true);
+            else if (u == 2) kstep((kt + 2) & 1, std::integral_constant<int, (2 + 2) % D>{}, no{}, yes{}, true, true);
+            else             kstep((kt + 3) & 1, std::integral_constant<int, (2 + 3) % D>{}, no{}, yes{}, true, true);
+        }
+    }
+    for (; kt < nk; ++kt) edge_step(kt);
+#pragma unroll
+    for (int i = 0; i < NM; ++i) mfma(a3, b3, i);
 }
 
 // C tile <- alpha * acc + beta * C (masked at the matrix edge and, for syrk, above the diagonal)
@@ -425,7 +452,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int bi, con
     for (int a = 0; a < NT; ++a)
 #pragma unroll
         for (int b = 0; b < NT; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
-    const bool fast = (T == 128) && p.fastA && p.fastB && (bi * T + T <= p.M) && (bj * T + T <= p.N) && kend <= p.K &&
+    const bool fast = p.fastA && p.fastB && (bi * T + T <= (p.Mr > p.M ? p.Mr : p.M)) && (bj * T + T <= p.N) && kend <= p.K &&
                       kend > kbeg && ((kend - kbeg) % BK) == 0;
     if (fast) gemm_mainloop_fast<TA, TB, T>(p, bi, bj, smem, kbeg, (kend - kbeg) / BK, acc);
     else gemm_mainloop<TA, TB, T>(p, bi, bj, smem, kbeg, kend, acc);
@@ -512,7 +539,7 @@ int launch_gemm_update_potf2(hipStream_t stream, int64_t M, int64_t N, int64_t K
     GemmParams p;
     p.A = P; p.B = P; p.C = C;
     p.lda = ldp; p.ldb = ldp; p.ldc = ldc;
-    p.M = (int)M; p.N = (int)N; p.K = (int)K;
+    p.M = (int)M; p.N = (int)N; p.K = (int)K; p.Mr = 0;
     p.alpha = -1.0; p.beta = 1.0; p.tri = TRI_SYRK_LOWER;
     p.fastA = p.fastB = (((uintptr_t)P & 15) == 0) && (ldp % 2 == 0);
     p.mblocks = (p.M + T - 1) / T;
@@ -559,7 +586,7 @@ int launch_gemm_batched(hipStream_t stream, bool ta, bool tb, int tri, int64_t M
     GemmParams p;
     p.A = A; p.B = B; p.C = C;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-    p.M = (int)M; p.N = (int)N; p.K = (int)K;
+    p.M = (int)M; p.N = (int)N; p.K = (int)K; p.Mr = 0;
     p.alpha = alpha; p.beta = beta; p.tri = tri;
     p.mblocks = p.nblocks = 0;
     p.fz_A = nullptr; p.fz_lda = 0; p.fz_nb = 0; p.fz_k0 = 0; p.fz_info = nullptr;
@@ -594,7 +621,7 @@ int launch_gemm_splitk(hipStream_t stream, bool ta, bool tb, int64_t M, int64_t 
     GemmParams p;
     p.A = A; p.B = B; p.C = Cpart;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-    p.M = (int)M; p.N = (int)N; p.K = (int)K;
+    p.M = (int)M; p.N = (int)N; p.K = (int)K; p.Mr = 0;
     p.alpha = alpha; p.beta = 0.0; p.tri = TRI_NONE;
     p.mblocks = p.nblocks = 0;
     p.fz_A = nullptr; p.fz_lda = 0; p.fz_nb = 0; p.fz_k0 = 0; p.fz_info = nullptr;
@@ -628,13 +655,14 @@ int gemm_split_count(gpirt_handle_t h, hipStream_t stream, int tri, int64_t M, i
 
 int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri, int64_t M,
                 int64_t N, int64_t K, double alpha, const double* A, int64_t lda, const double* B,
-                int64_t ldb, double beta, double* C, int64_t ldc)
+                int64_t ldb, double beta, double* C, int64_t ldc, int64_t Mread)
 {
     if (M <= 0 || N <= 0) return 0;
     GemmParams p;
     p.A = A; p.B = B; p.C = C;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.M = (int)M; p.N = (int)N; p.K = (int)K;
+    p.Mr = (!ta && Mread > M && Mread <= lda) ? (int)Mread : 0;
     p.alpha = alpha; p.beta = beta; p.tri = tri;
     p.mblocks = p.nblocks = 0;
     p.fz_A = nullptr; p.fz_lda = 0; p.fz_nb = 0; p.fz_k0 = 0; p.fz_info = nullptr;

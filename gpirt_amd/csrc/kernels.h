@@ -13,7 +13,9 @@ int launch_gemm_update_potf2(hipStream_t stream, int64_t M, int64_t N, int64_t K
 // gemm_f64.hip
 int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri, int64_t M,
                 int64_t N, int64_t K, double alpha, const double* A, int64_t lda, const double* B,
-                int64_t ldb, double beta, double* C, int64_t ldc);
+                int64_t ldb, double beta, double* C, int64_t ldc, int64_t Mread = 0);
+// Mread (> M, !ta only): rows of A beyond M that exist in memory (padding up to a tile multiple) -- lets the
+// last block row take the branch-free main loop; whatever those rows hold only reaches masked rows of C.
 
 int launch_gemm_batched(hipStream_t stream, bool ta, bool tb, int tri, int64_t M, int64_t N, int64_t K, double alpha,
                         const double* A, int64_t lda, int64_t strideA, const double* B, int64_t ldb, int64_t strideB,
@@ -81,7 +83,7 @@ int launch_fstar_epilogue(hipStream_t stream, const FstarEpiArgs& a);
 
 // theta.hip
 int launch_indicators(hipStream_t stream, const double* y, int64_t n, int64_t m, double* Ypm /* n x 2m */);
-int launch_loglik_terms(hipStream_t stream, const double* fstar, int64_t N, int64_t m, double* Gpm /* N x 2m */);
+int launch_loglik_terms(hipStream_t stream, const double* fstar, int64_t N, int64_t m, double* Gpm /* ldg x 2m */, int64_t ldg);
 struct ThetaArgs {
     const double* logpost;   // N x n (column i = respondent i), WITHOUT the prior
     int64_t N, n;

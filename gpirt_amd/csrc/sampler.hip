@@ -219,9 +219,10 @@ int do_theta_partial(gpirt_sampler_s* s)
 {
     hipStream_t st = s->h->stream;
     const int64_t n = s->n, m = s->m, N = s->N;
-    GP_TRY(launch_loglik_terms(st, s->fstar, N, m, s->Gpm));
+    const int64_t Np = (N + 127) / 128 * 128;     // Gpm is padded to whole 128-row tiles (zero rows)
+    GP_TRY(launch_loglik_terms(st, s->fstar, N, m, s->Gpm, Np));
     // logpost (N x n) = G+ Y+^T + G- Y-^T   (draw-theta.cpp:15-19 summed over this rank's items)
-    return launch_gemm(s->h, st, false, true, TRI_NONE, N, n, 2 * m, 1.0, s->Gpm, N, s->Ypm, n, 0.0, s->logpost, N);
+    return launch_gemm(s->h, st, false, true, TRI_NONE, N, n, 2 * m, 1.0, s->Gpm, Np, s->Ypm, n, 0.0, s->logpost, N, Np);
 }
 
 int do_theta_finish(gpirt_sampler_s* s)
@@ -293,7 +294,10 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
     GP_A(s->f, n * m);       GP_A(s->Z, n * m);        GP_A(s->NU, n * m);      GP_A(s->beta, 2 * m);
     GP_A(s->mu, n * m);      GP_A(s->mu_star, N * m + 1); GP_A(s->fstar, N * m + 1); GP_A(s->L, n * n);
     GP_A(s->tstar, N + 1);   GP_A(s->rhs, n * (N + m) + 2); GP_A(s->mean, N * m + 1); GP_A(s->s, N + 1);
-    GP_A(s->Gpm, N * 2 * m + 2); GP_A(s->logpost, N * n + 2); GP_A(s->irf_sum, N * m + 1);
+    GP_A(s->Gpm, ((N + 127) / 128 * 128) * 2 * m + 2); GP_A(s->logpost, N * n + 2); GP_A(s->irf_sum, N * m + 1);
+    if (hipMemset(s->Gpm, 0, sizeof(double) * (size_t)(((N + 127) / 128 * 128) * 2 * m + 2)) != hipSuccess) {   // its padding rows stay zero
+        set_error("hipMemset(Gpm) failed"); gpirt_sampler_destroy(s); return GPIRT_E_HIP;
+    }
     GP_A(s->pm, 2 * m);      GP_A(s->ps, 2 * m);       GP_A(s->step, 2 * m);
     GP_A(s->ess_k, m);       GP_A(s->flags, 4);
     if (!s->opt.fstar_fused) GP_A(s->kstar, n * N + 2);

@@ -117,13 +117,17 @@ __global__ void indicators_kernel(const double* __restrict__ y, int64_t total, d
 }
 
 // G+[k,j] = -log(1+exp(-f*_kj))  (y = +1),  G-[k,j] = -log(1+exp(+f*_kj))  (y = -1)
-__global__ void loglik_terms_kernel(const double* __restrict__ fstar, int64_t total, double* __restrict__ Gpm)
+// Gpm has leading dimension ldg >= N (rows N .. ldg-1 are padding the GEMM may read but never uses)
+__global__ void loglik_terms_kernel(const double* __restrict__ fstar, int64_t N, int64_t m, double* __restrict__ Gpm,
+                                    int64_t ldg)
 {
+    const int64_t total = N * m;
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total;
          g += (int64_t)gridDim.x * blockDim.x) {
         const double v = fstar[g];
-        Gpm[g] = -ll_term(1.0 * v);
-        Gpm[g + total] = -ll_term(-1.0 * v);
+        const int64_t o = (g % N) + (g / N) * ldg;
+        Gpm[o] = -ll_term(1.0 * v);
+        Gpm[o + ldg * m] = -ll_term(-1.0 * v);
     }
 }
 
@@ -342,9 +346,9 @@ int launch_indicators(hipStream_t stream, const double* y, int64_t n, int64_t m,
     return 0;
 }
 
-int launch_loglik_terms(hipStream_t stream, const double* fstar, int64_t N, int64_t m, double* Gpm)
+int launch_loglik_terms(hipStream_t stream, const double* fstar, int64_t N, int64_t m, double* Gpm, int64_t ldg)
 {
-    hipLaunchKernelGGL(loglik_terms_kernel, dim3(grid_for(N * m)), dim3(256), 0, stream, fstar, N * m, Gpm);
+    hipLaunchKernelGGL(loglik_terms_kernel, dim3(grid_for(N * m)), dim3(256), 0, stream, fstar, N, m, Gpm, ldg);
     GP_HIP(hipGetLastError());
     return 0;
 }
