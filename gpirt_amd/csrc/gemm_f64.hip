@@ -41,7 +41,7 @@ template <int T> struct Cfg {
     static constexpr int NT = T / 32;                     // MFMA tiles per wave per dimension
     static constexpr int PASSES = T / 32;                 // double2 loads per thread per operand tile
     static constexpr int DEPTH = (T == 64) ? 4 : 1;       // K-steps in flight between global memory and LDS
-    static constexpr int FDEPTH = (T == 64) ? 4 : 1;      // the same for the branch-free loop of interior tiles
+    static constexpr int FDEPTH = (T == 64) ? 2 : 1;      // the same for the branch-free loop of interior tiles
 };
 
 struct GemmParams {
@@ -373,7 +373,7 @@ __device__ __forceinline__ void gemm_mainloop_fast(const GemmParams& p, const in
         else if (slot == 2)           kstep(kt & 1, std::integral_constant<int, 2 % D>{}, no{}, no{}, st, ld);
         else                          kstep(kt & 1, std::integral_constant<int, 3 % D>{}, no{}, no{}, st, ld);
     };
-    static_assert(D == 1 || D == 4, "edge_step enumerates the slots of a ring of 1 or 4");
+    static_assert(D >= 1 && D <= 4, "edge_step enumerates the slots of a ring of 1 or 4");
     kstep(0, std::integral_constant<int, 1 % D>{}, yes{}, no{}, 1 < nk, 1 + D < nk);
     int kt = 1;
     // steady state, unrolled over the ring: steps kt .. kt+D-1 all have tiles kt+1 .. kt+2D in range
@@ -464,7 +464,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int bi, con
 // panel) factors that block right after producing it -- the potf2 launch and its kernel boundary
 // disappear from the panel chain (potrf.hip).
 template <bool TA, bool TB, int T, int PAD = 0, bool FUSE = false>
-__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p)
+__global__ __launch_bounds__(256, (T == 64 ? 3 : 2)) void gemm_f64_kernel(GemmParams p)
 {
     __shared__ __attribute__((aligned(16))) double smem[4 * Cfg<T>::TILE + PAD];
     p.A += (int64_t)blockIdx.y * p.sA;
