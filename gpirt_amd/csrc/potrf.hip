@@ -229,7 +229,7 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
         GP_HIP(hipEventCreateWithFlags(&h->ev_mid, hipEventDisableTiming));
         GP_HIP(hipEventCreateWithFlags(&h->ev_a, hipEventDisableTiming));
     }
-    static const int hold_rest = env_int("GPIRT_HOLD_REST", 3);     // 1: always, 2: never, 3: only before 128-tile updates
+    static const int hold_rest = env_int("GPIRT_HOLD_REST", 2);     // 1: always, 2: never (default), 3: only before 128-tile updates
     const int64_t nbp_la = (env_int("GPIRT_NBP", NBP) / NBI) * NBI > 0 ? (env_int("GPIRT_NBP", NBP) / NBI) * NBI : NBP;
     GP_TRY(factor_panel(h, stream, A, n, lda, 0, nbo < n ? nbo : n));
     for (int64_t K0 = 0; K0 < n; K0 += nbo) {
@@ -257,9 +257,10 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
                     // The large (128-tile) updates are released only once the second sub-panel is ready to go as
                     // well: a panel wave holds 424 of a SIMD's 512 registers and cannot squeeze in beside resident
                     // update waves, so it has to be dispatched (high-priority stream) before they fill the chip;
-                    // released earlier, update and panel kernel stretch each other 1.5-2x.  Measured: the update
-                    // kernel 0.44 -> 0.54 of the fp64 MFMA peak, the iteration 1.7 % slower (GPIRT_HOLD_REST=2
-                    // releases every update at once, =1 holds them all).
+                    // released earlier, update and panel kernel stretch each other 1.5-2x.  Measured with the
+                    // pipelined GEMM loop: holding (=3) puts the update kernel at 0.62 of the fp64 MFMA peak instead
+                    // of 0.54 but the iteration is 3.5 % slower, so the default (=2) releases every update at once;
+                    // =1 holds them all.
                     GP_HIP(hipEventRecord(h->ev_a, h->side));
                     GP_HIP(hipStreamWaitEvent(stream, h->ev_a, 0));
                 }
