@@ -554,8 +554,9 @@ int launch_gemm_update_potf2(hipStream_t stream, int64_t M, int64_t N, int64_t K
 
 bool gemm_trailing_uses_128(int64_t M, int64_t N)
 {
+    static const int tmin = getenv("GPIRT_TRAIL128_MIN") ? atoi(getenv("GPIRT_TRAIL128_MIN")) : 448;
     const int64_t mb = (M + 127) / 128, nb = (N + 127) / 128;
-    return nb * mb - nb * (nb - 1) / 2 >= 448;
+    return nb * mb - nb * (nb - 1) / 2 >= tmin;
 }
 
 template <int T>
