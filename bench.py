@@ -244,7 +244,9 @@ def main():
                 "item_sharded_stages": ["draw_f", "draw_fstar", "theta_gemm", "draw_beta"],
             },
             "roofline": {
-                "kernel": "gemm_f64_kernel<false, true, 128, 8, false> (potrf trailing update, syrk lower, v_mfma_f64_16x16x4_f64)",
+                "kernel": ("gemm_f64_kernel<false, true, 64, 0, false> (potrf trailing update, deferred block columns, syrk lower, v_mfma_f64_16x16x4_f64)"
+                           if os.environ.get("GPIRT_DEFER") in ("1", "3") else
+                           "gemm_f64_kernel<false, true, 128, 8, false> (potrf trailing update, syrk lower, v_mfma_f64_16x16x4_f64)"),
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": PEAK_FP64_MFMA_TFLOPS,

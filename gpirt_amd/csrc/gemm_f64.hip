@@ -552,11 +552,12 @@ int launch_gemm_update_potf2(hipStream_t stream, int64_t M, int64_t N, int64_t K
     return 0;
 }
 
-bool gemm_trailing_uses_128(int64_t M, int64_t N)
+bool gemm_trailing_uses_128(int64_t M, int64_t N, bool background)
 {
     static const int tmin = getenv("GPIRT_TRAIL128_MIN") ? atoi(getenv("GPIRT_TRAIL128_MIN")) : 448;
+    static const int bmin = getenv("GPIRT_BG128_MIN") ? atoi(getenv("GPIRT_BG128_MIN")) : 448;
     const int64_t mb = (M + 127) / 128, nb = (N + 127) / 128;
-    return nb * mb - nb * (nb - 1) / 2 >= tmin;
+    return nb * mb - nb * (nb - 1) / 2 >= (background ? bmin : tmin);
 }
 
 template <int T>
@@ -583,7 +584,7 @@ int launch_gemm_batched(hipStream_t stream, bool ta, bool tb, int tri, int64_t M
                         double beta, double* C, int64_t ldc, int64_t strideC, int batch)
 {
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
-    if (tri == TRI_SYRK_LOWER || tri == TRI_SYRK_LOWER_TRAILING) { set_error("batched gemm: no syrk mode"); return GPIRT_E_ARG; }
+    if (tri == TRI_SYRK_LOWER || tri == TRI_SYRK_LOWER_TRAILING || tri == TRI_SYRK_LOWER_BACKGROUND) { set_error("batched gemm: no syrk mode"); return GPIRT_E_ARG; }
     GemmParams p;
     p.A = A; p.B = B; p.C = C;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
@@ -670,10 +671,11 @@ int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri,
     p.sA = p.sB = p.sC = 0; p.ksplit = 0;
     p.fastA = (((uintptr_t)A & 15) == 0) && (lda % 2 == 0);
     p.fastB = (((uintptr_t)B & 15) == 0) && (ldb % 2 == 0);
-    if (tri == TRI_SYRK_LOWER_TRAILING) {
+    if (tri == TRI_SYRK_LOWER_TRAILING || tri == TRI_SYRK_LOWER_BACKGROUND) {
+        const bool bg = (tri == TRI_SYRK_LOWER_BACKGROUND);
         p.tri = TRI_SYRK_LOWER;
         if (M < N || ta || !tb) { set_error("trailing syrk mode needs the NT form and M >= N"); return GPIRT_E_ARG; }
-        if (gemm_trailing_uses_128(M, N)) return launch_gemm_trailing(stream, p);
+        if (gemm_trailing_uses_128(M, N, bg)) return launch_gemm_trailing(stream, p);
         return launch_gemm_t<64>(stream, ta, tb, p);
     }
     if (tri == TRI_SYRK_LOWER && M < N) { set_error("syrk mode needs M >= N"); return GPIRT_E_ARG; }

@@ -5,8 +5,9 @@
 
 namespace gpirt {
 
-enum { TRI_NONE = 0, TRI_SYRK_LOWER = 1, TRI_A_LOWER = 2, TRI_A_UPPER = 3, TRI_SYRK_LOWER_TRAILING = 4 };
-bool gemm_trailing_uses_128(int64_t M, int64_t N);
+enum { TRI_NONE = 0, TRI_SYRK_LOWER = 1, TRI_A_LOWER = 2, TRI_A_UPPER = 3, TRI_SYRK_LOWER_TRAILING = 4,
+       TRI_SYRK_LOWER_BACKGROUND = 5 /* deferred trailing update (GPIRT_DEFER): its own tile threshold GPIRT_BG128_MIN */ };
+bool gemm_trailing_uses_128(int64_t M, int64_t N, bool background = false);
 int launch_gemm_update_potf2(hipStream_t stream, int64_t M, int64_t N, int64_t K, const double* P, int64_t ldp,
                              double* C, int64_t ldc, int nb_next, int k0_next, int* info);   // does a trailing update of this shape run the 128-tile kernel?
 

@@ -16,6 +16,8 @@
 // arma::chol's contract).  A non-positive pivot records LAPACK's info (1-based order of the
 // leading minor) in h->d_info and lets NaNs propagate; the host checks it after the stream drains.
 #include "common.h"
+
+#include <vector>
 #include "kernels.h"
 #include "solve64.h"
 #include "potf2.h"
@@ -169,11 +171,11 @@ int factor_panel(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int
 // trailing update restricted to the column range [lo, hi):
 //   A[lo:n, lo:hi] -= A[lo:n, K0:c1] A[lo:hi, K0:c1]^T      (lower trapezoid, fp64 MFMA syrk)
 int trailing(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t K0, int64_t c1,
-             int64_t lo, int64_t hi, bool* fused_potf2 = nullptr)
+             int64_t lo, int64_t hi, bool* fused_potf2 = nullptr, bool background = false)
 {
     const int64_t M = n - lo, N = hi - lo, K = c1 - K0;
     // the roofline figure covers the launches of the dominant kernel only (128-tile syrk)
-    const bool prof = h->prof.enabled && gemm_trailing_uses_128(M, N);
+    const bool prof = h->prof.enabled && (background || gemm_trailing_uses_128(M, N, background));
     ProfPair pp{nullptr, nullptr, 0.0};
     if (prof) {
         if (!h->prof.free_pairs.empty()) { pp = h->prof.free_pairs.back(); h->prof.free_pairs.pop_back(); }
@@ -190,8 +192,8 @@ int trailing(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t
         *fused_potf2 = true;
         return 0;
     }
-    GP_TRY(launch_gemm(h, stream, false, true, TRI_SYRK_LOWER_TRAILING, M, N, K, -1.0,
-                       A + lo + K0 * lda, lda, A + lo + K0 * lda, lda, 1.0, A + lo + lo * lda, lda));
+    GP_TRY(launch_gemm(h, stream, false, true, background ? TRI_SYRK_LOWER_BACKGROUND : TRI_SYRK_LOWER_TRAILING, M, N, K,
+                       -1.0, A + lo + K0 * lda, lda, A + lo + K0 * lda, lda, 1.0, A + lo + lo * lda, lda));
     if (prof) {
         GP_HIP(hipEventRecord(pp.e1, stream));
         // algorithmic flops of the lower trapezoid: 2 K (M N - N (N - 1) / 2)
@@ -231,6 +233,19 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
     }
     static const int hold_rest = env_int("GPIRT_HOLD_REST", 2);     // 1: always, 2: never (default), 3: only before 128-tile updates
     const int64_t nbp_la = (env_int("GPIRT_NBP", NBP) / NBI) * NBI > 0 ? (env_int("GPIRT_NBP", NBP) / NBI) * NBI : NBP;
+    // Deferred trailing updates (opt-in, GPIRT_DEFER=3).  Panel q's update of a block column r >= q + 2 is not
+    // needed before panel r is factored.  Applying it to the whole rest of the matrix at once (right-looking,
+    // the default) loads the main stream with 38.7 GFLOP behind panel 0 and 1.1 behind panel 5, while the side
+    // chain needs the same ~0.55 ms every time.  With =3 each step only brings ONE more block column (GPIRT_DEFER_AHEAD)
+    // up to date, one launch per finished panel that has not reached it yet: 11.8 / 19.3 / 22.6 / 21.5 / 16.1 /
+    // 6.4 GFLOP per step at n = 8192.  Every block of C still receives its rank-1024 updates in ascending panel
+    // order, so L is bit-identical (tools/defer_check.py).  Measured: 120 it/s instead of 116 -- but those
+    // block-column launches are too small for the 128-tile kernel (356 tiles at most) and run on 64-tiles at
+    // 0.48 of the MFMA peak beside the panel kernel, against 0.53 for the undeferred 128-tile launches; =1 fuses a
+    // step's launches into one product of depth (q + 1) * 1024 (one read-modify-write of C, but 1.2 rounds of
+    // long tiles: 116 it/s).
+    static const int defer = env_int("GPIRT_DEFER", 2);      // 2: off (default), 3: one launch per panel, 1: fused
+    std::vector<int64_t> done_col;                   // (mode 3) columns < done_col[q] carry panel q's update
     GP_TRY(factor_panel(h, stream, A, n, lda, 0, nbo < n ? nbo : n));
     for (int64_t K0 = 0; K0 < n; K0 += nbo) {
         const int64_t c1 = (K0 + nbo < n) ? K0 + nbo : n;
@@ -268,7 +283,22 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
             } else {
                 GP_TRY(factor_panel(h, h->side, A, n, lda, c1, c2, diag_done)); // next panel, side stream
             }
-            GP_TRY(trailing(h, stream, A, n, lda, K0, c1, c2, n));        // the rest, concurrently
+            if (defer == 1 && split) {
+                const int64_t horizon = (c2 + nbo < n) ? c2 + nbo : n;
+                GP_TRY(trailing(h, stream, A, n, lda, 0, c1, c2, horizon, nullptr, true));
+            } else if (defer == 3 && split) {
+                done_col.push_back(c2);                                   // this panel: [c1, c2) done above
+                static const int ahead = env_int("GPIRT_DEFER_AHEAD", 1);  // block columns brought up to date per step
+                const int64_t horizon = (c2 + ahead * nbo < n) ? c2 + ahead * nbo : n;
+                for (size_t q = 0; q < done_col.size(); ++q)
+                    if (done_col[q] < horizon) {
+                        GP_TRY(trailing(h, stream, A, n, lda, (int64_t)q * nbo, (int64_t)(q + 1) * nbo, done_col[q], horizon,
+                                        nullptr, true));
+                        done_col[q] = horizon;
+                    }
+            } else {
+                GP_TRY(trailing(h, stream, A, n, lda, K0, c1, c2, n));    // the rest, concurrently
+            }
             GP_HIP(hipEventRecord(h->ev_join, h->side));
             GP_HIP(hipStreamWaitEvent(stream, h->ev_join, 0));
         } else {
