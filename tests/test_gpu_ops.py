@@ -31,6 +31,36 @@ def test_gemm_matches_numpy(handle, ta, tb, shape):
     assert np.abs(to_host(out) - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("K", [16, 32, 48, 64, 80, 112, 176])
+def test_gemm_pipelined_loop_64_tiles(handle, ta, tb, K):
+    """Interior 64-tiles take the branch-free software-pipelined K loop (register ring of 2): every prologue /
+    steady-state / tail combination of K-steps (K = 16 ... 176 = 1 ... 11 steps), plus one ragged block row."""
+    from gpirt_amd.ops import to_device, to_host
+    M, N = 192 + 5, 128
+    rng = np.random.default_rng(K + 2 * ta + tb)
+    A = rng.standard_normal((K, M) if ta else (M, K))
+    B = rng.standard_normal((N, K) if tb else (K, N))
+    C0 = rng.standard_normal((M, N))
+    out = handle.gemm(to_device(A), to_device(B), ta=ta, tb=tb, alpha=-1.0, beta=1.0, C_out=to_device(C0))
+    ref = C0 - (A.T if ta else A) @ (B.T if tb else B)
+    assert np.abs(to_host(out) - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("K", [16, 32, 48, 96])
+def test_gemm_pipelined_loop_128_tiles(handle, ta, tb, K):
+    """The same for the 128-tile kernel (chosen from 448 tiles on): 22 x 22 interior tiles + a ragged edge."""
+    from gpirt_amd.ops import to_device, to_host
+    M, N = 22 * 128 + 40, 22 * 128
+    rng = np.random.default_rng(K + 2 * ta + tb + 100)
+    A = rng.standard_normal((K, M) if ta else (M, K))
+    B = rng.standard_normal((N, K) if tb else (K, N))
+    out = handle.gemm(to_device(A), to_device(B), ta=ta, tb=tb)
+    ref = (A.T if ta else A) @ (B.T if tb else B)
+    assert np.abs(to_host(out) - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+
+
 def test_gemm_mfma_layout_asymmetric(handle):
     """A = I with an asymmetric B catches a transposed C/D lane map (guide section 3)."""
     from gpirt_amd.ops import to_device, to_host
