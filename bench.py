@@ -9,8 +9,9 @@ trmm + elliptical slice), draw_fstar (K*, trsm, [trsm^T], gemm, epilogue), draw_
 grid inverse-CDF), draw_beta (+ mu, mu_star), K + jitter + blocked MFMA Cholesky -- on synthetic 2PL
 responses of the metric's shape, N = 8192 respondents x m = 1024 items, fp64, item-keyed RNG
 (GPIRT_RNG_ITEM).  Inputs are resident in HBM before the timed region.  With N > 1 the SAME problem is
-sharded over item columns (strong scaling): the partial log-posterior of draw_theta is all-reduced
-over RCCL and the Cholesky is replicated (--chol bcast: rank 0 factors and broadcasts L).
+sharded over item columns (strong scaling): for draw_theta the ranks all-gather their f* columns (8 MB) over
+RCCL and each draws theta for its block of respondents (--theta allreduce: the 66 MB partial log-posteriors are
+all-reduced instead); the Cholesky is replicated (--chol bcast: rank 0 factors and broadcasts L).
 
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline      the potrf trailing-update kernel (fp64 MFMA syrk): algorithmic flops / HIP-event time
@@ -89,6 +90,8 @@ def main():
     ap.add_argument("--respondents", "--n", dest="n", type=int, default=8192)
     ap.add_argument("--items", "--m", dest="m", type=int, default=1024)
     ap.add_argument("--chol", default="replicated", choices=["replicated", "bcast"])
+    ap.add_argument("--theta", default="gather", choices=["gather", "allreduce"],
+                    help="N > 1: all-gather f* and draw theta per respondent block (default), or all-reduce the partial log-posterior")
     ap.add_argument("--fstar", default="lowrank", choices=["double_solve", "fused", "lowrank"],
                     help="double_solve: src/draw-fstar.cpp as written; fused: mean = (L^-1 k*)^T (L^-1 f); lowrank: fused + the "
                          "rank-64 Chebyshev factorisation of K(theta, theta*) (exact to 1e-15), 64 + m right-hand sides")
@@ -136,7 +139,7 @@ def main():
                        fstar_fused=(args.fstar != "double_solve"), kstar_rank=(64 if args.fstar == "lowrank" else 0),
                        item0=item0, m_total=m_total)
 
-    ss = ShardedSampler(factory, y, theta0, dist=dist if world > 1 else None, chol=args.chol)
+    ss = ShardedSampler(factory, y, theta0, dist=dist if world > 1 else None, chol=args.chol, theta=args.theta)
     ss.init()
     ss.engine.check()
 
@@ -232,8 +235,10 @@ def main():
                 "workload": f"M: N={n} respondents x m={m} items, synthetic 2PL responses (5% NA), full MCMC "
                             f"iteration on device (draw_f, draw_fstar[{args.fstar}], draw_theta, draw_beta, K+chol), "
                             f"rng=item, theta_stabilise=1",
-                "parallelism": f"items sharded over {world} GPU(s); chol {args.chol}; all-reduce of the "
-                               f"{1001}x{n} partial log-posterior per iteration" if world > 1 else "single GPU",
+                "parallelism": (f"items sharded over {world} GPU(s); chol {args.chol}; draw_theta: " +
+                                (f"all-gather of f* ({1001}x{m}), theta drawn per block of respondents, {n} draws combined"
+                                 if args.theta == "gather" else
+                                 f"all-reduce of the {1001}x{n} partial log-posterior per iteration")) if world > 1 else "single GPU",
                 "stage_ms": stage_ms,
                 "draw_fstar_form": {"double_solve": "src/draw-fstar.cpp:17-25 as written",
                                     "fused": "mean = (L^-1 k*)^T (L^-1 f)",
@@ -241,7 +246,9 @@ def main():
                                                "1.3e-15; f* within 2e-11 of the full solve): 2 x 64 right-hand sides instead "
                                                "of 1001 + m"}[args.fstar],
                 "iterations_per_s_other_forms": alt,
-                "item_sharded_stages": ["draw_f", "draw_fstar", "theta_gemm", "draw_beta"],
+                "item_sharded_stages": ["draw_f", "draw_fstar", "draw_beta"] + (["theta_gemm"] if args.theta == "allreduce" else []),
+                "respondent_sharded_stages": ["theta_gemm", "theta_sample"] if (world > 1 and args.theta == "gather") else [],
+                "stage_ms_note": "theta_allreduce = the collective of draw_theta (all-gather of f* or all-reduce of the log-posterior)",
             },
             "roofline": {
                 "kernel": ("gemm_f64_kernel<false, true, 64, 0, false> (potrf trailing update, deferred block columns, syrk lower, v_mfma_f64_16x16x4_f64)"

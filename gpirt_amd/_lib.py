@@ -86,6 +86,9 @@ SIGNATURES = {
     "gpirt_sampler_draw_fstar": (_i32, [_vp]),
     "gpirt_sampler_theta_partial": (_i32, [_vp]),
     "gpirt_sampler_theta_finish": (_i32, [_vp]),
+    "gpirt_sampler_set_theta_block": (_i32, [_vp, _vp, _i64, _i64, _i64]),
+    "gpirt_sampler_theta_block": (_i32, [_vp]),
+    "gpirt_sampler_theta_commit": (_i32, [_vp]),
     "gpirt_sampler_draw_beta": (_i32, [_vp]),
     "gpirt_sampler_factor": (_i32, [_vp]),
     "gpirt_sampler_skip_factor": (_i32, [_vp]),

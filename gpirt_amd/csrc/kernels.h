@@ -86,8 +86,10 @@ int launch_fstar_epilogue(hipStream_t stream, const FstarEpiArgs& a);
 int launch_indicators(hipStream_t stream, const double* y, int64_t n, int64_t m, double* Ypm /* n x 2m */);
 int launch_loglik_terms(hipStream_t stream, const double* fstar, int64_t N, int64_t m, double* Gpm /* ldg x 2m */, int64_t ldg);
 struct ThetaArgs {
-    const double* logpost;   // N x n (column i = respondent i), WITHOUT the prior
+    const double* logpost;   // N x n (column i = respondent i0 + i), WITHOUT the prior
     int64_t N, n;
+    int64_t i0;              // global index of the first respondent (a block of a sharded run; 0 otherwise):
+                             // keys the RNG and offsets theta_out, so draws do not depend on the partition
     int stabilise;
     uint64_t seed; uint32_t iter;
     const double* U; uint64_t* pos; uint64_t cap;  // R-stream replay when U != null

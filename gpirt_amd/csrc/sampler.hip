@@ -45,6 +45,10 @@ struct gpirt_sampler_s {
     // low-rank K* (opt.reserved[2] = r > 0): Chebyshev nodes, interpolation matrix V (N x r), split-K parts
     int kr = 0;
     double *knodes = nullptr, *kV = nullptr, *kparts = nullptr, *kP = nullptr;
+    // respondent-block form of draw_theta for item-sharded runs (gpirt_sampler_set_theta_block): this rank's
+    // block of respondents with ALL items
+    int64_t blk_i0 = 0, blk_n = 0, blk_m = 0;
+    double *Ypm_blk = nullptr, *Gpm_full = nullptr, *logpost_blk = nullptr, *fstar_full = nullptr, *theta_stage = nullptr;
     int *ess_k = nullptr, *flags = nullptr;    // flags[0] = err, flags[1] = degenerate theta count
     int *fstar_off = nullptr;                  // R-stream replay: consumption offsets of draw_fstar
     int *h_flags = nullptr;                    // pinned
@@ -236,6 +240,27 @@ int do_theta_finish(gpirt_sampler_s* s)
     GP_TRY(launch_theta_sample(st, a));
     if (stream_mode(s)) GP_TRY(launch_advance_pos(st, s->pos, (uint64_t)s->n));
     return 0;
+}
+
+// draw_theta for the respondents [blk_i0, blk_i0 + blk_n) from the gathered f* of ALL items: the same product and
+// the same sampling kernel as the single-GPU path, restricted to a column block of the log-posterior -- so the
+// sums over items run in one GEMM in item order (bit-identical to one GPU) and what crosses the links per
+// iteration is f* (N x m, 8 MB at the metric size) instead of the N x n partial log-posterior (66 MB).
+int do_theta_block(gpirt_sampler_s* s)
+{
+    hipStream_t st = s->h->stream;
+    const int64_t N = s->N, nb = s->blk_n, mt = s->blk_m;
+    const int64_t Np = (N + 127) / 128 * 128;
+    GP_HIP(hipMemsetAsync(s->theta_stage, 0, sizeof(double) * (size_t)s->n, st));
+    if (nb == 0) return 0;
+    GP_TRY(launch_loglik_terms(st, s->fstar_full, N, mt, s->Gpm_full, Np));
+    GP_TRY(launch_gemm(s->h, st, false, true, TRI_NONE, N, nb, 2 * mt, 1.0, s->Gpm_full, Np, s->Ypm_blk, nb, 0.0,
+                       s->logpost_blk, N, Np));
+    ThetaArgs a{};
+    a.logpost = s->logpost_blk; a.N = N; a.n = nb; a.i0 = s->blk_i0; a.stabilise = s->opt.theta_stabilise;
+    a.seed = s->opt.seed; a.iter = (uint32_t)(s->iter + 1);
+    a.theta_out = s->theta_stage; a.degenerate = s->flags + 1; a.err = s->flags;
+    return launch_theta_sample(st, a);
 }
 
 int do_draw_beta(gpirt_sampler_s* s)
@@ -507,6 +532,45 @@ int gpirt_sampler_draw_f(gpirt_sampler_t s) { GP_ARG(s && s->initialised); retur
 int gpirt_sampler_draw_fstar(gpirt_sampler_t s) { GP_ARG(s && s->initialised); return do_draw_fstar(s, (uint32_t)(s->iter + 1)); }
 int gpirt_sampler_theta_partial(gpirt_sampler_t s) { GP_ARG(s && s->initialised); return do_theta_partial(s); }
 int gpirt_sampler_theta_finish(gpirt_sampler_t s) { GP_ARG(s && s->initialised); return do_theta_finish(s); }
+
+int gpirt_sampler_set_theta_block(gpirt_sampler_t s, const double* y_block, int64_t i0, int64_t n_block, int64_t m_total)
+{
+    GP_ARG(s && (y_block || n_block == 0) && i0 >= 0 && n_block >= 0 && i0 + n_block <= s->n && m_total >= s->m);
+    if (stream_mode(s)) { set_error("the R-stream replay cannot be sharded"); return GPIRT_E_ARG; }
+    if (s->fstar_full) { set_error("the theta block is already set"); return GPIRT_E_ARG; }
+    const int64_t N = s->N, Np = (N + 127) / 128 * 128;
+    int rc = 0;
+    double* yb = nullptr;
+#define GP_B(p, cnt) do { rc = dalloc(s, &(p), (size_t)(cnt)); if (rc) return rc; } while (0)
+    GP_B(s->Ypm_blk, n_block * 2 * m_total + 2); GP_B(s->Gpm_full, Np * 2 * m_total + 2);
+    GP_B(s->logpost_blk, N * n_block + 2);       GP_B(s->fstar_full, N * m_total + 2);
+    GP_B(s->theta_stage, s->n + 1);              GP_B(yb, n_block * m_total + 1);
+#undef GP_B
+    hipStream_t st = s->h->stream;
+    GP_HIP(hipMemsetAsync(s->Gpm_full, 0, sizeof(double) * (size_t)(Np * 2 * m_total + 2), st));   // padding rows stay zero
+    if (n_block > 0) {
+        GP_HIP(hipMemcpyAsync(yb, y_block, sizeof(double) * (size_t)(n_block * m_total), hipMemcpyHostToDevice, st));
+        GP_TRY(launch_indicators(st, yb, n_block, m_total, s->Ypm_blk));
+    }
+    GP_HIP(hipStreamSynchronize(st));
+    s->blk_i0 = i0; s->blk_n = n_block; s->blk_m = m_total;
+    return 0;
+}
+
+int gpirt_sampler_theta_block(gpirt_sampler_t s)
+{
+    GP_ARG(s && s->initialised);
+    if (!s->fstar_full) { set_error("gpirt_sampler_set_theta_block has not been called"); return GPIRT_E_ARG; }
+    return do_theta_block(s);
+}
+
+/* theta := the staged draw (after the blocks of all ranks have been summed into "theta_stage") */
+int gpirt_sampler_theta_commit(gpirt_sampler_t s)
+{
+    GP_ARG(s && s->initialised && s->theta_stage);
+    GP_HIP(hipMemcpyAsync(s->theta, s->theta_stage, sizeof(double) * (size_t)s->n, hipMemcpyDeviceToDevice, s->h->stream));
+    return 0;
+}
 int gpirt_sampler_draw_beta(gpirt_sampler_t s) { GP_ARG(s && s->initialised); return do_draw_beta(s); }
 int gpirt_sampler_factor(gpirt_sampler_t s)
 {
@@ -593,6 +657,7 @@ static int lookup(gpirt_sampler_t s, const char* name, void** p, int64_t* count)
         { "logpost", s->logpost, N * n }, { "irf_sum", s->irf_sum, N * m }, { "ess_k", s->ess_k, m },
         { "s", s->s, N }, { "mean", s->mean, N * m }, { "nu", s->NU, n * m }, { "z", s->Z, n * m },
         { "y", s->y, n * m },
+        { "fstar_full", s->fstar_full, s->fstar_full ? N * s->blk_m : 0 }, { "theta_stage", s->theta_stage, s->theta_stage ? n : 0 },
     };
     for (auto& e : tab)
         if (strcmp(e.k, name) == 0) { *p = e.p; *count = e.c; return 0; }

@@ -137,8 +137,9 @@ __global__ __launch_bounds__(256) void theta_sample_kernel(ThetaArgs a)
     __shared__ double red[8];
     __shared__ double scan[256];
     __shared__ int    ired[4];
-    const int64_t i = blockIdx.x;
-    const double* lp = a.logpost + i * a.N;
+    const int64_t ib = blockIdx.x;                 // column of logpost
+    const int64_t i = ib + a.i0;                   // respondent
+    const double* lp = a.logpost + ib * a.N;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int N = (int)a.N;
     double P[4];

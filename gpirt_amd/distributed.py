@@ -3,9 +3,13 @@
 Given L and theta the m item columns of draw_f / draw_fstar / draw_beta are conditionally
 independent (src/draw-f.cpp:69-71, src/draw-fstar.cpp:23-29, src/draw-beta.cpp:16-38), so rank r
 owns columns [m*r/G, m*(r+1)/G).  What is not item-separable:
-  * draw_theta sums the log-likelihood over ALL items per respondent (src/draw-theta.cpp:15-19):
-    every rank computes the partial sum over its items (one MFMA GEMM) and the N* x n partial
-    log-posteriors are all-reduced; every rank then draws the same theta (RNG keyed by respondent).
+  * draw_theta sums the log-likelihood over ALL items per respondent (src/draw-theta.cpp:15-19).
+    `theta="gather"` (default): the ranks all-gather their f* columns (N* x m, 8 MB at the metric size), every
+    rank forms the log-posterior of ITS BLOCK OF RESPONDENTS over all items in one MFMA GEMM (the same sums in
+    the same order as on one GPU) and draws theta for that block; the n draws are then combined (64 KB).
+    `theta="allreduce"`: every rank computes the partial sum over its items for all respondents and the
+    N* x n partial log-posteriors (66 MB) are all-reduced; every rank then draws the same theta.
+    Either way the RNG is keyed by the global respondent index.
   * K + chol (src/gpirtMCMC.cpp:76-78): `chol="replicated"` factors on every rank (no traffic);
     `chol="bcast"` factors on rank 0 and broadcasts L (one RCCL broadcast per iteration).
 The per-item RNG sub-streams are keyed by the GLOBAL item index, so the draws do not depend on G.
@@ -28,7 +32,7 @@ def item_range(m: int, rank: int, world: int):
 
 class ShardedSampler:
     def __init__(self, engine_factory, y, theta_init, pm=None, ps=None, step=None, *, dist=None,
-                 chol="replicated"):
+                 chol="replicated", theta="gather"):
         self.dist = dist
         self.rank = dist.get_rank() if dist is not None else 0
         self.world = dist.get_world_size() if dist is not None else 1
@@ -45,11 +49,36 @@ class ShardedSampler:
         self.chol = chol
         if chol not in ("replicated", "bcast"):
             raise ValueError("chol must be 'replicated' or 'bcast'")
+        if theta not in ("gather", "allreduce"):
+            raise ValueError("theta must be 'gather' or 'allreduce'")
+        self.theta_mode = theta if self.world > 1 else "local"
+        if self.theta_mode == "gather":
+            self.i0, self.i1 = item_range(self.n, self.rank, self.world)     # this rank's block of respondents
+            self.engine.set_theta_block(y[self.i0:self.i1, :], self.i0, m)
+            self._equal_shards = (m % self.world == 0)
 
     # -- collectives on the engine's buffers ------------------------------------------------
     def _allreduce_logpost(self):
         if self.world > 1:
             self.dist.all_reduce(self.engine.device_tensor("logpost"))
+
+    def _gather_fstar(self):
+        """every rank's f* columns -> the full N* x m array on every rank (column-major: shards are contiguous)"""
+        e = self.engine
+        full, loc = e.device_tensor("fstar_full"), e.device_tensor("fstar")
+        if self._equal_shards:
+            try:
+                self.dist.all_gather_into_tensor(full, loc)
+                return
+            except (RuntimeError, NotImplementedError, AttributeError):
+                self._equal_shards = False          # backend without the flat all-gather: fall through
+        N = full.numel() // self.m_total
+        full.zero_()
+        full[N * self.lo: N * self.hi].copy_(loc[: N * (self.hi - self.lo)])
+        self.dist.all_reduce(full)                  # disjoint supports: the sum is the concatenation, exactly
+
+    def _combine_theta(self):
+        self.dist.all_reduce(self.engine.device_tensor("theta_stage"))   # zero outside each rank's block
 
     def _factor(self):
         if self.chol == "replicated" or self.world == 1:
@@ -73,9 +102,14 @@ class ShardedSampler:
         t = timer if timer is not None else (lambda name: None)
         e.draw_f(); t("draw_f")
         e.draw_fstar(); t("draw_fstar")
-        e.theta_partial(); t("theta_gemm")
-        self._allreduce_logpost(); t("theta_allreduce")
-        e.theta_finish(); t("theta_sample")
+        if self.theta_mode == "gather":
+            self._gather_fstar(); t("theta_allreduce")
+            e.theta_block(); t("theta_gemm")
+            self._combine_theta(); e.theta_commit(); t("theta_sample")
+        else:
+            e.theta_partial(); t("theta_gemm")
+            self._allreduce_logpost(); t("theta_allreduce")
+            e.theta_finish(); t("theta_sample")
         e.draw_beta(); t("draw_beta")
         self._factor(); t("factor")
 

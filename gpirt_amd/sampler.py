@@ -148,6 +148,13 @@ class Sampler:
     def draw_fstar(self): self._call("gpirt_sampler_draw_fstar")
     def theta_partial(self): self._call("gpirt_sampler_theta_partial")
     def theta_finish(self): self._call("gpirt_sampler_theta_finish")
+    def theta_block(self): self._call("gpirt_sampler_theta_block")
+    def theta_commit(self): self._call("gpirt_sampler_theta_commit")
+
+    def set_theta_block(self, y_block, i0: int, m_total: int):
+        """This rank's block of respondents with ALL item columns (item-sharded runs, include/gpirt_hip.h)."""
+        yb = _f64(np.asfortranarray(y_block))
+        check(self.lib.gpirt_sampler_set_theta_block(self._s, _ptr(yb), int(i0), int(yb.shape[0]), int(m_total)))
     def draw_beta(self): self._call("gpirt_sampler_draw_beta")
     def factor(self): self._call("gpirt_sampler_factor")
     def skip_factor(self): self._call("gpirt_sampler_skip_factor")

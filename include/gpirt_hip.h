@@ -207,6 +207,15 @@ int gpirt_sampler_draw_f(gpirt_sampler_t s);             /* :68 / :87 */
 int gpirt_sampler_draw_fstar(gpirt_sampler_t s);         /* :69 / :88 */
 int gpirt_sampler_theta_partial(gpirt_sampler_t s);      /* local-item part of draw_theta's log-posterior */
 int gpirt_sampler_theta_finish(gpirt_sampler_t s);       /* :70 / :89 (after any cross-rank reduction) */
+/* Respondent-block form of draw_theta for item-sharded runs (replaces theta_partial / all-reduce / theta_finish):
+ * once, hand over this rank's block of the response matrix with ALL item columns (host, n_block x m_total,
+ * column-major, same coding as y); per iteration gather every rank's f* columns into the device array
+ * "fstar_full" (N x m_total, gpirt_sampler_devptr), call theta_block -- draw-theta.cpp:15-34 for the respondents
+ * [i0, i0 + n_block), result in "theta_stage" (n values, zero outside the block) --, sum "theta_stage" over the
+ * ranks and call theta_commit.  Draws are keyed by the global respondent index: independent of the partition. */
+int gpirt_sampler_set_theta_block(gpirt_sampler_t s, const double* y_block, int64_t i0, int64_t n_block, int64_t m_total);
+int gpirt_sampler_theta_block(gpirt_sampler_t s);
+int gpirt_sampler_theta_commit(gpirt_sampler_t s);
 int gpirt_sampler_draw_beta(gpirt_sampler_t s);          /* :71-75 / :90-94 (beta, mu, mu_star) */
 int gpirt_sampler_factor(gpirt_sampler_t s);             /* :76-78 / :95-97 */
 /* closes the iteration WITHOUT factoring: for ranks that receive L by broadcast ("L" devptr) */

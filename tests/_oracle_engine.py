@@ -25,7 +25,36 @@ class OracleEngine:
 
     # state views shared with torch (what the collectives operate on)
     def device_tensor(self, name):
-        return {"logpost": self._logpost, "L": self._L}[name]
+        if name == "fstar":
+            self._fstar_t = torch.from_numpy(np.ascontiguousarray(self.fstar.reshape(-1, order="F")))
+            return self._fstar_t
+        return {"logpost": self._logpost, "L": self._L, "fstar_full": getattr(self, "_fstar_full", None),
+                "theta_stage": getattr(self, "_theta_stage", None)}[name]
+
+    # respondent-block form of draw_theta (gpirt_sampler_set_theta_block / theta_block / theta_commit)
+    def set_theta_block(self, y_block, i0, m_total):
+        self.y_blk = np.asfortranarray(y_block)
+        self.blk_i0 = i0
+        self._fstar_full = torch.zeros(self.N * m_total, dtype=torch.float64)
+        self._theta_stage = torch.zeros(self.n, dtype=torch.float64)
+
+    def theta_block(self):
+        fs = self._fstar_full.numpy().reshape(self.N, -1, order="F")
+        prior = np.array([O.lib().orc_dnorm_log(t, 0.0, 1.0) for t in self.ts])
+        st = self._theta_stage.numpy()
+        st[:] = 0.0
+        for ib in range(self.y_blk.shape[0]):
+            i = self.blk_i0 + ib
+            ok = ~np.isnan(self.y_blk[ib])
+            a = fs[:, ok] * self.y_blk[ib, ok][None, :]
+            P = prior + (-np.sum(np.log(1 + np.exp(-a)), axis=1))
+            P = np.cumsum(np.exp(P - P.max()))
+            P = (P - P.min()) / (P.max() - P.min())
+            u = O.item_uniform(self.rng.s.seed, self.it + 1, O.ST_THETA, i, 0)
+            st[i] = self.ts[np.nonzero(P > u)[0][0]]
+
+    def theta_commit(self):
+        self.theta = self._theta_stage.numpy().copy()
 
     @property
     def L(self):

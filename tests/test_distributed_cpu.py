@@ -15,7 +15,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(rank, world, port, chol, outdir):
+def _run(rank, world, port, chol, outdir, theta="gather", m=7):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -24,8 +24,8 @@ def _run(rank, world, port, chol, outdir):
     from _oracle_engine import OracleEngine
     from gpirt_amd.distributed import ShardedSampler
     from gpirt_amd.synthetic import make_responses
-    y, th0 = make_responses(40, 7, seed=4)
-    ss = ShardedSampler(OracleEngine, y, th0, dist=dist, chol=chol)
+    y, th0 = make_responses(40, m, seed=4)
+    ss = ShardedSampler(OracleEngine, y, th0, dist=dist, chol=chol, theta=theta)
     ss.init()
     for _ in range(2):
         ss.step()
@@ -33,21 +33,25 @@ def _run(rank, world, port, chol, outdir):
     beta = ss.gather("beta")
     fstar = ss.gather("fstar")
     if rank == 0:
-        np.savez(os.path.join(outdir, f"sharded_{chol}.npz"), f=f, beta=beta, fstar=fstar, theta=ss.engine.theta,
+        np.savez(os.path.join(outdir, f"sharded_{chol}_{theta}_{m}.npz"), f=f, beta=beta, fstar=fstar, theta=ss.engine.theta,
                  L=ss.engine.L)
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("chol", ["replicated", "bcast"])
-def test_two_ranks_reproduce_single_process(tmp_path, chol):
+@pytest.mark.parametrize("chol,theta,m", [("replicated", "gather", 7), ("bcast", "gather", 8), ("replicated", "allreduce", 7),
+                                          ("bcast", "allreduce", 7)])
+def test_two_ranks_reproduce_single_process(tmp_path, chol, theta, m):
+    """theta="gather": f* is all-gathered (m = 8: equal shards, flat all-gather; m = 7: unequal shards, the
+    all-reduce-of-disjoint-supports fallback) and each rank draws theta for its block of respondents;
+    theta="allreduce": the partial log-posteriors are all-reduced."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from _oracle_engine import OracleEngine
     from gpirt_amd.distributed import ShardedSampler
     from gpirt_amd.synthetic import make_responses
-    port = 29500 + (os.getpid() % 2000) + (1 if chol == "bcast" else 0)
-    mp.spawn(_run, args=(2, port, chol, str(tmp_path)), nprocs=2, join=True)
-    got = np.load(tmp_path / f"sharded_{chol}.npz")
-    y, th0 = make_responses(40, 7, seed=4)
+    port = 29500 + (os.getpid() % 2000) + (1 if chol == "bcast" else 0) + (2 if theta == "gather" else 0)
+    mp.spawn(_run, args=(2, port, chol, str(tmp_path), theta, m), nprocs=2, join=True)
+    got = np.load(tmp_path / f"sharded_{chol}_{theta}_{m}.npz")
+    y, th0 = make_responses(40, m, seed=4)
     ref = ShardedSampler(OracleEngine, y, th0, dist=None)
     ref.init()
     for _ in range(2):

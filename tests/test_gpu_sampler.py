@@ -84,6 +84,51 @@ def test_sampler_stage_api_equals_step(handle, oracle):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("n,m", [(150, 11), (1200, 40)])
+def test_theta_by_respondent_blocks_equals_theta_by_items(handle, n, m):
+    """The item-sharded runs draw theta per block of respondents from the gathered f* (gpirt_sampler_theta_block).
+    Two 'ranks' on one device -- each owning half of the item columns, one of two unequal respondent blocks -- must
+    reproduce the single sampler's theta bit for bit, through the same collectives ShardedSampler issues."""
+    import torch
+    from gpirt_amd import Sampler
+    from gpirt_amd.distributed import item_range
+    from gpirt_amd.synthetic import make_responses
+    y, th0 = make_responses(n, m, seed=21)
+    one = Sampler(handle, y, th0, rng="item", seed=5)
+    one.init()
+    ranks = []
+    cut = [0, n // 3, n]
+    for r in range(2):
+        lo, hi = item_range(m, r, 2)
+        e = Sampler(handle, y[:, lo:hi], th0, rng="item", seed=5, item0=lo, m_total=m)
+        e.set_theta_block(y[cut[r]:cut[r + 1], :], cut[r], m)
+        e.init()
+        ranks.append((e, lo, hi))
+    N = 1001
+    for _ in range(2):
+        one.step()
+        for e, lo, hi in ranks:
+            e.draw_f(); e.draw_fstar()
+        for e, _, _ in ranks:                                  # "all-gather" of the f* columns
+            full = e.device_tensor("fstar_full")
+            for src, lo, hi in ranks:
+                full[N * lo: N * hi].copy_(src.device_tensor("fstar")[: N * (hi - lo)])
+        for e, _, _ in ranks:
+            e.theta_block()
+        total = sum(e.device_tensor("theta_stage").clone() for e, _, _ in ranks)      # "all-reduce"
+        for e, _, _ in ranks:
+            e.device_tensor("theta_stage").copy_(total)
+            e.theta_commit(); e.draw_beta(); e.factor()
+        torch.cuda.synchronize()
+        for e, lo, hi in ranks:
+            e.check()
+            assert np.array_equal(e.get("theta"), one.get("theta"))
+            assert np.array_equal(e.get("f"), one.get("f")[:, lo:hi])
+    for e, _, _ in ranks:
+        e.close()
+    one.close()
+
+
 @pytest.mark.parametrize("n,m,S,B", [(5, 1, 1, 0), (64, 2, 1, 1), (65, 3, 0, 1), (257, 4, 1, 0)])
 def test_mcmc_edge_shapes(handle, oracle, n, m, S, B):
     """Tiny / ragged problems (n below, at and just above a 64-column panel; a single item; S = 0 -> NaN IRFs)."""
