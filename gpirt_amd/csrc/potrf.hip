@@ -270,7 +270,7 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
                                    A + cA + c1 * lda, lda, A + cA + c1 * lda, lda, 1.0, A + cA + cA * lda, lda));
                 if (hold_rest == 1 || (hold_rest == 3 && gemm_trailing_uses_128(n - c2, n - c2))) {
                     // The large (128-tile) updates are released only once the second sub-panel is ready to go as
-                    // well: a panel wave holds 424 of a SIMD's 512 registers and cannot squeeze in beside resident
+                    // well: a panel wave holds all 512 registers of its SIMD slice and cannot squeeze in beside resident
                     // update waves, so it has to be dispatched (high-priority stream) before they fill the chip;
                     // released earlier, update and panel kernel stretch each other 1.5-2x.  Measured with the
                     // pipelined GEMM loop: holding (=3) puts the update kernel at 0.62 of the fp64 MFMA peak instead
