@@ -103,6 +103,8 @@ SIGNATURES = {
     "gpirt_sampler_stage_times": (_i32, [_vp, _dp, _i32, C.POINTER(_i32), C.POINTER(C.c_char_p)]),
     "gpirt_prof_trailing": (_i32, [_vp, _i32, _dp, C.POINTER(_i64), _dp]),
     "gpirt_prof_enable": (_i32, [_vp, _i32]),
+    "gpirt_prof_syrk": (_i32, [_vp, _i32, _i32, _dp, C.POINTER(_i64), _dp]),
+    "gpirt_sampler_set_iteration": (_i32, [_vp, _i32]),
 }
 
 _lib = None

@@ -62,6 +62,19 @@ __global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double* out, int ite
     out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// The persistent panel kernel gave up on a progress counter (flagsync.h): info[1] = 1, info[2] = waiting row
+// block (absolute), info[3] = awaited row block, info[4..5] = value needed, info[6..7] = value last seen.
+int report_panel_guard(gpirt_handle_t h, const int* w, hipStream_t stream)
+{
+    unsigned long long need = 0, seen = 0;
+    memcpy(&need, w + 4, sizeof(need));
+    memcpy(&seen, w + 6, sizeof(seen));
+    hipMemsetAsync(h->d_info + 1, 0, 7 * sizeof(int), stream);
+    set_error("potrf panel kernel: a progress-counter wait expired (device hang guard): row block %d waited for "
+              "counter %d to reach %llu, last saw %llu", w[2], w[3], need, seen);
+    return GPIRT_E_HIP;
+}
+
 }  // namespace gpirt
 
 using namespace gpirt;
@@ -98,12 +111,27 @@ int gpirt_create(gpirt_handle_t* out, int device, void* stream)
     gpirt_handle_s* h = new (std::nothrow) gpirt_handle_s();
     if (!h) { set_error("out of host memory"); return GPIRT_E_ALLOC; }
     h->device = cur;
+    h->n_cu = prop.multiProcessorCount;
     // stream == NULL is HIP's default (null) stream, like every hipStream_t argument
     h->stream = (hipStream_t)stream;
     h->own_stream = false;
-    GP_HIP(hipMalloc(&h->d_info, 64));
-    GP_HIP(hipMemset(h->d_info, 0, 64));
-    GP_HIP(hipHostMalloc(&h->h_info, 64, hipHostMallocDefault));
+    // Every word the kernels poll or publish (potrf info + hang-guard record, the panel kernel's progress
+    // counters) is cleared ON THE HANDLE'S STREAM and the stream is drained before the handle is handed out:
+    // a null-stream hipMemset is not ordered against a hipStreamNonBlocking stream (gpirt_create_own_stream),
+    // so a kernel launched there could start on recycled, uncleared words or have its counters zeroed under it.
+    const size_t prog_cap = 2048;        // 64-row blocks: n <= 131008 without growing
+    hipError_t e = hipMalloc(&h->d_info, 64);
+    if (e == hipSuccess) e = hipMalloc(&h->d_prog, prog_cap * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipHostMalloc(&h->h_info, 64, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMemsetAsync(h->d_info, 0, 64, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->d_prog, 0, prog_cap * sizeof(unsigned long long), h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {
+        set_error("handle workspace setup failed: %s", hipGetErrorString(e));
+        gpirt_destroy(h);
+        return GPIRT_E_ALLOC;
+    }
+    h->prog_cap = prog_cap;
     *out = h;
     return 0;
 }
@@ -141,11 +169,16 @@ int gpirt_synchronize(gpirt_handle_t h)
 
 int gpirt_create_own_stream(gpirt_handle_t* out, int device)
 {
-    GP_TRY(gpirt_create(out, device, nullptr));
+    GP_ARG(out != nullptr);
+    *out = nullptr;
+    GP_TRY(check_device(device < 0 ? 0 : device));
+    if (device >= 0) GP_HIP(hipSetDevice(device));
     hipStream_t st = nullptr;
     hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-    if (e != hipSuccess) { gpirt_destroy(*out); *out = nullptr; set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); return GPIRT_E_HIP; }
-    (*out)->stream = st;
+    if (e != hipSuccess) { set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); return GPIRT_E_HIP; }
+    // the handle is set up ON this stream (gpirt_create clears its workspace there and drains it)
+    const int rc = gpirt_create(out, device, st);
+    if (rc != 0) { hipStreamDestroy(st); return rc; }
     (*out)->own_stream = true;
     return 0;
 }
@@ -187,14 +220,10 @@ int gpirt_calibrate_mfma_f64(gpirt_handle_t h, double* tflops)
 
 static int finish_info(gpirt_handle_t h)
 {
-    GP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    GP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 8 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     GP_HIP(hipStreamSynchronize(h->stream));
     const int info = *h->h_info;
-    if (h->h_info[1] != 0) {
-        hipMemsetAsync(h->d_info + 1, 0, sizeof(int), h->stream);
-        set_error("potrf panel kernel: a progress-counter wait expired (device hang guard)");
-        return GPIRT_E_HIP;
-    }
+    if (h->h_info[1] != 0) return report_panel_guard(h, h->h_info, h->stream);
     if (info > 0) set_error("chol(): decomposition failed (leading minor of order %d is not positive definite)", info);
     return info;
 }
@@ -369,26 +398,37 @@ int gpirt_prof_enable(gpirt_handle_t h, int on)
     return 0;
 }
 
+static int prof_resolve(gpirt_handle_t h)
+{
+    if (h->prof.pending.empty()) return 0;
+    GP_HIP(hipStreamSynchronize(h->stream));
+    if (h->side) GP_HIP(hipStreamSynchronize(h->side));
+    for (auto& pp : h->prof.pending) {
+        float ms = 0.f;
+        GP_HIP(hipEventElapsedTime(&ms, pp.e0, pp.e1));
+        h->prof.ms[pp.cls] += ms;
+        h->prof.launches[pp.cls] += 1;
+        h->prof.flops[pp.cls] += pp.flops;
+        h->prof.free_pairs.push_back(pp);
+    }
+    h->prof.pending.clear();
+    return 0;
+}
+
+int gpirt_prof_syrk(gpirt_handle_t h, int cls, int reset, double* total_ms, int64_t* launches, double* flops)
+{
+    GP_ARG(h != nullptr && cls >= 0 && cls < PROF_CLASSES);
+    GP_TRY(prof_resolve(h));
+    if (total_ms) *total_ms = h->prof.ms[cls];
+    if (launches) *launches = h->prof.launches[cls];
+    if (flops) *flops = h->prof.flops[cls];
+    if (reset) { h->prof.ms[cls] = 0.0; h->prof.launches[cls] = 0; h->prof.flops[cls] = 0.0; }
+    return 0;
+}
+
 int gpirt_prof_trailing(gpirt_handle_t h, int reset, double* total_ms, int64_t* launches, double* flops)
 {
-    GP_ARG(h != nullptr);
-    if (!h->prof.pending.empty()) {
-        GP_HIP(hipStreamSynchronize(h->stream));
-        for (auto& pp : h->prof.pending) {
-            float ms = 0.f;
-            GP_HIP(hipEventElapsedTime(&ms, pp.e0, pp.e1));
-            h->prof.trailing_ms += ms;
-            h->prof.trailing_launches += 1;
-            h->prof.trailing_flops += pp.flops;
-            h->prof.free_pairs.push_back(pp);
-        }
-        h->prof.pending.clear();
-    }
-    if (total_ms) *total_ms = h->prof.trailing_ms;
-    if (launches) *launches = h->prof.trailing_launches;
-    if (flops) *flops = h->prof.trailing_flops;
-    if (reset) { h->prof.trailing_ms = 0.0; h->prof.trailing_launches = 0; h->prof.trailing_flops = 0.0; }
-    return 0;
+    return gpirt_prof_syrk(h, 0, reset, total_ms, launches, flops);
 }
 
 // ---------------------------------------------------------------- R stream (host) ----------
@@ -446,9 +486,10 @@ void gpirt_default_options(gpirt_options* o)
 {
     if (!o) return;
     memset(o, 0, sizeof(*o));
-    o->rng_kind = GPIRT_RNG_ITEM;
+    // the reference's contract: R's own stream replayed draw for draw, draw_theta exactly as src/draw-theta.cpp words it
+    o->rng_kind = GPIRT_RNG_RSTREAM;
     o->seed = 1;
-    o->theta_stabilise = 1;
+    o->theta_stabilise = 0;
     o->fstar_fused = 0;
     o->device = -1;
     o->use_graph = 0;

@@ -40,14 +40,16 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 // ---------------------------------------------------------------- handle -------------------
-// Event-pair profiler for the potrf trailing-update launches: pairs are recorded on the launch
-// stream without synchronising and resolved later by gpirt_prof_trailing().
-struct ProfPair { hipEvent_t e0, e1; double flops; };
+// Event-pair profiler for the syrk launches of the factorisation (the MFMA work of arma::chol): pairs are recorded
+// on the launch stream without synchronising and resolved later by gpirt_prof_syrk().  Classes:
+//   0  trailing update, 128-tile kernel   1  trailing update, 64-tile kernel   2  update inside an outer panel (K = 512)
+constexpr int PROF_CLASSES = 3;
+struct ProfPair { hipEvent_t e0, e1; double flops; int cls; };
 struct Prof {
     bool        enabled = false;
-    double      trailing_ms = 0.0;
-    int64_t     trailing_launches = 0;
-    double      trailing_flops = 0.0;
+    double      ms[PROF_CLASSES] = {};
+    int64_t     launches[PROF_CLASSES] = {};
+    double      flops[PROF_CLASSES] = {};
     std::vector<ProfPair> pending;
     std::vector<ProfPair> free_pairs;
 };
@@ -72,6 +74,8 @@ struct gpirt_handle_s {
     size_t       prog_cap = 0;
     unsigned long long prog_seq = 0;
     long long*   panel_trace = nullptr;   // debug stamps (micro-benchmarks only)
+    int          n_cu = 0;                // compute units of `device` (grid cap of the persistent kernel)
+    bool         panel_attr_set = false;  // dynamic-LDS attribute of panel_ll_kernel set on this device
     // gemm_f64.hip: parts of automatically split-K products
     double*      d_splitk = nullptr;
     size_t       splitk_bytes = 0;

@@ -23,9 +23,11 @@ __device__ __forceinline__ unsigned long long ld_prog(const unsigned long long* 
 // `have` caches the last value seen for this counter so later waits on smaller values cost nothing.
 // `urgent` (uniform): the waiter is the next diagonal owner -- it polls back to back; everybody else naps
 // between polls, which also keeps them from crowding the memory channel that holds the fresh block.
+// On expiry the first work-group to give up records who waited for what in info[2..7] (api.hip:
+// report_panel_guard): waiting row block, awaited row block, value needed, value last seen.
 __device__ __forceinline__ bool wait_prog(const unsigned long long* p, unsigned long long need,
                                           unsigned long long& have, unsigned long long* s_seen, int* info,
-                                          bool urgent = false)
+                                          bool urgent = false, int waiter = -1, int awaited = -1)
 {
     if (have >= need) return true;
     if (threadIdx.x == 0) {
@@ -35,7 +37,14 @@ __device__ __forceinline__ bool wait_prog(const unsigned long long* p, unsigned 
             if (urgent) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(24);
             v = ld_prog(p);
         }
-        if (v < need) { atomicExch(info + 1, 1); v = 0; }
+        if (v < need) {
+            if (atomicCAS(info + 1, 0, 1) == 0) {
+                info[2] = waiter; info[3] = awaited;
+                info[4] = (int)(need & 0xffffffffu); info[5] = (int)(need >> 32);
+                info[6] = (int)(v & 0xffffffffu);    info[7] = (int)(v >> 32);
+            }
+            v = 0;
+        }
         *s_seen = v;
     }
     __syncthreads();

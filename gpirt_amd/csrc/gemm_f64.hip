@@ -529,6 +529,19 @@ static int launch_gemm_trailing(hipStream_t stream, GemmParams p)
     return 0;
 }
 
+// ... and so do the factorisation's 64-tile updates (trailing updates too small for 128-tiles, the K = 512 update
+// between the sub-panels of an outer panel).
+static int launch_gemm_syrk64(hipStream_t stream, GemmParams p)
+{
+    constexpr int T = 64;
+    p.mblocks = (p.M + T - 1) / T;
+    p.nblocks = (p.N + T - 1) / T;
+    const int64_t grid = (int64_t)p.nblocks * p.mblocks - (int64_t)p.nblocks * (p.nblocks - 1) / 2;
+    hipLaunchKernelGGL((gemm_f64_kernel<false, true, 64, 8>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    GP_HIP(hipGetLastError());
+    return 0;
+}
+
 // Panel update of the blocked Cholesky (K <= 64, lower trapezoid) with the factorisation of the next
 // diagonal block fused into work-group 0: C = A[r0:, r0:c1] and the block is C's leading 64 x 64 tile.
 int launch_gemm_update_potf2(hipStream_t stream, int64_t M, int64_t N, int64_t K, const double* P, int64_t ldp,
@@ -676,9 +689,17 @@ int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri,
         p.tri = TRI_SYRK_LOWER;
         if (M < N || ta || !tb) { set_error("trailing syrk mode needs the NT form and M >= N"); return GPIRT_E_ARG; }
         if (gemm_trailing_uses_128(M, N, bg)) return launch_gemm_trailing(stream, p);
-        return launch_gemm_t<64>(stream, ta, tb, p);
+        return launch_gemm_syrk64(stream, p);
     }
     if (tri == TRI_SYRK_LOWER && M < N) { set_error("syrk mode needs M >= N"); return GPIRT_E_ARG; }
+    if (tri == TRI_SYRK_LOWER && !ta && tb) {
+        // the factorisation's own updates (only potrf.hip asks for this mode): same split between the tile sizes as
+        // every other product, but under the PAD = 8 names, so traces tell them apart from draw_theta's NT product
+        const int64_t mb_ = (M + 127) / 128, nb_ = (N + 127) / 128;
+        static const int t128_min_ = getenv("GPIRT_T128_MIN") ? atoi(getenv("GPIRT_T128_MIN")) : 448;
+        if (nb_ * mb_ - nb_ * (nb_ - 1) / 2 >= t128_min_) return launch_gemm_trailing(stream, p);
+        return launch_gemm_syrk64(stream, p);
+    }
     // 128-tiles when they already give every CU >= 2 work-groups, 64-tiles otherwise
     const int64_t mb = (M + 127) / 128, nb = (N + 127) / 128;
     int64_t blocks128 = (tri == TRI_SYRK_LOWER) ? nb * mb - nb * (nb - 1) / 2 : mb * nb;

@@ -109,6 +109,9 @@ struct BetaArgs {
 int launch_draw_beta(hipStream_t stream, const BetaArgs& a);
 int launch_linear_mean(hipStream_t stream, const double* x, int64_t n, const double* beta, int64_t m, double* mu);
 
+// api.hip: turns the hang-guard record of the panel kernel (info[1..7]) into the error message and clears it
+int report_panel_guard(gpirt_handle_t h, const int* info_words, hipStream_t stream);
+
 // misc
 int launch_axpy_irf(hipStream_t stream, double* acc, const double* fstar, int64_t count);
 int launch_advance_pos(hipStream_t stream, uint64_t* pos, uint64_t delta);

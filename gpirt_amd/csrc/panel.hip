@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
             if (j > 0) {
                 double breg[16];
                 d4 XI[4];
-                if (!wait_prog(o_prog, p.base + 1, have, &s_seen, p.info)) return;
+                if (!wait_prog(o_prog, p.base + 1, have, &s_seen, p.info, false, cb0 + Rr, cb0 + j)) return;
                 load_block_regs(breg, A, lda, n, orow0, p.K0);
                 load_strip(XI, A, lda, n, row0, p.K0, PB);
                 for (int k = 0; k < j; ++k) {
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
 #pragma unroll
                     for (int J = 0; J < 4; ++J) XC[J] = XI[J];
                     if (k + 1 < j) {
-                        if (!wait_prog(o_prog, p.base + (unsigned long long)(k + 2), have, &s_seen, p.info)) return;
+                        if (!wait_prog(o_prog, p.base + (unsigned long long)(k + 2), have, &s_seen, p.info, false, cb0 + Rr, cb0 + j)) return;
                         const int64_t kc = p.K0 + (int64_t)(k + 1) * PB;
                         load_block_regs(breg, A, lda, n, orow0, kc);
                         load_strip(XI, A, lda, n, row0, kc, PB);
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
             }
             // ---- X = T L_jj^{-T}
             PANEL_STAMP(1);
-            if (!wait_prog(o_prog, p.base + (unsigned long long)(j + 1), have, &s_seen, p.info, Rr == j + 1)) return;
+            if (!wait_prog(o_prog, p.base + (unsigned long long)(j + 1), have, &s_seen, p.info, Rr == j + 1, cb0 + Rr, cb0 + j)) return;
             PANEL_STAMP(2);
             {
                 double v[16];
@@ -305,25 +305,27 @@ int launch_panel_ll(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, 
     if (K0 >= c1) return 0;
     const int64_t need = (n + PB - 1) / PB + 1;
     if ((int64_t)h->prog_cap < need) {
-        // counters only ever grow (epochs), so a fresh zeroed array is always consistent
+        // (gpirt_create sizes the array for n <= 131008, so this is the rare path.)  Counters only ever grow
+        // (epochs), so a fresh zeroed array is always consistent -- provided the fill is ORDERED before the launch:
+        // it is issued on the launch stream and drained, never on the null stream (a hipStreamNonBlocking stream
+        // does not wait for it).
         GP_HIP(hipStreamSynchronize(stream));
         if (h->side) GP_HIP(hipStreamSynchronize(h->side));
+        if (h->stream != stream) GP_HIP(hipStreamSynchronize(h->stream));
         if (h->d_prog) GP_HIP(hipFree(h->d_prog));
         h->d_prog = nullptr;
+        h->prog_cap = 0;
         GP_HIP(hipMalloc(&h->d_prog, (size_t)need * sizeof(unsigned long long)));
-        GP_HIP(hipMemset(h->d_prog, 0, (size_t)need * sizeof(unsigned long long)));
+        GP_HIP(hipMemsetAsync(h->d_prog, 0, (size_t)need * sizeof(unsigned long long), stream));
+        GP_HIP(hipStreamSynchronize(stream));
         h->prog_cap = (size_t)need;
     }
-    static int n_cu = 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipDeviceProp_t prop;
-        GP_HIP(hipGetDeviceProperties(&prop, h->device));
-        n_cu = prop.multiProcessorCount;
+    if (!h->panel_attr_set) {
         GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_ll_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel_ll_smem_bytes()));
-        attr_set = true;
+        h->panel_attr_set = true;
     }
+    const int n_cu = h->n_cu;
     PanelArgs p;
     p.A = A; p.lda = lda; p.n = n; p.K0 = K0; p.c1 = c1;
     p.prog = h->d_prog;

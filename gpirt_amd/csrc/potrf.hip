@@ -105,6 +105,36 @@ __global__ void zero_upper_kernel(double* __restrict__ A, int64_t n, int64_t lda
 
 namespace {
 
+// event pair around one syrk launch of the factorisation (only while gpirt_prof_enable is on)
+int prof_begin(gpirt_handle_t h, hipStream_t stream, ProfPair& pp)
+{
+    pp = ProfPair{nullptr, nullptr, 0.0, 0};
+    if (!h->prof.enabled) return 0;
+    if (!h->prof.free_pairs.empty()) { pp = h->prof.free_pairs.back(); h->prof.free_pairs.pop_back(); }
+    else { GP_HIP(hipEventCreate(&pp.e0)); GP_HIP(hipEventCreate(&pp.e1)); }
+    GP_HIP(hipEventRecord(pp.e0, stream));
+    return 0;
+}
+int prof_end(gpirt_handle_t h, hipStream_t stream, ProfPair& pp, int cls, int64_t M, int64_t N, int64_t K)
+{
+    if (!pp.e0) return 0;
+    GP_HIP(hipEventRecord(pp.e1, stream));
+    // algorithmic flops of the lower trapezoid: 2 K (M N - N (N - 1) / 2)
+    pp.flops = 2.0 * (double)K * ((double)M * (double)N - 0.5 * (double)N * (double)(N - 1));
+    pp.cls = cls;
+    h->prof.pending.push_back(pp);
+    return 0;
+}
+// C[M x N lower trapezoid] -= P P^T inside an outer panel (between its sub-panels), profiled as class 2
+int panel_update(gpirt_handle_t h, hipStream_t stream, int64_t M, int64_t N, int64_t K, const double* P, int64_t ldp,
+                 double* C, int64_t ldc)
+{
+    ProfPair pp;
+    GP_TRY(prof_begin(h, stream, pp));
+    GP_TRY(launch_gemm(h, stream, false, true, TRI_SYRK_LOWER, M, N, K, -1.0, P, ldp, P, ldp, 1.0, C, ldc));
+    return prof_end(h, stream, pp, 2, M, N, K);
+}
+
 int env_int(const char* name, int dflt)
 {
     const char* v = getenv(name);
@@ -136,8 +166,7 @@ int factor_panel(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int
             const int64_t k1 = (k0 + nbp < c1) ? k0 + nbp : c1;
             GP_TRY(launch_panel_ll(h, stream, A, n, lda, k0, k1));
             if (k1 < c1)      // A[k1:n, k1:c1] -= A[k1:n, k0:k1] A[k1:c1, k0:k1]^T
-                GP_TRY(launch_gemm(h, stream, false, true, TRI_SYRK_LOWER, n - k1, c1 - k1, k1 - k0, -1.0,
-                                   A + k1 + k0 * lda, lda, A + k1 + k0 * lda, lda, 1.0, A + k1 + k1 * lda, lda));
+                GP_TRY(panel_update(h, stream, n - k1, c1 - k1, k1 - k0, A + k1 + k0 * lda, lda, A + k1 + k1 * lda, lda));
         }
         return 0;
     }
@@ -174,14 +203,8 @@ int trailing(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t
              int64_t lo, int64_t hi, bool* fused_potf2 = nullptr, bool background = false)
 {
     const int64_t M = n - lo, N = hi - lo, K = c1 - K0;
-    // the roofline figure covers the launches of the dominant kernel only (128-tile syrk)
-    const bool prof = h->prof.enabled && (background || gemm_trailing_uses_128(M, N, background));
-    ProfPair pp{nullptr, nullptr, 0.0};
-    if (prof) {
-        if (!h->prof.free_pairs.empty()) { pp = h->prof.free_pairs.back(); h->prof.free_pairs.pop_back(); }
-        else { GP_HIP(hipEventCreate(&pp.e0)); GP_HIP(hipEventCreate(&pp.e1)); }
-        GP_HIP(hipEventRecord(pp.e0, stream));
-    }
+    ProfPair pp;
+    GP_TRY(prof_begin(h, stream, pp));
     static const bool fuse = !(getenv("GPIRT_FUSE_POTF2") && atoi(getenv("GPIRT_FUSE_POTF2")) == 2);
     if (fused_potf2) *fused_potf2 = false;
     if (fused_potf2 && fuse && !panel_persistent() && !gemm_trailing_uses_128(M, N)) {
@@ -190,17 +213,11 @@ int trailing(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t
         GP_TRY(launch_gemm_update_potf2(stream, M, N, K, A + lo + K0 * lda, lda, A + lo + lo * lda, lda, nb_next,
                                         (int)lo, h->d_info));
         *fused_potf2 = true;
-        return 0;
+        return prof_end(h, stream, pp, 1, M, N, K);
     }
     GP_TRY(launch_gemm(h, stream, false, true, background ? TRI_SYRK_LOWER_BACKGROUND : TRI_SYRK_LOWER_TRAILING, M, N, K,
                        -1.0, A + lo + K0 * lda, lda, A + lo + K0 * lda, lda, 1.0, A + lo + lo * lda, lda));
-    if (prof) {
-        GP_HIP(hipEventRecord(pp.e1, stream));
-        // algorithmic flops of the lower trapezoid: 2 K (M N - N (N - 1) / 2)
-        pp.flops = 2.0 * (double)K * ((double)M * (double)N - 0.5 * (double)N * (double)(N - 1));
-        h->prof.pending.push_back(pp);
-    }
-    return 0;
+    return prof_end(h, stream, pp, gemm_trailing_uses_128(M, N, background) ? 0 : 1, M, N, K);
 }
 
 
@@ -266,8 +283,7 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
                 GP_TRY(trailing(h, stream, A, n, lda, K0, c1, cA, c2));
                 GP_HIP(hipEventRecord(h->ev_mid, stream));
                 GP_HIP(hipStreamWaitEvent(h->side, h->ev_mid, 0));
-                GP_TRY(launch_gemm(h, h->side, false, true, TRI_SYRK_LOWER, n - cA, c2 - cA, cA - c1, -1.0,
-                                   A + cA + c1 * lda, lda, A + cA + c1 * lda, lda, 1.0, A + cA + cA * lda, lda));
+                GP_TRY(panel_update(h, h->side, n - cA, c2 - cA, cA - c1, A + cA + c1 * lda, lda, A + cA + cA * lda, lda));
                 if (hold_rest == 1 || (hold_rest == 3 && gemm_trailing_uses_128(n - c2, n - c2))) {
                     // The large (128-tile) updates are released only once the second sub-panel is ready to go as
                     // well: a panel wave holds all 512 registers of its SIMD slice and cannot squeeze in beside resident

@@ -284,6 +284,16 @@ int do_factor(gpirt_sampler_s* s)
     return launch_potrf_lower(s->h, st, s->L, s->n, s->n, false, !s->sticky_info); // :78
 }
 
+// draw_theta's CDF came out 0/0 for some respondents: the reference reads theta_star[N] out of bounds there
+// (src/draw-theta.cpp:28, quirk Q5); the device wrote NaN and counted them -- the chain cannot go on.
+int report_degenerate_theta(gpirt_sampler_s* s, int count)
+{
+    hipMemsetAsync(s->flags + 1, 0, sizeof(int), s->h->stream);
+    set_error("draw_theta: exp() underflowed for %d respondent(s) (0/0 in the reference's CDF, src/draw-theta.cpp:23-34); "
+              "theta_stabilise = 1 draws from the same distribution without the underflow", count);
+    return GPIRT_E_NUMERIC;
+}
+
 inline void mark(gpirt_sampler_s* s, int idx)
 {
     if (s->timing) hipEventRecord(s->ev[idx], s->h->stream);
@@ -320,8 +330,10 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
     GP_A(s->mu, n * m);      GP_A(s->mu_star, N * m + 1); GP_A(s->fstar, N * m + 1); GP_A(s->L, n * n);
     GP_A(s->tstar, N + 1);   GP_A(s->rhs, n * (N + m) + 2); GP_A(s->mean, N * m + 1); GP_A(s->s, N + 1);
     GP_A(s->Gpm, ((N + 127) / 128 * 128) * 2 * m + 2); GP_A(s->logpost, N * n + 2); GP_A(s->irf_sum, N * m + 1);
-    if (hipMemset(s->Gpm, 0, sizeof(double) * (size_t)(((N + 127) / 128 * 128) * 2 * m + 2)) != hipSuccess) {   // its padding rows stay zero
-        set_error("hipMemset(Gpm) failed"); gpirt_sampler_destroy(s); return GPIRT_E_HIP;
+    // padding rows stay zero; cleared on the handle's stream (drained below) -- a null-stream hipMemset is not
+    // ordered against a non-blocking stream
+    if (hipMemsetAsync(s->Gpm, 0, sizeof(double) * (size_t)(((N + 127) / 128 * 128) * 2 * m + 2), st) != hipSuccess) {
+        set_error("hipMemsetAsync(Gpm) failed"); gpirt_sampler_destroy(s); return GPIRT_E_HIP;
     }
     GP_A(s->pm, 2 * m);      GP_A(s->ps, 2 * m);       GP_A(s->step, 2 * m);
     GP_A(s->ess_k, m);       GP_A(s->flags, 4);
@@ -624,19 +636,23 @@ int gpirt_sampler_iteration(gpirt_sampler_t s, int* iter)
     return 0;
 }
 
+int gpirt_sampler_set_iteration(gpirt_sampler_t s, int iter)
+{
+    GP_ARG(s && s->initialised && iter >= 0);
+    if (stream_mode(s)) { set_error("the R-stream replay has no iteration-keyed sub-streams"); return GPIRT_E_ARG; }
+    s->iter = iter;
+    return 0;
+}
+
 int gpirt_sampler_check(gpirt_sampler_t s)
 {
     GP_ARG(s != nullptr);
     gpirt_handle_t h = s->h;
     hipStream_t st = h->stream;
-    GP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    GP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
     GP_HIP(hipMemcpyAsync(s->h_flags, s->flags, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     GP_HIP(hipStreamSynchronize(st));
-    if (h->h_info[1] != 0) {
-        hipMemsetAsync(h->d_info + 1, 0, sizeof(int), st);
-        set_error("potrf panel kernel: a progress-counter wait expired (device hang guard)");
-        return GPIRT_E_HIP;
-    }
+    if (h->h_info[1] != 0) return report_panel_guard(h, h->h_info, st);
     if (*h->h_info > 0) {
         set_error("chol(): decomposition failed (leading minor of order %d is not positive definite)", *h->h_info);
         return *h->h_info;
@@ -645,6 +661,7 @@ int gpirt_sampler_check(gpirt_sampler_t s)
         set_error("sampler state is not finite (flag %d): elliptical slice sampler did not terminate or the R stream window overflowed", s->h_flags[0]);
         return s->h_flags[0];
     }
+    if (s->h_flags[1] != 0) return report_degenerate_theta(s, s->h_flags[1]);
     return 0;
 }
 
@@ -751,7 +768,7 @@ int gpirt_mcmc(const double* h_y, int64_t n, int64_t m, const double* h_theta0, 
     double *snap_f = nullptr, *snap_small = nullptr;       // snap_small: [theta (n) | beta (2m)]
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_snap = nullptr, ev_flags = nullptr;
-    int* h_poll = nullptr;                                 // pinned: [potrf info, flag0, flag1, panel guard]
+    int* h_poll = nullptr;                                 // pinned: [potrf info + panel guard record (8) | flag0, flag1]
     auto cleanup = [&]() {
         if (snap_f) hipFree(snap_f);
         if (snap_small) hipFree(snap_small);
@@ -792,23 +809,20 @@ int gpirt_mcmc(const double* h_y, int64_t n, int64_t m, const double* h_theta0, 
     };
     auto post_flags = [&]() -> int {                        // async read-back of the sticky error words
         hipStream_t st = h->stream;
-        if (hipMemcpyAsync(h_poll, h->d_info, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipMemcpyAsync(h_poll + 3, h->d_info + 1, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipMemcpyAsync(h_poll + 1, s->flags, 2 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        if (hipMemcpyAsync(h_poll, h->d_info, 8 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(h_poll + 8, s->flags, 2 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipEventRecord(ev_flags, st) != hipSuccess)
             return fail_hip("flag read-back");
         return 0;
     };
     auto inspect_flags = [&]() -> int {
-        if (h_poll[3] != 0) {
-            set_error("potrf panel kernel: a progress-counter wait expired (device hang guard)");
-            return GPIRT_E_HIP;
-        }
+        if (h_poll[1] != 0) return report_panel_guard(h, h_poll, h->stream);
         if (h_poll[0] > 0) {
             set_error("chol(): decomposition failed (leading minor of order %d is not positive definite)", h_poll[0]);
             return h_poll[0];
         }
-        if (h_poll[1] != 0) { set_error("sampler state is not finite (flag %d)", h_poll[1]); return h_poll[1]; }
+        if (h_poll[8] != 0) { set_error("sampler state is not finite (flag %d)", h_poll[8]); return h_poll[8]; }
+        if (h_poll[9] != 0) return report_degenerate_theta(s, h_poll[9]);
         return 0;
     };
     const int total = S_it + B_it;
@@ -821,7 +835,7 @@ int gpirt_mcmc(const double* h_y, int64_t n, int64_t m, const double* h_theta0, 
             hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&ev_snap, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ev_flags, hipEventDisableTiming) != hipSuccess ||
-            hipHostMalloc(&h_poll, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess)
+            hipHostMalloc(&h_poll, 16 * sizeof(int), hipHostMallocDefault) != hipSuccess)
             rc = fail_hip("allocation");
     }
     s->sticky_info = true;            // potrf no longer clears its info word: first failure sticks

@@ -63,7 +63,8 @@ __global__ __launch_bounds__(128) void lowrank_s_kernel(const double* __restrict
         if (k < w) red[k] += red[k + w];
         __syncthreads();
     }
-    if (k == 0) s[j] = 1.0 - sqrt(red[0]);
+    // the reference's sum of squares cannot be negative; the quadratic form can, by cancellation, when it is ~0
+    if (k == 0) s[j] = 1.0 - sqrt(fmax(red[0], 0.0));
 }
 
 // exclusive count of RNG-consuming grid points (s_i > 0 and finite) -- R-stream replay only
@@ -126,8 +127,14 @@ __global__ void loglik_terms_kernel(const double* __restrict__ fstar, int64_t N,
          g += (int64_t)gridDim.x * blockDim.x) {
         const double v = fstar[g];
         const int64_t o = (g % N) + (g / N) * ldg;
-        Gpm[o] = -ll_term(1.0 * v);
-        Gpm[o + ldg * m] = -ll_term(-1.0 * v);
+        // |f*| > ~709.8 overflows exp(): the reference adds -inf for the responses that see it and skips the others
+        // (isnan(y), src/log-likelihood.cpp:16); in the GEMM form the skipped ones would be 0 * -inf = NaN, so -inf
+        // is held at a finite -1e300 (exp() of the sum is still exactly 0).  NaN stays NaN.
+        double gp = -ll_term(1.0 * v), gm = -ll_term(-1.0 * v);
+        if (gp == -INFINITY) gp = -1e300;
+        if (gm == -INFINITY) gm = -1e300;
+        Gpm[o] = gp;
+        Gpm[o + ldg * m] = gm;
     }
 }
 

@@ -6,8 +6,9 @@
 //   split the rows in two, solve the first half, fold it into the second half with ONE fp64-MFMA
 //   gemm (K = half the rows, so the deep products carry the flops), recurse.  The leaves run the
 //   MFMA-layout substitution of solve64.h: off-diagonal 16 x 16 coupling by MFMA, the 16 x 16 diagonal
-//   blocks through their inverses (formed on the fly in LDS; nothing larger than 16 x 16 is ever
-//   inverted: S has condition ~1e6 by construction).
+//   blocks through their inverses (formed on the fly in LDS).  The 512-row leaves of the recursion apply explicit
+//   inverses of L's 512 x 512 diagonal blocks (1024 x 1024 for thin solves), built once per factor: only DIAGONAL
+//   BLOCKS OF L are ever inverted -- their condition is bounded by cond(L) = sqrt(cond(S)) ~ 1e3.
 #include "common.h"
 #include "kernels.h"
 #include "solve64.h"

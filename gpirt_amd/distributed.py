@@ -52,33 +52,41 @@ class ShardedSampler:
         if theta not in ("gather", "allreduce"):
             raise ValueError("theta must be 'gather' or 'allreduce'")
         self.theta_mode = theta if self.world > 1 else "local"
+        self._views = {}
         if self.theta_mode == "gather":
             self.i0, self.i1 = item_range(self.n, self.rank, self.world)     # this rank's block of respondents
             self.engine.set_theta_block(y[self.i0:self.i1, :], self.i0, m)
-            self._equal_shards = (m % self.world == 0)
+            # The gather path is chosen ONCE, from facts every rank agrees on (backend, m % world): a rank that
+            # switched paths on its own (e.g. after a failed collective) would leave its peers in a different
+            # collective.  Equal shards on a backend with the flat all-gather (RCCL, gloo) use it; anything else
+            # all-reduces disjoint supports.
+            self._flat_gather = (m % self.world == 0) and hasattr(dist, "all_gather_into_tensor")
+
+    def _view(self, name):
+        """torch view of an engine buffer, created once (the buffers live as long as the engine)"""
+        v = self._views.get(name)
+        if v is None:
+            v = self._views[name] = self.engine.device_tensor(name)
+        return v
 
     # -- collectives on the engine's buffers ------------------------------------------------
     def _allreduce_logpost(self):
         if self.world > 1:
-            self.dist.all_reduce(self.engine.device_tensor("logpost"))
+            self.dist.all_reduce(self._view("logpost"))
 
     def _gather_fstar(self):
         """every rank's f* columns -> the full N* x m array on every rank (column-major: shards are contiguous)"""
-        e = self.engine
-        full, loc = e.device_tensor("fstar_full"), e.device_tensor("fstar")
-        if self._equal_shards:
-            try:
-                self.dist.all_gather_into_tensor(full, loc)
-                return
-            except (RuntimeError, NotImplementedError, AttributeError):
-                self._equal_shards = False          # backend without the flat all-gather: fall through
+        full, loc = self._view("fstar_full"), self._view("fstar")
+        if self._flat_gather:
+            self.dist.all_gather_into_tensor(full, loc)
+            return
         N = full.numel() // self.m_total
         full.zero_()
         full[N * self.lo: N * self.hi].copy_(loc[: N * (self.hi - self.lo)])
         self.dist.all_reduce(full)                  # disjoint supports: the sum is the concatenation, exactly
 
     def _combine_theta(self):
-        self.dist.all_reduce(self.engine.device_tensor("theta_stage"))   # zero outside each rank's block
+        self.dist.all_reduce(self._view("theta_stage"))   # zero outside each rank's block
 
     def _factor(self):
         if self.chol == "replicated" or self.world == 1:
@@ -88,7 +96,7 @@ class ShardedSampler:
                 self.engine.factor()
             else:
                 self.engine.skip_factor()
-            self.dist.broadcast(self.engine.device_tensor("L"), src=0)
+            self.dist.broadcast(self._view("L"), src=0)
 
     def init(self):
         self.engine.init()

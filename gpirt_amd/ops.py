@@ -211,6 +211,17 @@ class Handle:
         check(self.lib.gpirt_prof_trailing(self._h, int(reset), C.byref(ms), C.byref(n), C.byref(fl)))
         return ms.value, n.value, fl.value
 
+    SYRK_CLASSES = ("trailing_128tile", "trailing_64tile", "in_panel_k512")
+
+    def prof_syrk(self, reset: bool = False) -> dict:
+        """Event-timed syrk launches of the factorisation per class: {name: (ms, launches, algorithmic flops)}."""
+        out = {}
+        for cls, name in enumerate(self.SYRK_CLASSES):
+            ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+            check(self.lib.gpirt_prof_syrk(self._h, cls, int(reset), C.byref(ms), C.byref(n), C.byref(fl)))
+            out[name] = (ms.value, n.value, fl.value)
+        return out
+
 
 class RStream:
     """R's default RNG on the host: RStream(seed) == set.seed(seed); .rnorm(n) == rnorm(n)."""

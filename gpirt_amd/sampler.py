@@ -167,6 +167,9 @@ class Sampler:
         check(self.lib.gpirt_sampler_iteration(self._s, C.byref(it)))
         return it.value
 
+    def set_iteration(self, it: int):
+        check(self.lib.gpirt_sampler_set_iteration(self._s, int(it)))
+
     _SHAPES = {"theta": "n", "f": "nm", "beta": "2m", "mu": "nm", "mu_star": "Nm", "fstar": "Nm", "L": "nn",
                "logpost": "Nn", "irf_sum": "Nm", "s": "N", "mean": "Nm", "nu": "nm", "z": "nm", "y": "nm"}
 

@@ -222,6 +222,9 @@ int gpirt_sampler_factor(gpirt_sampler_t s);             /* :76-78 / :95-97 */
 int gpirt_sampler_skip_factor(gpirt_sampler_t s);
 int gpirt_sampler_accumulate_irf(gpirt_sampler_t s);     /* :103 */
 int gpirt_sampler_iteration(gpirt_sampler_t s, int* iter);
+/* Sets the completed-iteration counter (the GPIRT_RNG_ITEM sub-streams are keyed by it): lets a second sampler
+ * replay a stage of another one's iteration on copied state (bench.py's in-run check of the draw_fstar forms). */
+int gpirt_sampler_set_iteration(gpirt_sampler_t s, int iter);
 int gpirt_sampler_check(gpirt_sampler_t s);              /* syncs; returns potrf info / GPIRT_E_* */
 /* Device pointer of a named state array ("theta","f","beta","mu","mu_star","fstar","L","logpost",
  * "irf_sum","ess_k") and its element count; the pointer stays valid until destroy. */
@@ -238,6 +241,11 @@ int gpirt_sampler_stage_times(gpirt_sampler_t s, double* ms_out, int max_stages,
  * reset (hipEvents on the launch stream); the roofline figure of bench.py. */
 int gpirt_prof_trailing(gpirt_handle_t h, int reset, double* total_ms, int64_t* launches,
                         double* flops);
+/* The same per class of syrk launch inside arma::chol's replacement (src/gpirtMCMC.cpp:17,78,97):
+ * cls 0 = trailing update on the 128-tile kernel (what gpirt_prof_trailing reports), 1 = trailing update on the
+ * 64-tile kernel, 2 = the K = 512 update between the two sub-panels of an outer panel.  flops are the
+ * algorithmic ones of the lower trapezoid, 2 K (M N - N (N - 1) / 2). */
+int gpirt_prof_syrk(gpirt_handle_t h, int cls, int reset, double* total_ms, int64_t* launches, double* flops);
 int gpirt_prof_enable(gpirt_handle_t h, int on);
 
 #ifdef __cplusplus

@@ -41,18 +41,43 @@ static int rng_is_default_mt(SEXP seedvec)
 SEXP _gpirt_gpirtMCMC(SEXP ySEXP, SEXP thetaSEXP, SEXP sample_iterationsSEXP, SEXP burn_iterationsSEXP,
                       SEXP beta_prior_meansSEXP, SEXP beta_prior_sdsSEXP, SEXP beta_step_sizesSEXP)
 {
+    /* Rcpp's input_parameter<const arma::mat&> / <arma::vec> / <const int> (src/RcppExports.cpp:20-26) coerce
+     * whatever storage mode R hands over (an integer-storage response_matrix passes is.response_matrix,
+     * R/response_matrix.R:109-115) and as<arma::mat> insists on a matrix: do both by hand, PROTECTed, before
+     * anything is dereferenced. */
+    int nprot = 0;
+    SEXP yR = PROTECT(coerceVector(ySEXP, REALSXP)); ++nprot;
+    SEXP thR = PROTECT(coerceVector(thetaSEXP, REALSXP)); ++nprot;
+    SEXP pmR = PROTECT(coerceVector(beta_prior_meansSEXP, REALSXP)); ++nprot;
+    SEXP psR = PROTECT(coerceVector(beta_prior_sdsSEXP, REALSXP)); ++nprot;
+    SEXP stR = PROTECT(coerceVector(beta_step_sizesSEXP, REALSXP)); ++nprot;
     SEXP dim = getAttrib(ySEXP, R_DimSymbol);
+    if (TYPEOF(dim) != INTSXP || LENGTH(dim) != 2) { UNPROTECT(nprot); error("gpirt-hip: y must be a matrix"); }
     const int64_t n = INTEGER(dim)[0], m = INTEGER(dim)[1];
+    if (n < 1 || m < 1) { UNPROTECT(nprot); error("gpirt-hip: y must have at least one row and one column"); }
+    if ((int64_t)XLENGTH(thR) != n) { UNPROTECT(nprot); error("gpirt-hip: theta must have one value per row of y (%ld)", (long)n); }
+    {
+        SEXP mats[3] = { beta_prior_meansSEXP, beta_prior_sdsSEXP, beta_step_sizesSEXP };
+        const char* nm[3] = { "beta_prior_means", "beta_prior_sds", "beta_step_sizes" };
+        for (int k = 0; k < 3; ++k) {
+            SEXP d = getAttrib(mats[k], R_DimSymbol);
+            if (TYPEOF(d) != INTSXP || LENGTH(d) != 2 || INTEGER(d)[0] != 2 || (int64_t)INTEGER(d)[1] != m) {
+                UNPROTECT(nprot);
+                error("gpirt-hip: %s must be a 2 x %ld matrix", nm[k], (long)m);
+            }
+        }
+    }
     const int S = asInteger(sample_iterationsSEXP), B = asInteger(burn_iterationsSEXP);
+    if (S == NA_INTEGER || B == NA_INTEGER || S < 0 || B < 0) { UNPROTECT(nprot); error("gpirt-hip: iteration counts must be non-negative integers"); }
     const int64_t N = GPIRT_NGRID;
 
-    SEXP theta = PROTECT(allocMatrix(REALSXP, S + 1, (int)n));
-    SEXP beta = PROTECT(alloc3DArray(REALSXP, 2, (int)m, S + 1));
-    SEXP f = PROTECT(alloc3DArray(REALSXP, (int)n, (int)m, S + 1));
-    SEXP irfs = PROTECT(allocMatrix(REALSXP, (int)N, (int)m));
+    SEXP theta = PROTECT(allocMatrix(REALSXP, S + 1, (int)n)); ++nprot;
+    SEXP beta = PROTECT(alloc3DArray(REALSXP, 2, (int)m, S + 1)); ++nprot;
+    SEXP f = PROTECT(alloc3DArray(REALSXP, (int)n, (int)m, S + 1)); ++nprot;
+    SEXP irfs = PROTECT(allocMatrix(REALSXP, (int)N, (int)m)); ++nprot;
 
     gpirt_options opt;
-    gpirt_default_options(&opt);
+    gpirt_default_options(&opt);                             /* = the reference's contract: R stream, no extras */
     opt.theta_stabilise = asLogical(GetOption1(install("gpirt.hip.theta_stabilise"))) == TRUE;
     opt.fstar_fused = asLogical(GetOption1(install("gpirt.hip.fstar_fused"))) == TRUE;
     opt.reserved[2] = opt.fstar_fused ? asInteger(GetOption1(install("gpirt.hip.kstar_rank"))) : 0;
@@ -74,15 +99,14 @@ SEXP _gpirt_gpirtMCMC(SEXP ySEXP, SEXP thetaSEXP, SEXP sample_iterationsSEXP, SE
         PutRNGstate();                                       /* make .Random.seed current */
         seedvec = findVarInFrame(R_GlobalEnv, install(".Random.seed"));
         if (!rng_is_default_mt(seedvec)) {
-            UNPROTECT(4);
+            UNPROTECT(nprot);
             error("gpirt-hip: rng = \"reference\" needs RNGkind(\"Mersenne-Twister\", \"Inversion\")");
         }
         gpirt_rstream_from_state(&rs, (const uint32_t*)(INTEGER(seedvec) + 2), INTEGER(seedvec)[1]);
         GetRNGstate();
     }
 
-    int rc = gpirt_mcmc(REAL(ySEXP), n, m, REAL(thetaSEXP), S, B, REAL(beta_prior_meansSEXP),
-                        REAL(beta_prior_sdsSEXP), REAL(beta_step_sizesSEXP), &opt, rs, tick, NULL,
+    int rc = gpirt_mcmc(REAL(yR), n, m, REAL(thR), S, B, REAL(pmR), REAL(psR), REAL(stR), &opt, rs, tick, NULL,
                         REAL(theta), REAL(beta), REAL(f), REAL(irfs));
 
     if (rs) {                                                /* hand the advanced stream back to R */
@@ -95,20 +119,20 @@ SEXP _gpirt_gpirtMCMC(SEXP ySEXP, SEXP thetaSEXP, SEXP sample_iterationsSEXP, SE
     PutRNGstate();                                           /* Rcpp::RNGScope, exit */
 
     if (rc != 0) {                                           /* device resources are already released */
-        UNPROTECT(4);
+        UNPROTECT(nprot);
         if (rc == GPIRT_E_INTERRUPT) { Rprintf("\n"); Rf_onintr(); }
         error("%s", rc > 0 ? "chol(): decomposition failed" : gpirt_last_error());
     }
     Rprintf("\r100.000 %% complete\n");                      /* src/gpirtMCMC.cpp:105 */
 
-    SEXP res = PROTECT(allocVector(VECSXP, 4));
-    SEXP names = PROTECT(allocVector(STRSXP, 4));
+    SEXP res = PROTECT(allocVector(VECSXP, 4)); ++nprot;
+    SEXP names = PROTECT(allocVector(STRSXP, 4)); ++nprot;
     SET_VECTOR_ELT(res, 0, theta); SET_STRING_ELT(names, 0, mkChar("theta"));
     SET_VECTOR_ELT(res, 1, beta);  SET_STRING_ELT(names, 1, mkChar("beta"));
     SET_VECTOR_ELT(res, 2, f);     SET_STRING_ELT(names, 2, mkChar("f"));
     SET_VECTOR_ELT(res, 3, irfs);  SET_STRING_ELT(names, 3, mkChar("IRFs"));
     setAttrib(res, R_NamesSymbol, names);
-    UNPROTECT(6);
+    UNPROTECT(nprot);
     return res;
 }
 

@@ -22,14 +22,21 @@ class OracleEngine:
         self.N = len(self.ts)
         self._logpost = torch.zeros(self.N * self.n, dtype=torch.float64)
         self._L = torch.zeros(self.n * self.n, dtype=torch.float64)
+        self._fstar_t = torch.zeros(self.N * self.m, dtype=torch.float64)   # persistent, like the device array
 
     # state views shared with torch (what the collectives operate on)
     def device_tensor(self, name):
-        if name == "fstar":
-            self._fstar_t = torch.from_numpy(np.ascontiguousarray(self.fstar.reshape(-1, order="F")))
-            return self._fstar_t
-        return {"logpost": self._logpost, "L": self._L, "fstar_full": getattr(self, "_fstar_full", None),
+        return {"logpost": self._logpost, "L": self._L, "fstar": self._fstar_t,
+                "fstar_full": getattr(self, "_fstar_full", None),
                 "theta_stage": getattr(self, "_theta_stage", None)}[name]
+
+    @property
+    def fstar(self):
+        return self._fstar_t.numpy().reshape(self.N, self.m, order="F")
+
+    @fstar.setter
+    def fstar(self, value):
+        self._fstar_t.numpy()[:] = np.asarray(value).reshape(-1, order="F")
 
     # respondent-block form of draw_theta (gpirt_sampler_set_theta_block / theta_block / theta_commit)
     def set_theta_block(self, y_block, i0, m_total):

@@ -37,7 +37,8 @@ def test_version_and_options(lib):
     from gpirt_amd import _lib
     assert lib.gpirt_version() >= 100
     o = _lib.default_options()
-    assert o.rng_kind == _lib.RNG_ITEM and o.device == -1 and o.theta_stabilise == 1
+    # the C defaults are the reference's contract: R-stream replay, draw_theta as written
+    assert o.rng_kind == _lib.RNG_RSTREAM and o.device == -1 and o.theta_stabilise == 0 and o.fstar_fused == 0
 
 
 def test_no_gpu_means_loud_failure(lib):
