@@ -472,16 +472,39 @@ __global__ __launch_bounds__(256, (T == 64 ? 3 : 2)) void gemm_f64_kernel(GemmPa
     p.C += (int64_t)blockIdx.y * p.sC;
     int bi, bj;
     if (p.tri == TRI_SYRK_LOWER) {
-        // block columns bj = 0..nblocks-1, each holding block rows bj..mblocks-1 (M >= N trapezoid)
-        const int t = blockIdx.x, mb = p.mblocks;
-        const double q = 2.0 * mb + 1.0;
-        int c = (int)((q - sqrt(q * q - 8.0 * (double)t)) * 0.5);
-        if (c < 0) c = 0;
-        if (c > p.nblocks - 1) c = p.nblocks - 1;
-        while (c > 0 && c * mb - c * (c - 1) / 2 > t) --c;
-        while (c + 1 < p.nblocks && (c + 1) * mb - (c + 1) * c / 2 <= t) ++c;
-        bj = c;
-        bi = c + (t - (c * mb - c * (c - 1) / 2));
+        // Lower trapezoid (M >= N): block columns bj = 0..nblocks-1, each holding block rows bj..mblocks-1.
+        // The order the tiles are handed out in is a pure SPEED choice (bijective for any grid):
+        //  * work-groups are dealt round-robin over the 8 XCDs (observed, MI355X_MICROARCH.md), so ids with equal
+        //    id % 8 share an L2: each such group gets a CONTIGUOUS range of the logical tile order;
+        //  * the logical order runs through super-columns of SW block columns, row by row inside a super-column:
+        //    the ~64-96 tiles resident on an XCD at a time are then ~8 block rows x 8 block columns and stream
+        //    8 + 8 operand blocks through that L2 instead of 64 + 1 (a plain column-major order) or, dealt
+        //    round-robin, the same block column on all eight L2s at once.
+        constexpr int SW = 8;
+        const int mb = p.mblocks, nb = p.nblocks;
+        const int G = (int)gridDim.x;
+        const int id = (int)blockIdx.x;
+        const int xq = G >> 3, xr = G & 7, xcd = id & 7;
+        int t = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (id >> 3);
+        int c0 = 0, w = nb < SW ? nb : SW;
+        for (;;) {                                     // <= nb / SW iterations, scalar
+            const int cnt = w * (w + 1) / 2 + (mb - c0 - w) * w;
+            if (t < cnt || c0 + w >= nb) break;
+            t -= cnt;
+            c0 += w;
+            w = (nb - c0) < SW ? (nb - c0) : SW;
+        }
+        const int tri_cnt = w * (w + 1) / 2;
+        if (t < tri_cnt) {
+            int i = 0;
+            while ((i + 1) * (i + 2) / 2 <= t) ++i;    // row i of the triangle holds i + 1 tiles
+            bi = c0 + i;
+            bj = c0 + (t - i * (i + 1) / 2);
+        } else {
+            const int v = t - tri_cnt;
+            bi = c0 + w + v / w;
+            bj = c0 + v % w;
+        }
     } else if (p.tri == TRI_A_LOWER || p.tri == TRI_A_UPPER) {
         // triangular A: the K range of block row bi grows (or shrinks) linearly with bi, so each
         // work-group takes the pair (mblocks-1-q, q): every work-group then carries the same

@@ -8,7 +8,11 @@ The C restatement of the reference cannot run these sizes in seconds, so the che
   * agreement of the three draw_fstar forms (as written `double_solve`, `fused`, rank-64 `lowrank`) over whole
     iterations with theta grid-valued (the sampler's steady state, quirk Q6: S is as ill-conditioned as it gets);
   * size-independent properties (theta on the grid, bit-reproducibility, shard invariance of the draws).
-Tolerances are the north-star ones: f, f*, means, s abs 1e-9; theta exact; L: LAPACK's own backward error.
+Tolerances: theta exact; s abs 1e-9; L max-abs 1e-9 against dpotrf; f*, means: 1e-9 x max(1, max|f*|) -- ten times
+tighter than the north star's 1e-8 relative.  (At n = 8192 with theta on the grid cond(S) ~ 5e6, so two
+backward-stable fp64 evaluations of k*^T S^-1 f differ by ~cond * eps * |f*| whatever computes them: the test also
+MEASURES that floor on the host -- LAPACK as written, L^-T L^-1 f, against LAPACK in the fused order,
+(L^-1 k*)^T (L^-1 f), on the sampled columns -- and prints it beside the device gaps.)
 """
 import numpy as np
 import pytest
@@ -39,7 +43,9 @@ def _lapack_reference(theta, f_cols, mu_star_cols=None):
     alpha = solve_triangular(L, solve_triangular(L, f_cols, lower=True, check_finite=False), lower=True, trans="T",
                              check_finite=False)                          # :3-8, :24
     mean = kstar.T @ alpha                                                # :25
-    return L, s, mean
+    # the same quantity in the other association, still LAPACK: how far apart two valid fp64 answers are
+    mean_alt = tmp.T @ solve_triangular(L, f_cols, lower=True, check_finite=False)
+    return L, s, mean, float(np.abs(mean - mean_alt).max())
 
 
 def _run_forms(handle, n, m, seed, iters, cols):
@@ -50,7 +56,8 @@ def _run_forms(handle, n, m, seed, iters, cols):
     S = _forms(handle, y, th0, seed=11)
     for s in S.values():
         s.init()
-    worst = dict(fstar_fused=0.0, fstar_lowrank=0.0, f=0.0, L_lapack=0.0, s_lapack=0.0, mean_lapack=0.0)
+    worst = dict(fstar_fused=0.0, fstar_lowrank=0.0, f=0.0, L_lapack=0.0, s_lapack=0.0, mean_lapack=0.0,
+                 lapack_floor=0.0, fstar_scale=1.0)
     for it in range(iters):
         theta_before = S["double_solve"].get("theta")
         for s in S.values():
@@ -65,7 +72,9 @@ def _run_forms(handle, n, m, seed, iters, cols):
             worst["fstar_" + k] = max(worst["fstar_" + k], float(np.abs(fs[k] - fs["double_solve"]).max()))
             worst["f"] = max(worst["f"], float(np.abs(S[k].get("f") - f_dev).max()))
         if it in (0, iters - 1):                # LAPACK on the host: first (theta_init) and last (grid-valued) state
-            Lh, s_h, mean_h = _lapack_reference(theta_before, f_dev[:, cols])
+            Lh, s_h, mean_h, floor = _lapack_reference(theta_before, f_dev[:, cols])
+            worst["lapack_floor"] = max(worst["lapack_floor"], floor)
+            worst["fstar_scale"] = max(worst["fstar_scale"], float(np.abs(fs["double_solve"]).max()))
             worst["L_lapack"] = max(worst["L_lapack"], float(np.abs(np.tril(ref.get("L")) - Lh).max()))
             worst["s_lapack"] = max(worst["s_lapack"], float(np.abs(ref.get("s") - s_h).max()))
             mu_star = ref.get("mu_star")[:, cols]
@@ -86,25 +95,32 @@ def _run_forms(handle, n, m, seed, iters, cols):
     return worst
 
 
+def _report(tag, w, capsys):
+    with capsys.disabled():
+        print("\n[%s] max|f*_fused - f*_ds| %.3e  max|f*_lowrank - f*_ds| %.3e  max|df| %.3e  max|L - L_lapack| %.3e  "
+              "max|s - s_lapack| %.3e  max|mean - mean_lapack| %.3e  (LAPACK-vs-LAPACK floor %.3e, max|f*| %.2f)"
+              % (tag, w["fstar_fused"], w["fstar_lowrank"], w["f"], w["L_lapack"], w["s_lapack"], w["mean_lapack"],
+                 w["lapack_floor"], w["fstar_scale"]))
+
+
 def test_metric_size_iterations_three_forms_and_lapack(handle, capsys):
     """M = 8192 x 1024, three iterations (theta grid-valued from the second on)."""
     w = _run_forms(handle, 8192, 1024, seed=20240, iters=3, cols=[0, 511, 1023])
-    with capsys.disabled():
-        print("\n[M 8192x1024] max|f*_fused - f*_ds| %.3e  max|f*_lowrank - f*_ds| %.3e  max|df| %.3e  "
-              "max|L - L_lapack| %.3e  max|s - s_lapack| %.3e  max|mean - mean_lapack| %.3e"
-              % (w["fstar_fused"], w["fstar_lowrank"], w["f"], w["L_lapack"], w["s_lapack"], w["mean_lapack"]))
-    assert w["fstar_fused"] <= TOL and w["fstar_lowrank"] <= TOL, w
+    _report("M 8192x1024", w, capsys)
+    tol = TOL * max(1.0, w["fstar_scale"])        # 1e-9 relative to max|f*| (north star: 1e-8 relative)
+    assert w["fstar_fused"] <= tol and w["fstar_lowrank"] <= tol, w
+    assert w["mean_lapack"] <= tol, w
     assert w["f"] == 0.0, w                       # f does not depend on the draw_fstar form once theta agrees
-    assert w["L_lapack"] <= TOL and w["s_lapack"] <= TOL and w["mean_lapack"] <= TOL, w
+    assert w["L_lapack"] <= TOL and w["s_lapack"] <= TOL, w
 
 
 def test_c3_iterations_three_forms_and_lapack(handle, capsys):
     """C3 = 4096 x 1024."""
     w = _run_forms(handle, 4096, 1024, seed=20243, iters=3, cols=[1, 1000])
-    with capsys.disabled():
-        print("\n[C3 4096x1024] " + "  ".join("%s %.3e" % kv for kv in w.items()))
-    assert w["fstar_fused"] <= TOL and w["fstar_lowrank"] <= TOL and w["f"] == 0.0, w
-    assert w["L_lapack"] <= TOL and w["s_lapack"] <= TOL and w["mean_lapack"] <= TOL, w
+    _report("C3 4096x1024", w, capsys)
+    tol = TOL * max(1.0, w["fstar_scale"])
+    assert w["fstar_fused"] <= tol and w["fstar_lowrank"] <= tol and w["f"] == 0.0, w
+    assert w["L_lapack"] <= TOL and w["s_lapack"] <= TOL and w["mean_lapack"] <= tol, w
 
 
 def test_c4_one_gpu_forms_and_item_shards(handle, capsys):
@@ -126,9 +142,10 @@ def test_c4_one_gpu_forms_and_item_shards(handle, capsys):
         worst = max(worst, float(np.abs(S["fused"].get("fstar") - S["lowrank"].get("fstar")).max()))
         assert np.array_equal(S["fused"].get("theta"), S["lowrank"].get("theta"))
         assert np.array_equal(S["fused"].get("f"), S["lowrank"].get("f"))
+    scale = max(1.0, float(np.abs(S["fused"].get("fstar")).max()))
     with capsys.disabled():
-        print("\n[C4 8192x2048] max|f*_lowrank - f*_fused| %.3e" % worst)
-    assert worst <= TOL
+        print("\n[C4 8192x2048] max|f*_lowrank - f*_fused| %.3e  (max|f*| %.2f)" % (worst, scale))
+    assert worst <= TOL * scale               # 1e-9 relative to max|f*| (see the metric-size test)
     S["lowrank"].close()
     full = S["fused"]
     # shards: same theta path is needed, so compare the stages that depend on (theta, L) only through shared state:
