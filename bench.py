@@ -11,7 +11,8 @@ responses of the metric's shape, N = 8192 respondents x m = 1024 items, fp64, it
 (GPIRT_RNG_ITEM).  Inputs are resident in HBM before the timed region.  With N > 1 the SAME problem is
 sharded over item columns (strong scaling): for draw_theta the ranks all-gather their f* columns (8 MB) over
 RCCL and each draws theta for its block of respondents (--theta allreduce: the 66 MB partial log-posteriors are
-all-reduced instead); the Cholesky is replicated (--chol bcast: rank 0 factors and broadcasts L).
+all-reduced instead); the Cholesky is replicated (--chol bcast: rank 0 factors and broadcasts L; --chol distributed:
+block-cyclic outer panels, each finished panel broadcast while the previous one is applied).
 
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline      every syrk launch of the factorisation (fp64 MFMA, both tile instantiations): algorithmic flops /
@@ -52,7 +53,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--respondents", "--n", dest="n", type=int, default=8192)
     ap.add_argument("--items", "--m", dest="m", type=int, default=1024)
-    ap.add_argument("--chol", default="replicated", choices=["replicated", "bcast"])
+    ap.add_argument("--chol", default="replicated", choices=["replicated", "bcast", "distributed"],
+                    help="N > 1: every rank factors (default); rank 0 factors and broadcasts L; or the factorisation is "
+                         "distributed: 1-D block-cyclic outer panels, panel broadcasts overlapped with the trailing updates")
     ap.add_argument("--theta", default="gather", choices=["gather", "allreduce"],
                     help="N > 1: all-gather f* and draw theta per respondent block (default), or all-reduce the partial log-posterior")
     ap.add_argument("--fstar", default="lowrank", choices=["double_solve", "fused", "lowrank"],

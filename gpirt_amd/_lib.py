@@ -58,6 +58,12 @@ SIGNATURES = {
     "gpirt_se_kernel": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _dbl]),
     "gpirt_potrf_lower": (_i32, [_vp, _vp, _i64, _i64]),
     "gpirt_factor": (_i32, [_vp, _vp, _i64, _vp, _i64]),
+    "gpirt_potrf_panel_width": (_i64, []),
+    "gpirt_potrf_begin": (_i32, [_vp]),
+    "gpirt_potrf_panel_factor": (_i32, [_vp, _vp, _i64, _i64, _i64]),
+    "gpirt_potrf_panel_update": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64]),
+    "gpirt_potrf_panel_copy": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i32]),
+    "gpirt_potrf_finish": (_i32, [_vp]),
     "gpirt_trmm_lz": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64]),
     "gpirt_trsm_lower": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _i32]),
     "gpirt_gemm": (_i32, [_vp, _i32, _i32, _i64, _i64, _i64, _dbl, _vp, _i64, _vp, _i64, _dbl, _vp, _i64]),
@@ -92,6 +98,7 @@ SIGNATURES = {
     "gpirt_sampler_draw_beta": (_i32, [_vp]),
     "gpirt_sampler_factor": (_i32, [_vp]),
     "gpirt_sampler_skip_factor": (_i32, [_vp]),
+    "gpirt_sampler_build_cov": (_i32, [_vp]),
     "gpirt_sampler_accumulate_irf": (_i32, [_vp]),
     "gpirt_sampler_iteration": (_i32, [_vp, C.POINTER(_i32)]),
     "gpirt_sampler_check": (_i32, [_vp]),

@@ -250,6 +250,47 @@ int gpirt_factor(gpirt_handle_t h, const double* d_theta, int64_t n, double* d_L
     return finish_info(h);
 }
 
+// ---- distributed factorisation pieces (no host synchronisation; info is read by gpirt_potrf_finish) ----------------
+int64_t gpirt_potrf_panel_width(void) { return potrf_panel_width(); }
+
+int gpirt_potrf_begin(gpirt_handle_t h)
+{
+    GP_ARG(h != nullptr);
+    GP_HIP(hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
+    return 0;
+}
+
+int gpirt_potrf_panel_factor(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda, int64_t p)
+{
+    GP_ARG(h && d_A && n > 0 && lda >= n);
+    return potrf_panel_factor(h, h->stream, d_A, n, lda, p);
+}
+
+int gpirt_potrf_panel_update(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda, int64_t p, int64_t c)
+{
+    GP_ARG(h && d_A && n > 0 && lda >= n);
+    return potrf_panel_update(h, h->stream, d_A, n, lda, p, c);
+}
+
+// rows [pW, n) of outer panel p <-> a dense (n - pW) x w buffer (w = the panel's column count)
+int gpirt_potrf_panel_copy(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda, int64_t p, double* d_buf, int to_buf)
+{
+    GP_ARG(h && d_A && d_buf && n > 0 && lda >= n && p >= 0);
+    const int64_t W = potrf_panel_width(), K0 = p * W;
+    GP_ARG(K0 < n);
+    const int64_t w = (K0 + W < n) ? W : n - K0, rows = n - K0;
+    double* a = d_A + K0 + K0 * lda;
+    if (to_buf) GP_HIP(hipMemcpy2DAsync(d_buf, (size_t)rows * 8, a, (size_t)lda * 8, (size_t)rows * 8, (size_t)w, hipMemcpyDeviceToDevice, h->stream));
+    else        GP_HIP(hipMemcpy2DAsync(a, (size_t)lda * 8, d_buf, (size_t)rows * 8, (size_t)rows * 8, (size_t)w, hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+}
+
+int gpirt_potrf_finish(gpirt_handle_t h)
+{
+    GP_ARG(h != nullptr);
+    return finish_info(h);
+}
+
 int gpirt_trmm_lz(gpirt_handle_t h, const double* d_L, int64_t n, int64_t ldl, const double* d_Z,
                   int64_t m, int64_t ldz, double* d_out, int64_t ldo)
 {

@@ -40,6 +40,11 @@ int launch_se_kernel_lower(hipStream_t stream, const double* x, int64_t n, doubl
 int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda,
                        bool zero_upper, bool reset_info = true);
 
+// the same factorisation in pieces (distributed hosts): outer panel p = columns [p W, (p + 1) W)
+int64_t potrf_panel_width();
+int potrf_panel_factor(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t p);
+int potrf_panel_update(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t p, int64_t c);
+
 // panel.hip: columns [K0, c1) of the Cholesky factor, all rows below, one persistent kernel
 int launch_panel_ll(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t K0, int64_t c1);
 

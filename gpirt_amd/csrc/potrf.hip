@@ -223,6 +223,33 @@ int trailing(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t
 
 }  // namespace
 
+// ---- the factorisation in pieces, for a host that distributes it (gpirt_amd/distributed.py) ----------
+// Outer panel p = columns [p W, min((p + 1) W, n)), W = NBO.  1-D block-cyclic ownership: the owner of panel p factors
+// it once its columns carry the updates of every panel q < p, the finished panel travels to the other ranks, and each
+// rank applies it to the block columns it owns.  The pieces are exactly the launches of launch_potrf_lower -- same
+// sub-panel split, same K = 1024 products applied to every block in ascending panel order -- so the assembled L is
+// bit-identical to the single-GPU factor.
+int64_t potrf_panel_width()
+{
+    static const int nbo_env = env_int("GPIRT_NBO", NBO);
+    return (nbo_env / NBI) * NBI > 0 ? (nbo_env / NBI) * NBI : NBO;
+}
+
+int potrf_panel_factor(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t p)
+{
+    const int64_t W = potrf_panel_width(), K0 = p * W;
+    if (p < 0 || K0 >= n) { set_error("panel %lld out of range", (long long)p); return GPIRT_E_ARG; }
+    return factor_panel(h, stream, A, n, lda, K0, (K0 + W < n) ? K0 + W : n);
+}
+
+// A[cW:n, cW:(c+1)W] -= A[cW:n, pW:(p+1)W] A[cW:(c+1)W, pW:(p+1)W]^T   (lower trapezoid of block column c > p)
+int potrf_panel_update(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t p, int64_t c)
+{
+    const int64_t W = potrf_panel_width(), K0 = p * W, lo = c * W;
+    if (p < 0 || c <= p || lo >= n) { set_error("panel update (%lld -> %lld) out of range", (long long)p, (long long)c); return GPIRT_E_ARG; }
+    return trailing(h, stream, A, n, lda, K0, K0 + W, lo, (lo + W < n) ? lo + W : n);
+}
+
 // Look-ahead schedule: the trailing update of panel p is split into the columns of panel p+1
 // (done first, on the main stream) and the rest; panel p+1 is then factored on a high-priority
 // side stream WHILE the rest of update p runs on the main stream.  The persistent panel kernel keeps

@@ -592,6 +592,14 @@ int gpirt_sampler_factor(gpirt_sampler_t s)
     return 0;
 }
 
+int gpirt_sampler_build_cov(gpirt_sampler_t s)
+{
+    GP_ARG(s && s->initialised);
+    hipStream_t st = s->h->stream;
+    if (!s->sticky_info) GP_HIP(hipMemsetAsync(s->h->d_info, 0, sizeof(int), st));
+    return launch_se_kernel_lower(st, s->theta, s->n, s->L, s->n, GPIRT_JITTER, s->opt.reserved[1] != 0);   // :76-77
+}
+
 int gpirt_sampler_skip_factor(gpirt_sampler_t s)
 {
     GP_ARG(s && s->initialised);

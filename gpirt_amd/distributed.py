@@ -11,7 +11,11 @@ owns columns [m*r/G, m*(r+1)/G).  What is not item-separable:
     N* x n partial log-posteriors (66 MB) are all-reduced; every rank then draws the same theta.
     Either way the RNG is keyed by the global respondent index.
   * K + chol (src/gpirtMCMC.cpp:76-78): `chol="replicated"` factors on every rank (no traffic);
-    `chol="bcast"` factors on rank 0 and broadcasts L (one RCCL broadcast per iteration).
+    `chol="bcast"` factors on rank 0 and broadcasts L (one RCCL broadcast per iteration);
+    `chol="distributed"`: 1-D block-cyclic ownership of the 1024-column outer panels -- the owner
+    factors a panel, the finished panel is broadcast while every rank applies the PREVIOUS panel to the block columns
+    it owns (the next panel's columns first, so its owner can start factoring), and every rank ends with the full L:
+    the panel broadcasts ARE the broadcast of L.  Same launches as the single-GPU factorisation => bit-identical L.
 The per-item RNG sub-streams are keyed by the GLOBAL item index, so the draws do not depend on G.
 
 `engine_factory(y_local, theta_init, pm, ps, step, item0, m_total)` must return an object with the
@@ -47,8 +51,9 @@ class ShardedSampler:
         self.engine = engine_factory(y[:, sl], np.asarray(theta_init, dtype=np.float64), pm[:, sl], ps[:, sl],
                                      step[:, sl], self.lo, m)
         self.chol = chol
-        if chol not in ("replicated", "bcast"):
-            raise ValueError("chol must be 'replicated' or 'bcast'")
+        if chol not in ("replicated", "bcast", "distributed"):
+            raise ValueError("chol must be 'replicated', 'bcast' or 'distributed'")
+        self._panel_bufs = None
         if theta not in ("gather", "allreduce"):
             raise ValueError("theta must be 'gather' or 'allreduce'")
         self.theta_mode = theta if self.world > 1 else "local"
@@ -88,8 +93,54 @@ class ShardedSampler:
     def _combine_theta(self):
         self.dist.all_reduce(self._view("theta_stage"))   # zero outside each rank's block
 
+    def _factor_distributed(self):
+        """Right-looking over outer panels with one panel of look-ahead.  Panel p is owned by rank p % world.
+        Every block column receives the panels' updates in ascending order on its owner's (in-order) stream."""
+        import torch
+        e, W, n = self.engine, self.engine.panel_width, self.n
+        NP = (n + W - 1) // W
+        owner = lambda p: p % self.world
+        if self._panel_bufs is None:
+            # two broadcast buffers (panel p + 1 travels while panel p is still being applied)
+            self._panel_bufs = [torch.empty(n * min(W, n), dtype=torch.float64, device=e.torch_device) for _ in range(2)]
+        buf = lambda p: self._panel_bufs[p % 2][: (n - p * W) * min(W, n - p * W)]
+        e.build_cov()
+        work = None
+
+        def send(p):            # the finished panel p leaves its owner; collective: every rank calls it
+            if owner(p) == self.rank:
+                e.panel_copy(p, buf(p), True)
+            return self.dist.broadcast(buf(p), src=owner(p), async_op=True)
+
+        def receive(p, w):
+            w.wait()
+            if owner(p) != self.rank:
+                e.panel_copy(p, buf(p), False)
+
+        if owner(0) == self.rank:
+            e.panel_factor(0)
+        receive(0, send(0))
+        for p in range(NP - 1):
+            nxt = p + 1
+            if owner(nxt) == self.rank:
+                e.panel_update(p, nxt)              # the next panel's columns first ...
+                e.panel_factor(nxt)                 # ... so its owner can factor it
+            if nxt < NP - 1:
+                work = send(nxt)                    # travels while panel p is applied to the remaining columns
+            for c in range(nxt + 1, NP):
+                if owner(c) == self.rank:
+                    e.panel_update(p, c)
+            if nxt < NP - 1:
+                receive(nxt, work)
+        # the last panel has nothing to update: it only has to reach everybody
+        if NP > 1:
+            receive(NP - 1, send(NP - 1))
+        e.skip_factor()
+
     def _factor(self):
-        if self.chol == "replicated" or self.world == 1:
+        if self.chol == "distributed" and self.world > 1:
+            self._factor_distributed()
+        elif self.chol in ("replicated", "distributed") or self.world == 1:
             self.engine.factor()
         else:
             if self.rank == 0:

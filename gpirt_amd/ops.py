@@ -118,6 +118,29 @@ class Handle:
         check(info)
         return S
 
+    # -- the same factorisation in pieces (include/gpirt_hip.h "gpirt_potrf_panel_*"): what a distributing host calls
+    @property
+    def panel_width(self) -> int:
+        return int(self.lib.gpirt_potrf_panel_width())
+
+    def potrf_begin(self):
+        check(self.lib.gpirt_potrf_begin(self._h))
+
+    def potrf_panel_factor(self, A: torch.Tensor, p: int):
+        check(self.lib.gpirt_potrf_panel_factor(self._h, _p(A), A.shape[0], _ld(A), int(p)))
+
+    def potrf_panel_update(self, A: torch.Tensor, p: int, c: int):
+        check(self.lib.gpirt_potrf_panel_update(self._h, _p(A), A.shape[0], _ld(A), int(p), int(c)))
+
+    def potrf_panel_copy(self, A: torch.Tensor, p: int, buf: torch.Tensor, to_buf: bool):
+        check(self.lib.gpirt_potrf_panel_copy(self._h, _p(A), A.shape[0], _ld(A), int(p), _p(buf), int(bool(to_buf))))
+
+    def potrf_finish(self):
+        info = self.lib.gpirt_potrf_finish(self._h)
+        if info > 0:
+            raise RuntimeError("chol(): decomposition failed (leading minor %d)" % info)
+        check(info)
+
     def factor(self, theta: torch.Tensor) -> torch.Tensor:
         """K(theta,theta) + 0.001 I -> lower Cholesky factor (src/gpirtMCMC.cpp:15-17)."""
         n = theta.shape[0]

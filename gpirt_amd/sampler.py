@@ -158,6 +158,33 @@ class Sampler:
     def draw_beta(self): self._call("gpirt_sampler_draw_beta")
     def factor(self): self._call("gpirt_sampler_factor")
     def skip_factor(self): self._call("gpirt_sampler_skip_factor")
+    def build_cov(self): self._call("gpirt_sampler_build_cov")
+
+    # -- the factorisation in pieces (distributed hosts, include/gpirt_hip.h "gpirt_potrf_panel_*"), on "L" in place
+    @property
+    def panel_width(self) -> int:
+        return int(self.lib.gpirt_potrf_panel_width())
+
+    @property
+    def torch_device(self):
+        import torch
+        return torch.device("cuda", self.handle.device)
+
+    def _Lptr(self):
+        if not hasattr(self, "_L_ptr"):
+            self._L_ptr = C.c_void_p(self.devptr("L")[0])
+        return self._L_ptr
+
+    def panel_factor(self, p: int):
+        check(self.lib.gpirt_potrf_panel_factor(self.handle.ptr, self._Lptr(), self.n, self.n, int(p)))
+
+    def panel_update(self, p: int, c: int):
+        check(self.lib.gpirt_potrf_panel_update(self.handle.ptr, self._Lptr(), self.n, self.n, int(p), int(c)))
+
+    def panel_copy(self, p: int, buf, to_buf: bool):
+        """rows [pW, n) of outer panel p <-> the dense torch buffer `buf` (what the host broadcasts)"""
+        check(self.lib.gpirt_potrf_panel_copy(self.handle.ptr, self._Lptr(), self.n, self.n, int(p),
+                                              C.c_void_p(buf.data_ptr()), int(bool(to_buf))))
     def accumulate_irf(self): self._call("gpirt_sampler_accumulate_irf")
     def check(self): self._call("gpirt_sampler_check")
 

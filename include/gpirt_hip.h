@@ -89,6 +89,20 @@ int gpirt_potrf_lower(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda);
 /* Fused K(theta,theta) + jitter + chol: src/gpirtMCMC.cpp:15-17,76-78,95-97.  d_L n x n. */
 int gpirt_factor(gpirt_handle_t h, const double* d_theta, int64_t n, double* d_L, int64_t ldl);
 
+/* The same factorisation in pieces, for a host that distributes it over several GPUs (one process each): outer panel
+ * p = columns [p W, min((p + 1) W, n)), W = gpirt_potrf_panel_width().  With 1-D block-cyclic ownership of the outer
+ * panels the owner of p calls panel_factor once its columns carry the updates of every panel q < p, the finished
+ * panel travels to the other ranks through panel_copy (rows [pW, n) of the panel <-> a dense (n - pW) x w buffer the
+ * host broadcasts), and every rank applies it to the block columns c > p it owns with panel_update.  The pieces are
+ * the launches gpirt_potrf_lower itself makes, so the assembled factor is bit-identical to it.  Nothing here
+ * synchronises; gpirt_potrf_begin clears the info word and gpirt_potrf_finish drains the stream and returns it. */
+int64_t gpirt_potrf_panel_width(void);
+int gpirt_potrf_begin(gpirt_handle_t h);
+int gpirt_potrf_panel_factor(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda, int64_t p);
+int gpirt_potrf_panel_update(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda, int64_t p, int64_t c);
+int gpirt_potrf_panel_copy(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda, int64_t p, double* d_buf, int to_buf);
+int gpirt_potrf_finish(gpirt_handle_t h);
+
 /* rmvnorm()'s product `cholS * res` (src/mvnormal.h:10) for all item columns at once:
  * d_out (n x m) = L * Z with L lower triangular; the strict upper triangle of d_L must hold zeros
  * (as gpirt_potrf_lower / arma::chol leave it). */
@@ -218,6 +232,10 @@ int gpirt_sampler_theta_block(gpirt_sampler_t s);
 int gpirt_sampler_theta_commit(gpirt_sampler_t s);
 int gpirt_sampler_draw_beta(gpirt_sampler_t s);          /* :71-75 / :90-94 (beta, mu, mu_star) */
 int gpirt_sampler_factor(gpirt_sampler_t s);             /* :76-78 / :95-97 */
+/* K(theta, theta) + jitter into "L" (lower blocks; src/gpirtMCMC.cpp:76-77) without factoring: the first step of a
+ * factorisation the host distributes with the gpirt_potrf_panel_* pieces on the "L" devptr; gpirt_sampler_skip_factor
+ * then closes the iteration. */
+int gpirt_sampler_build_cov(gpirt_sampler_t s);
 /* closes the iteration WITHOUT factoring: for ranks that receive L by broadcast ("L" devptr) */
 int gpirt_sampler_skip_factor(gpirt_sampler_t s);
 int gpirt_sampler_accumulate_irf(gpirt_sampler_t s);     /* :103 */

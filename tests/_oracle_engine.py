@@ -132,5 +132,43 @@ class OracleEngine:
     def skip_factor(self):
         self.it += 1
 
+    # -- the factorisation in pieces (gpirt_potrf_panel_* / gpirt_sampler_build_cov), NumPy, small panels ----------
+    panel_width = 16
+    torch_device = torch.device("cpu")
+
+    def build_cov(self):
+        S = O.se_kernel(self.theta, self.theta)
+        S[np.diag_indices_from(S)] += 0.001
+        self.L[:, :] = S
+
+    def _cols(self, p):
+        K0 = p * self.panel_width
+        return K0, min(K0 + self.panel_width, self.n)
+
+    def panel_factor(self, p):
+        L = self.L
+        K0, c1 = self._cols(p)
+        for j in range(K0, c1):                       # left-looking inside the panel, unblocked
+            L[j:, j] -= L[j:, K0:j] @ L[j, K0:j]
+            d = np.sqrt(L[j, j])
+            L[j, j] = d
+            L[j + 1:, j] /= d
+            L[:j, j] = 0.0                            # arma::chol leaves zeros above the diagonal
+
+    def panel_update(self, p, c):
+        L = self.L
+        K0, c1 = self._cols(p)
+        lo, hi = self._cols(c)
+        L[lo:, lo:hi] -= L[lo:, K0:c1] @ L[lo:hi, K0:c1].T
+
+    def panel_copy(self, p, buf, to_buf):
+        K0, c1 = self._cols(p)
+        view = buf.numpy()[: (self.n - K0) * (c1 - K0)].reshape(self.n - K0, c1 - K0, order="F")
+        if to_buf:
+            view[:, :] = self.L[K0:, K0:c1]
+        else:
+            self.L[K0:, K0:c1] = view
+            self.L[:K0, K0:c1] = 0.0
+
     def get(self, name):
         return np.asfortranarray(getattr(self, name) if name != "L" else self.L)

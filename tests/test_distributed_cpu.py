@@ -39,7 +39,7 @@ def _run(rank, world, port, chol, outdir, theta="gather", m=7):
 
 
 @pytest.mark.parametrize("chol,theta,m", [("replicated", "gather", 7), ("bcast", "gather", 8), ("replicated", "allreduce", 7),
-                                          ("bcast", "allreduce", 7)])
+                                          ("bcast", "allreduce", 7), ("distributed", "gather", 8)])
 def test_two_ranks_reproduce_single_process(tmp_path, chol, theta, m):
     """theta="gather": f* is all-gathered (m = 8: equal shards, flat all-gather; m = 7: unequal shards, the
     all-reduce-of-disjoint-supports fallback) and each rank draws theta for its block of respondents;
@@ -57,7 +57,15 @@ def test_two_ranks_reproduce_single_process(tmp_path, chol, theta, m):
     for _ in range(2):
         ref.step()
     assert np.array_equal(got["theta"], ref.engine.theta)
-    assert np.abs(got["L"] - ref.engine.L).max() == 0
-    assert np.abs(got["f"] - ref.gather("f")).max() < 1e-12
-    assert np.abs(got["beta"] - ref.gather("beta")).max() < 1e-12
-    assert np.abs(got["fstar"] - ref.gather("fstar")).max() < 1e-12
+    if chol == "distributed":
+        # n = 40 -> three 16-column outer panels dealt round-robin to the two ranks, one panel of look-ahead; the
+        # NumPy pieces round differently from the oracle's unblocked potrf (the HIP pieces ARE the single-GPU launches:
+        # tests/test_gpu_distributed.py asserts bit-identity there)
+        assert np.abs(got["L"] - ref.engine.L).max() < 1e-12
+        assert np.abs(np.triu(got["L"], 1)).max() == 0
+    else:
+        assert np.abs(got["L"] - ref.engine.L).max() == 0
+    tol = 1e-9 if chol == "distributed" else 1e-12
+    assert np.abs(got["f"] - ref.gather("f")).max() < tol
+    assert np.abs(got["beta"] - ref.gather("beta")).max() < tol
+    assert np.abs(got["fstar"] - ref.gather("fstar")).max() < tol

@@ -1,7 +1,8 @@
 """Two ranks sharing the one visible MI355X (gloo backend, device tensors): the item-sharded HIP sampler
 must reproduce the single-process HIP sampler.  Exercises the real engine behind
 gpirt_amd/distributed.py: zero-copy device views of sampler state, the all-reduce of the partial
-log-posterior, the broadcast of L, and the global-item RNG keys.  (RCCL itself needs >= 2 GPUs and is
+log-posterior, the broadcast of L, the distributed factorisation (1-D block-cyclic outer panels, panel broadcasts
+with one panel of look-ahead: L must be BIT-IDENTICAL to gpirt_sampler_factor), and the global-item RNG keys.  (RCCL itself needs >= 2 GPUs and is
 exercised by bench.py --gpus N on the driver's 8-GPU node.)"""
 import os
 import sys
@@ -25,7 +26,8 @@ def _run(rank, world, port, chol, outdir):
     from gpirt_amd.ops import Handle
     from gpirt_amd.sampler import Sampler
     from gpirt_amd.synthetic import make_responses
-    y, th0 = make_responses(300, 22, seed=6)
+    n = 2500 if chol == "distributed" else 300      # distributed: three 1024-column outer panels (the last ragged)
+    y, th0 = make_responses(n, 22, seed=6)
     h = Handle(0)
 
     def factory(yl, th, pm, ps, st, item0, m_total):
@@ -43,15 +45,15 @@ def _run(rank, world, port, chol, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("chol", ["replicated", "bcast"])
+@pytest.mark.parametrize("chol", ["replicated", "bcast", "distributed"])
 def test_two_ranks_one_gpu_match_single_process(handle, tmp_path, chol):
     import torch.multiprocessing as mp
     from gpirt_amd.sampler import Sampler
     from gpirt_amd.synthetic import make_responses
-    port = 29700 + (os.getpid() % 1000) + (1 if chol == "bcast" else 0)
+    port = 29700 + (os.getpid() % 1000) + {"replicated": 0, "bcast": 1, "distributed": 2}[chol]
     mp.spawn(_run, args=(2, port, chol, str(tmp_path)), nprocs=2, join=True)
     got = np.load(tmp_path / f"gpu_sharded_{chol}.npz")
-    y, th0 = make_responses(300, 22, seed=6)
+    y, th0 = make_responses(2500 if chol == "distributed" else 300, 22, seed=6)
     ref = Sampler(handle, y, th0, rng="item", seed=77)
     ref.init()
     for _ in range(2):

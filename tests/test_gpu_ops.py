@@ -97,6 +97,38 @@ def test_potrf_matches_oracle(handle, oracle, n):
     assert np.abs(L - Lref).max() <= 1e-11
 
 
+@pytest.mark.parametrize("n,G", [(5000, 3), (8192, 8), (1500, 2), (900, 4)])
+def test_potrf_in_pieces_is_bit_identical(handle, n, G):
+    """the factorisation as a distributing host drives it -- 1-D block-cyclic ownership of the outer
+    panels over G ranks (played here by G copies of S on the one device), owner factors, the panel travels through the
+    dense buffer, every rank applies it to the block columns it owns -- must reproduce gpirt_potrf_lower BIT FOR BIT on
+    every rank (ragged last panel; more ranks than panels; a single panel)."""
+    import torch
+    from gpirt_amd.ops import to_device
+    from gpirt_amd.synthetic import make_responses
+    _, th0 = make_responses(n, 2, seed=n)
+    th = to_device(th0)
+    ref = handle.factor(th)
+    W = handle.panel_width
+    NP = (n + W - 1) // W
+    ranks = [handle.se_kernel(th, th, jitter=0.001) for _ in range(G)]           # <= 8 x 0.5 GiB
+    buf = torch.empty(n * min(W, n), dtype=torch.float64, device="cuda")
+    handle.potrf_begin()
+    for p in range(NP):
+        own = p % G
+        handle.potrf_panel_factor(ranks[own], p)
+        handle.potrf_panel_copy(ranks[own], p, buf, True)
+        for r in range(G):
+            if r != own:
+                handle.potrf_panel_copy(ranks[r], p, buf, False)
+            for c in range(p + 1, NP):
+                if c % G == r:
+                    handle.potrf_panel_update(ranks[r], p, c)
+    handle.potrf_finish()
+    for r in range(G):
+        assert torch.equal(torch.tril(ranks[r]), torch.tril(ref)), f"rank {r} differs from the single-GPU factor"
+
+
 def test_potrf_operator_on_user_matrix(handle, oracle):
     from gpirt_amd.ops import to_device, to_host
     n = 200
