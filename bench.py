@@ -151,9 +151,7 @@ def main():
         chk = make("fused")
         chk.init()
         c = chk.engine
-        for name in ("theta", "f", "mu_star", "L"):
-            c.device_tensor(name).copy_(e.device_tensor(name))
-        c.set_iteration(e.iteration)
+        c.copy_state_from(e)           # theta, f, beta, mu, mu_star, L, iteration counter (device to device)
         e.draw_fstar()
         c.draw_fstar()
         e.check(); c.check()

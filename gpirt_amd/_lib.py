@@ -99,6 +99,12 @@ SIGNATURES = {
     "gpirt_sampler_factor": (_i32, [_vp]),
     "gpirt_sampler_skip_factor": (_i32, [_vp]),
     "gpirt_sampler_build_cov": (_i32, [_vp]),
+    "gpirt_sampler_panel_factor": (_i32, [_vp, _i64]),
+    "gpirt_sampler_panel_update": (_i32, [_vp, _i64, _i64]),
+    "gpirt_sampler_panel_copy": (_i32, [_vp, _i64, _vp, _i32]),
+    "gpirt_sampler_panel_rows": (_i32, [_vp, C.POINTER(_i64)]),
+    "gpirt_sampler_ldl": (_i32, [_vp, C.POINTER(_i64)]),
+    "gpirt_sampler_copy_state": (_i32, [_vp, _vp]),
     "gpirt_sampler_accumulate_irf": (_i32, [_vp]),
     "gpirt_sampler_iteration": (_i32, [_vp, C.POINTER(_i32)]),
     "gpirt_sampler_check": (_i32, [_vp]),

@@ -75,6 +75,18 @@ int report_panel_guard(gpirt_handle_t h, const int* w, hipStream_t stream)
     return GPIRT_E_HIP;
 }
 
+int potrf_panel_copy(hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t p, double* buf, bool to_buf,
+                     int64_t extra_rows)
+{
+    const int64_t W = potrf_panel_width(), K0 = p * W;
+    if (p < 0 || K0 >= n) { set_error("panel %lld out of range", (long long)p); return GPIRT_E_ARG; }
+    const int64_t w = (K0 + W < n) ? W : n - K0, rows = n + extra_rows - K0;
+    double* a = A + K0 + K0 * lda;
+    if (to_buf) GP_HIP(hipMemcpy2DAsync(buf, (size_t)rows * 8, a, (size_t)lda * 8, (size_t)rows * 8, (size_t)w, hipMemcpyDeviceToDevice, stream));
+    else        GP_HIP(hipMemcpy2DAsync(a, (size_t)lda * 8, buf, (size_t)rows * 8, (size_t)rows * 8, (size_t)w, hipMemcpyDeviceToDevice, stream));
+    return 0;
+}
+
 }  // namespace gpirt
 
 using namespace gpirt;
@@ -276,13 +288,7 @@ int gpirt_potrf_panel_update(gpirt_handle_t h, double* d_A, int64_t n, int64_t l
 int gpirt_potrf_panel_copy(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda, int64_t p, double* d_buf, int to_buf)
 {
     GP_ARG(h && d_A && d_buf && n > 0 && lda >= n && p >= 0);
-    const int64_t W = potrf_panel_width(), K0 = p * W;
-    GP_ARG(K0 < n);
-    const int64_t w = (K0 + W < n) ? W : n - K0, rows = n - K0;
-    double* a = d_A + K0 + K0 * lda;
-    if (to_buf) GP_HIP(hipMemcpy2DAsync(d_buf, (size_t)rows * 8, a, (size_t)lda * 8, (size_t)rows * 8, (size_t)w, hipMemcpyDeviceToDevice, h->stream));
-    else        GP_HIP(hipMemcpy2DAsync(a, (size_t)lda * 8, d_buf, (size_t)rows * 8, (size_t)rows * 8, (size_t)w, hipMemcpyDeviceToDevice, h->stream));
-    return 0;
+    return potrf_panel_copy(h->stream, d_A, n, lda, p, d_buf, to_buf != 0, 0);
 }
 
 int gpirt_potrf_finish(gpirt_handle_t h)

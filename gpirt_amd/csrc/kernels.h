@@ -38,12 +38,15 @@ int launch_se_kernel_lower(hipStream_t stream, const double* x, int64_t n, doubl
 
 // potrf.hip
 int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda,
-                       bool zero_upper, bool reset_info = true);
+                       bool zero_upper, bool reset_info = true, int64_t extra_rows = 0);
 
 // the same factorisation in pieces (distributed hosts): outer panel p = columns [p W, (p + 1) W)
 int64_t potrf_panel_width();
-int potrf_panel_factor(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t p);
-int potrf_panel_update(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t p, int64_t c);
+int potrf_panel_factor(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t p, int64_t extra_rows = 0);
+int potrf_panel_update(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t p, int64_t c,
+                       int64_t extra_rows = 0);
+int potrf_panel_copy(hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t p, double* buf, bool to_buf,
+                     int64_t extra_rows = 0);
 
 // panel.hip: columns [K0, c1) of the Cholesky factor, all rows below, one persistent kernel
 int launch_panel_ll(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t K0, int64_t c1);
@@ -118,6 +121,8 @@ int launch_linear_mean(hipStream_t stream, const double* x, int64_t n, const dou
 int report_panel_guard(gpirt_handle_t h, const int* info_words, hipStream_t stream);
 
 // misc
+// out (cols x rows, ldo) = in^T, in is rows x cols with leading dimension ldi
+int launch_transpose(hipStream_t stream, const double* in, int64_t rows, int64_t cols, int64_t ldi, double* out, int64_t ldo);
 int launch_axpy_irf(hipStream_t stream, double* acc, const double* fstar, int64_t count);
 int launch_advance_pos(hipStream_t stream, uint64_t* pos, uint64_t delta);
 

@@ -235,19 +235,20 @@ int64_t potrf_panel_width()
     return (nbo_env / NBI) * NBI > 0 ? (nbo_env / NBI) * NBI : NBO;
 }
 
-int potrf_panel_factor(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t p)
+int potrf_panel_factor(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t p, int64_t extra_rows)
 {
     const int64_t W = potrf_panel_width(), K0 = p * W;
     if (p < 0 || K0 >= n) { set_error("panel %lld out of range", (long long)p); return GPIRT_E_ARG; }
-    return factor_panel(h, stream, A, n, lda, K0, (K0 + W < n) ? K0 + W : n);
+    return factor_panel(h, stream, A, n + extra_rows, lda, K0, (K0 + W < n) ? K0 + W : n);
 }
 
 // A[cW:n, cW:(c+1)W] -= A[cW:n, pW:(p+1)W] A[cW:(c+1)W, pW:(p+1)W]^T   (lower trapezoid of block column c > p)
-int potrf_panel_update(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t p, int64_t c)
+int potrf_panel_update(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t p, int64_t c,
+                       int64_t extra_rows)
 {
     const int64_t W = potrf_panel_width(), K0 = p * W, lo = c * W;
     if (p < 0 || c <= p || lo >= n) { set_error("panel update (%lld -> %lld) out of range", (long long)p, (long long)c); return GPIRT_E_ARG; }
-    return trailing(h, stream, A, n, lda, K0, K0 + W, lo, (lo + W < n) ? lo + W : n);
+    return trailing(h, stream, A, n + extra_rows, lda, K0, K0 + W, lo, (lo + W < n) ? lo + W : n);
 }
 
 // Look-ahead schedule: the trailing update of panel p is split into the columns of panel p+1
@@ -257,10 +258,15 @@ int potrf_panel_update(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
 // Measured gain ~6 % of the factorisation: the pivot chain is fp64-VALU latency-bound and slows down
 // (clocks, shared FP64 pipes) while the update runs; CU masks (hipExtStreamCreateWithCUMask) and
 // single-occupancy GEMM variants were measured and made it worse.
+// extra_rows > 0: the matrix is (n + extra_rows) x n -- rows below the square part ride along as ordinary row blocks of
+// every panel and trailing update and end up holding  E L^-T  for the rows E they held on entry (a bordered Cholesky:
+// draw_fstar's L^-1 K(theta, c) comes out of the factorisation instead of a triangular solve).  Needs n % 64 == 0.
 int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda,
-                       bool zero_upper, bool reset_info)
+                       bool zero_upper, bool reset_info, int64_t extra_rows)
 {
     if (n <= 0) return 0;
+    if (extra_rows > 0 && (n % NBI) != 0) { set_error("bordered factorisation needs n %% 64 == 0"); return GPIRT_E_ARG; }
+    const int64_t nr = n + extra_rows;          // rows of every panel / update; column limits stay n
     static const int nbo_env = env_int("GPIRT_NBO", NBO);
     static const int lookahead = env_int("GPIRT_LOOKAHEAD", 1);     // 2 = off
     const int64_t nbo = (nbo_env / NBI) * NBI > 0 ? (nbo_env / NBI) * NBI : NBO;
@@ -290,7 +296,7 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
     // long tiles: 116 it/s).
     static const int defer = env_int("GPIRT_DEFER", 2);      // 2: off (default), 3: one launch per panel, 1: fused
     std::vector<int64_t> done_col;                   // (mode 3) columns < done_col[q] carry panel q's update
-    GP_TRY(factor_panel(h, stream, A, n, lda, 0, nbo < n ? nbo : n));
+    GP_TRY(factor_panel(h, stream, A, nr, lda, 0, nbo < n ? nbo : n));
     for (int64_t K0 = 0; K0 < n; K0 += nbo) {
         const int64_t c1 = (K0 + nbo < n) ? K0 + nbo : n;
         if (c1 >= n) break;
@@ -299,19 +305,19 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
         // with persistent sub-panels and look-ahead, only the first sub-panel's columns gate the side stream
         const int64_t cA = (c1 + nbp_la < c2) ? c1 + nbp_la : c2;
         const bool split = la && c2 < n && panel_persistent() && cA < c2;
-        GP_TRY(trailing(h, stream, A, n, lda, K0, c1, c1, split ? cA : c2, split ? nullptr : &diag_done));
+        GP_TRY(trailing(h, stream, A, nr, lda, K0, c1, c1, split ? cA : c2, split ? nullptr : &diag_done));
         if (la && c2 < n) {
             GP_HIP(hipEventRecord(h->ev_fork, stream));
             GP_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
             if (split) {
                 // the side stream starts on the first sub-panel as soon as ITS columns are up to date; the
                 // other columns of the outer panel are brought up to date behind it on the main stream
-                GP_TRY(factor_panel(h, h->side, A, n, lda, c1, cA));
-                GP_TRY(trailing(h, stream, A, n, lda, K0, c1, cA, c2));
+                GP_TRY(factor_panel(h, h->side, A, nr, lda, c1, cA));
+                GP_TRY(trailing(h, stream, A, nr, lda, K0, c1, cA, c2));
                 GP_HIP(hipEventRecord(h->ev_mid, stream));
                 GP_HIP(hipStreamWaitEvent(h->side, h->ev_mid, 0));
-                GP_TRY(panel_update(h, h->side, n - cA, c2 - cA, cA - c1, A + cA + c1 * lda, lda, A + cA + cA * lda, lda));
-                if (hold_rest == 1 || (hold_rest == 3 && gemm_trailing_uses_128(n - c2, n - c2))) {
+                GP_TRY(panel_update(h, h->side, nr - cA, c2 - cA, cA - c1, A + cA + c1 * lda, lda, A + cA + cA * lda, lda));
+                if (hold_rest == 1 || (hold_rest == 3 && gemm_trailing_uses_128(nr - c2, n - c2))) {
                     // The large (128-tile) updates are released only once the second sub-panel is ready to go as
                     // well: a panel wave holds all 512 registers of its SIMD slice and cannot squeeze in beside resident
                     // update waves, so it has to be dispatched (high-priority stream) before they fill the chip;
@@ -322,31 +328,31 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
                     GP_HIP(hipEventRecord(h->ev_a, h->side));
                     GP_HIP(hipStreamWaitEvent(stream, h->ev_a, 0));
                 }
-                GP_TRY(factor_panel(h, h->side, A, n, lda, cA, c2));
+                GP_TRY(factor_panel(h, h->side, A, nr, lda, cA, c2));
             } else {
-                GP_TRY(factor_panel(h, h->side, A, n, lda, c1, c2, diag_done)); // next panel, side stream
+                GP_TRY(factor_panel(h, h->side, A, nr, lda, c1, c2, diag_done)); // next panel, side stream
             }
             if (defer == 1 && split) {
                 const int64_t horizon = (c2 + nbo < n) ? c2 + nbo : n;
-                GP_TRY(trailing(h, stream, A, n, lda, 0, c1, c2, horizon, nullptr, true));
+                GP_TRY(trailing(h, stream, A, nr, lda, 0, c1, c2, horizon, nullptr, true));
             } else if (defer == 3 && split) {
                 done_col.push_back(c2);                                   // this panel: [c1, c2) done above
                 static const int ahead = env_int("GPIRT_DEFER_AHEAD", 1);  // block columns brought up to date per step
                 const int64_t horizon = (c2 + ahead * nbo < n) ? c2 + ahead * nbo : n;
                 for (size_t q = 0; q < done_col.size(); ++q)
                     if (done_col[q] < horizon) {
-                        GP_TRY(trailing(h, stream, A, n, lda, (int64_t)q * nbo, (int64_t)(q + 1) * nbo, done_col[q], horizon,
+                        GP_TRY(trailing(h, stream, A, nr, lda, (int64_t)q * nbo, (int64_t)(q + 1) * nbo, done_col[q], horizon,
                                         nullptr, true));
                         done_col[q] = horizon;
                     }
             } else {
-                GP_TRY(trailing(h, stream, A, n, lda, K0, c1, c2, n));    // the rest, concurrently
+                GP_TRY(trailing(h, stream, A, nr, lda, K0, c1, c2, n));    // the rest, concurrently
             }
             GP_HIP(hipEventRecord(h->ev_join, h->side));
             GP_HIP(hipStreamWaitEvent(stream, h->ev_join, 0));
         } else {
-            if (c2 < n) GP_TRY(trailing(h, stream, A, n, lda, K0, c1, c2, n));
-            GP_TRY(factor_panel(h, stream, A, n, lda, c1, c2, diag_done));
+            if (c2 < n) GP_TRY(trailing(h, stream, A, nr, lda, K0, c1, c2, n));
+            GP_TRY(factor_panel(h, stream, A, nr, lda, c1, c2, diag_done));
         }
     }
     if (zero_upper) {

@@ -15,6 +15,7 @@
 #include "kernels.h"
 #include "rstream.h"
 
+#include <stdlib.h>
 #include <new>
 #include <string>
 #include <vector>
@@ -45,6 +46,10 @@ struct gpirt_sampler_s {
     // low-rank K* (opt.reserved[2] = r > 0): Chebyshev nodes, interpolation matrix V (N x r), split-K parts
     int kr = 0;
     double *knodes = nullptr, *kV = nullptr, *kparts = nullptr, *kP = nullptr;
+    // L is stored (n + ext) x n with leading dimension ldl.  ext = kr when the low-rank K* is on and n % 64 == 0: the
+    // extra rows enter the factorisation holding K(c, theta) (r x n) and leave it holding (L^-1 K(theta, c))^T -- the
+    // forward solve of draw_fstar comes out of the bordered factorisation (potrf.hip) for ~1 % more work.
+    int64_t ext = 0, ldl = 0;
     // respondent-block form of draw_theta for item-sharded runs (gpirt_sampler_set_theta_block): this rank's
     // block of respondents with ALL items
     int64_t blk_i0 = 0, blk_n = 0, blk_m = 0;
@@ -145,7 +150,7 @@ int do_draw_f(gpirt_sampler_s* s)
     const uint32_t iter = (uint32_t)(s->iter + 1);
     if (!stream_mode(s)) {
         GP_TRY(launch_item_uniforms(st, s->opt.seed, iter, GPIRT_ST_F_Z, (uint32_t)s->opt.item0, m, n, s->Z, true));
-        GP_TRY(launch_gemm(h, st, false, false, TRI_A_LOWER, n, m, n, 1.0, s->L, n, s->Z, n, 0.0, s->NU, n));
+        GP_TRY(launch_gemm(h, st, false, false, TRI_A_LOWER, n, m, n, 1.0, s->L, s->ldl, s->Z, n, 0.0, s->NU, n));
         EssArgs a{};
         a.f = s->f; a.nu = s->NU; a.y = s->y; a.mu = s->mu; a.n = n; a.m = m; a.k_out = s->ess_k;
         a.err = s->flags; a.seed = s->opt.seed; a.iter = iter; a.item0 = (uint32_t)s->opt.item0;
@@ -154,7 +159,7 @@ int do_draw_f(gpirt_sampler_s* s)
     // exact R order: item j draws its n normals, then u, eps0 and one uniform per rejection
     for (int64_t j = 0; j < m; ++j) {
         GP_TRY(launch_rstream_normals(st, s->U, s->pos, 0, n, 1, s->Z));
-        hipLaunchKernelGGL(trmv_lower_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, s->L, n, n, s->Z, s->NU);
+        hipLaunchKernelGGL(trmv_lower_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, s->L, n, s->ldl, s->Z, s->NU);
         EssArgs a{};
         a.f = s->f + j * n; a.nu = s->NU; a.y = s->y + j * n; a.mu = s->mu + j * n; a.n = n; a.m = 1;
         a.k_out = s->ess_k + j; a.err = s->flags; a.item0 = (uint32_t)j;
@@ -181,13 +186,25 @@ int do_draw_fstar(gpirt_sampler_s* s, uint32_t iter)
         const int r = s->kr;
         double* Bu = s->rhs;                                  // n x r : U, then B
         double* Cu = s->rhs + (size_t)n * r;                  // n x r : B, then C
-        GP_TRY(launch_se_kernel(st, s->theta, n, s->knodes, r, Bu, n, 0.0));
-        GP_TRY(launch_trsm_lower(h, st, s->L, n, n, Bu, r, n, false));
-        GP_HIP(hipMemcpyAsync(Cu, Bu, sizeof(double) * (size_t)n * r, hipMemcpyDeviceToDevice, st));
-        GP_TRY(launch_trsm_lower(h, st, s->L, n, n, Cu, r, n, true, true));
+        const bool bordered = s->ext > 0;
+        if (bordered) {
+            // B^T (r x n) already sits in the rows below L: the bordered factorisation produced it (do_factor)
+            const double* Bt = s->L + n;
+            GP_TRY(launch_transpose(st, Bt, r, n, s->ldl, Cu, n));                       // Cu = B
+            GP_TRY(launch_trsm_lower(h, st, s->L, n, s->ldl, Cu, r, n, true));
+        } else {
+            GP_TRY(launch_se_kernel(st, s->theta, n, s->knodes, r, Bu, n, 0.0));
+            GP_TRY(launch_trsm_lower(h, st, s->L, n, s->ldl, Bu, r, n, false));
+            GP_HIP(hipMemcpyAsync(Cu, Bu, sizeof(double) * (size_t)n * r, hipMemcpyDeviceToDevice, st));
+            GP_TRY(launch_trsm_lower(h, st, s->L, n, s->ldl, Cu, r, n, true, true));
+        }
         double* G = s->kP;                                    // r x r
         double* Q = s->kP + (size_t)r * r;                    // r x m
-        GP_TRY(launch_gemm_splitk(st, true, false, r, r, n, 1.0, Bu, n, Bu, n, s->kparts, r, (int64_t)r * r, KSPLIT, G, r, 0.0));
+        if (bordered)   // G = B^T B from the r x n rows (NT form)
+            GP_TRY(launch_gemm_splitk(st, false, true, r, r, n, 1.0, s->L + n, s->ldl, s->L + n, s->ldl, s->kparts, r,
+                                      (int64_t)r * r, KSPLIT, G, r, 0.0));
+        else
+            GP_TRY(launch_gemm_splitk(st, true, false, r, r, n, 1.0, Bu, n, Bu, n, s->kparts, r, (int64_t)r * r, KSPLIT, G, r, 0.0));
         GP_TRY(launch_gemm_splitk(st, true, false, r, m, n, 1.0, Cu, n, s->f, n, s->kparts, r, (int64_t)r * m, KSPLIT, Q, r, 0.0));
         GP_TRY(launch_lowrank_s(st, s->kV, N, r, G, r, s->s));
         GP_TRY(launch_gemm(h, st, false, false, TRI_NONE, N, m, r, 1.0, s->kV, N, Q, r, 0.0, s->mean, N));
@@ -204,12 +221,12 @@ int do_draw_fstar(gpirt_sampler_s* s, uint32_t iter)
         GP_HIP(hipMemcpyAsync(tmp, s->kstar, sizeof(double) * (size_t)n * N, hipMemcpyDeviceToDevice, st));
     }
     GP_HIP(hipMemcpyAsync(W, s->f, sizeof(double) * (size_t)n * m, hipMemcpyDeviceToDevice, st));
-    GP_TRY(launch_trsm_lower(h, st, s->L, n, n, s->rhs, N + m, n, false));                    // :19, :7 inner
+    GP_TRY(launch_trsm_lower(h, st, s->L, n, s->ldl, s->rhs, N + m, n, false));                    // :19, :7 inner
     GP_TRY(launch_colnorm_s(st, tmp, n, N, n, s->s));                                         // :20
     if (fused) {
         GP_TRY(launch_gemm(h, st, true, false, TRI_NONE, N, m, n, 1.0, tmp, n, W, n, 0.0, s->mean, N));
     } else {
-        GP_TRY(launch_trsm_lower(h, st, s->L, n, n, W, m, n, true));                          // :7 outer
+        GP_TRY(launch_trsm_lower(h, st, s->L, n, s->ldl, W, m, n, true));                          // :7 outer
         GP_TRY(launch_gemm(h, st, true, false, TRI_NONE, N, m, n, 1.0, s->kstar, n, W, n, 0.0, s->mean, N)); // :25
     }
     FstarEpiArgs a{};
@@ -277,11 +294,20 @@ int do_draw_beta(gpirt_sampler_s* s)
     return 0;
 }
 
+// S = K(theta, theta) + jitter into the lower blocks of L; with the bordered layout also K(c, theta) into the rows below
+int build_cov(gpirt_sampler_s* s)
+{
+    hipStream_t st = s->h->stream;
+    GP_TRY(launch_se_kernel_lower(st, s->theta, s->n, s->L, s->ldl, GPIRT_JITTER, s->opt.reserved[1] != 0));
+    if (s->ext > 0) GP_TRY(launch_se_kernel(st, s->knodes, s->ext, s->theta, s->n, s->L + s->n, s->ldl, 0.0));
+    return 0;
+}
+
 int do_factor(gpirt_sampler_s* s)
 {
     hipStream_t st = s->h->stream;
-    GP_TRY(launch_se_kernel_lower(st, s->theta, s->n, s->L, s->n, GPIRT_JITTER, s->opt.reserved[1] != 0));   // :76-77
-    return launch_potrf_lower(s->h, st, s->L, s->n, s->n, false, !s->sticky_info); // :78
+    GP_TRY(build_cov(s));                                                                                  // :76-77
+    return launch_potrf_lower(s->h, st, s->L, s->n, s->ldl, false, !s->sticky_info, s->ext);              // :78
 }
 
 // draw_theta's CDF came out 0/0 for some respondents: the reference reads theta_star[N] out of bounds there
@@ -327,7 +353,15 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
 #define GP_A(p, cnt) do { rc = dalloc(s, &(p), (size_t)(cnt)); if (rc) { gpirt_sampler_destroy(s); return rc; } } while (0)
     GP_A(s->y, n * m);       GP_A(s->Ypm, n * 2 * m);  GP_A(s->theta, n);       GP_A(s->theta_new, n);
     GP_A(s->f, n * m);       GP_A(s->Z, n * m);        GP_A(s->NU, n * m);      GP_A(s->beta, 2 * m);
-    GP_A(s->mu, n * m);      GP_A(s->mu_star, N * m + 1); GP_A(s->fstar, N * m + 1); GP_A(s->L, n * n);
+    s->kr = s->opt.reserved[2];
+    if (s->kr != 0 && (!s->opt.fstar_fused || s->kr < 16 || s->kr > 128 || (s->kr % 16) != 0)) {
+        set_error("kstar_rank must be a multiple of 16 in 16..128 and needs fstar_fused");
+        gpirt_sampler_destroy(s);
+        return GPIRT_E_ARG;
+    }
+    s->ext = (s->kr > 0 && s->opt.fstar_fused && (n % 64) == 0 && !(getenv("GPIRT_BORDERED") && atoi(getenv("GPIRT_BORDERED")) == 2)) ? s->kr : 0;
+    s->ldl = n + s->ext;
+    GP_A(s->mu, n * m);      GP_A(s->mu_star, N * m + 1); GP_A(s->fstar, N * m + 1); GP_A(s->L, s->ldl * n);
     GP_A(s->tstar, N + 1);   GP_A(s->rhs, n * (N + m) + 2); GP_A(s->mean, N * m + 1); GP_A(s->s, N + 1);
     GP_A(s->Gpm, ((N + 127) / 128 * 128) * 2 * m + 2); GP_A(s->logpost, N * n + 2); GP_A(s->irf_sum, N * m + 1);
     // padding rows stay zero; cleared on the handle's stream (drained below) -- a null-stream hipMemset is not
@@ -338,13 +372,7 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
     GP_A(s->pm, 2 * m);      GP_A(s->ps, 2 * m);       GP_A(s->step, 2 * m);
     GP_A(s->ess_k, m);       GP_A(s->flags, 4);
     if (!s->opt.fstar_fused) GP_A(s->kstar, n * N + 2);
-    s->kr = s->opt.reserved[2];
     if (s->kr != 0) {
-        if (!s->opt.fstar_fused || s->kr < 16 || s->kr > 128 || (s->kr % 16) != 0) {
-            set_error("kstar_rank must be a multiple of 16 in 16..128 and needs fstar_fused");
-            gpirt_sampler_destroy(s);
-            return GPIRT_E_ARG;
-        }
         GP_A(s->knodes, s->kr); GP_A(s->kV, N * s->kr);
         GP_A(s->kparts, (size_t)KSPLIT * s->kr * (s->kr + m)); GP_A(s->kP, (size_t)s->kr * (s->kr + m));
     }
@@ -426,7 +454,7 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
         hipMemcpyAsync(s->knodes, nodes.data(), sizeof(double) * (size_t)r, hipMemcpyHostToDevice, st);
         hipMemcpyAsync(s->kV, V.data(), sizeof(double) * (size_t)(N * r), hipMemcpyHostToDevice, st);
     }
-    hipMemsetAsync(s->L, 0, sizeof(double) * (size_t)(n * n), st);         // strict upper stays zero
+    hipMemsetAsync(s->L, 0, sizeof(double) * (size_t)(s->ldl * n), st);    // strict upper stays zero
     hipMemsetAsync(s->irf_sum, 0, sizeof(double) * (size_t)(N * m), st);   // :42
     hipMemsetAsync(s->flags, 0, 4 * sizeof(int), st);
     hipMemsetAsync(s->ess_k, 0, sizeof(int) * (size_t)m, st);
@@ -464,7 +492,7 @@ int gpirt_sampler_init(gpirt_sampler_t s)
     GP_TRY(do_factor(s));                                                         // :15-17
     if (!stream_mode(s)) {
         GP_TRY(launch_item_uniforms(st, s->opt.seed, 0, GPIRT_ST_INIT_F, (uint32_t)s->opt.item0, m, n, s->Z, true));
-        GP_TRY(launch_gemm(h, st, false, false, TRI_A_LOWER, n, m, n, 1.0, s->L, n, s->Z, n, 0.0, s->f, n)); // :18-21
+        GP_TRY(launch_gemm(h, st, false, false, TRI_A_LOWER, n, m, n, 1.0, s->L, s->ldl, s->Z, n, 0.0, s->f, n)); // :18-21
         // beta(p, j) = R::rnorm(prior_mean, prior_sd), index = p                    :22-27
         std::vector<double> b((size_t)(2 * m));
         const double* pm = s->host_tmp.data();
@@ -506,7 +534,7 @@ int gpirt_sampler_init(gpirt_sampler_t s)
         GP_HIP(hipMemcpyAsync(s->U, s->hU, (nf + nfs) * sizeof(double), hipMemcpyHostToDevice, st));
         GP_HIP(hipMemsetAsync(s->pos, 0, sizeof(uint64_t), st));
         GP_TRY(launch_rstream_normals(st, s->U, s->pos, 2 * n, n, m, s->Z));
-        GP_TRY(launch_gemm(h, st, false, false, TRI_A_LOWER, n, m, n, 1.0, s->L, n, s->Z, n, 0.0, s->f, n));
+        GP_TRY(launch_gemm(h, st, false, false, TRI_A_LOWER, n, m, n, 1.0, s->L, s->ldl, s->Z, n, 0.0, s->f, n));
         GP_TRY(launch_advance_pos(st, s->pos, nf));
         GP_HIP(hipMemcpyAsync(s->beta, b.data(), sizeof(double) * b.size(), hipMemcpyHostToDevice, st));
         GP_HIP(hipStreamSynchronize(st));
@@ -597,7 +625,7 @@ int gpirt_sampler_build_cov(gpirt_sampler_t s)
     GP_ARG(s && s->initialised);
     hipStream_t st = s->h->stream;
     if (!s->sticky_info) GP_HIP(hipMemsetAsync(s->h->d_info, 0, sizeof(int), st));
-    return launch_se_kernel_lower(st, s->theta, s->n, s->L, s->n, GPIRT_JITTER, s->opt.reserved[1] != 0);   // :76-77
+    return build_cov(s);                                                                                   // :76-77
 }
 
 int gpirt_sampler_skip_factor(gpirt_sampler_t s)
@@ -693,7 +721,68 @@ static int lookup(gpirt_sampler_t s, const char* name, void** p, int64_t* count)
 int gpirt_sampler_devptr(gpirt_sampler_t s, const char* name, void** d_ptr, int64_t* count)
 {
     GP_ARG(s && name && d_ptr && count);
-    return lookup(s, name, d_ptr, count);
+    GP_TRY(lookup(s, name, d_ptr, count));
+    if (strcmp(name, "L") == 0) *count = s->ldl * s->n;     // the whole buffer (leading dimension gpirt_sampler_ldl)
+    return 0;
+}
+
+int gpirt_sampler_ldl(gpirt_sampler_t s, int64_t* ldl)
+{
+    GP_ARG(s && ldl);
+    *ldl = s->ldl;
+    return 0;
+}
+
+// ---- the factorisation in pieces on this sampler's L (distributed hosts; include/gpirt_hip.h) ---------------------
+int gpirt_sampler_panel_factor(gpirt_sampler_t s, int64_t p)
+{
+    GP_ARG(s && s->initialised);
+    return potrf_panel_factor(s->h, s->h->stream, s->L, s->n, s->ldl, p, s->ext);
+}
+
+int gpirt_sampler_panel_update(gpirt_sampler_t s, int64_t p, int64_t c)
+{
+    GP_ARG(s && s->initialised);
+    return potrf_panel_update(s->h, s->h->stream, s->L, s->n, s->ldl, p, c, s->ext);
+}
+
+int gpirt_sampler_panel_copy(gpirt_sampler_t s, int64_t p, double* d_buf, int to_buf)
+{
+    GP_ARG(s && s->initialised && d_buf);
+    return potrf_panel_copy(s->h->stream, s->L, s->n, s->ldl, p, d_buf, to_buf != 0, s->ext);
+}
+
+int gpirt_sampler_panel_rows(gpirt_sampler_t s, int64_t* rows)
+{
+    GP_ARG(s && rows);
+    *rows = s->n + s->ext;
+    return 0;
+}
+
+// dst's chain state := src's (theta, f, beta, mu, mu_star, fstar, the n x n factor, the iteration counter): lets a second
+// sampler with other options replay a stage on the same state (bench.py's in-run check of the draw_fstar forms)
+int gpirt_sampler_copy_state(gpirt_sampler_t dst, gpirt_sampler_t src)
+{
+    GP_ARG(dst && src && dst->initialised && src->initialised && dst->n == src->n && dst->m == src->m && dst->h == src->h);
+    hipStream_t st = dst->h->stream;
+    const int64_t n = dst->n, m = dst->m, N = dst->N;
+    GP_HIP(hipMemcpyAsync(dst->theta, src->theta, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    GP_HIP(hipMemcpyAsync(dst->f, src->f, sizeof(double) * (size_t)(n * m), hipMemcpyDeviceToDevice, st));
+    GP_HIP(hipMemcpyAsync(dst->beta, src->beta, sizeof(double) * (size_t)(2 * m), hipMemcpyDeviceToDevice, st));
+    GP_HIP(hipMemcpyAsync(dst->mu, src->mu, sizeof(double) * (size_t)(n * m), hipMemcpyDeviceToDevice, st));
+    GP_HIP(hipMemcpyAsync(dst->mu_star, src->mu_star, sizeof(double) * (size_t)(N * m), hipMemcpyDeviceToDevice, st));
+    GP_HIP(hipMemcpyAsync(dst->fstar, src->fstar, sizeof(double) * (size_t)(N * m), hipMemcpyDeviceToDevice, st));
+    GP_HIP(hipMemcpy2DAsync(dst->L, (size_t)dst->ldl * 8, src->L, (size_t)src->ldl * 8, (size_t)n * 8, (size_t)n,
+                            hipMemcpyDeviceToDevice, st));
+    if (dst->ext > 0) {
+        // the rows below L are (L^-1 K(theta, c))^T: rebuild them for the copied (theta, L) by the forward solve
+        double* Bu = dst->rhs;
+        GP_TRY(launch_se_kernel(st, dst->theta, n, dst->knodes, dst->kr, Bu, n, 0.0));
+        GP_TRY(launch_trsm_lower(dst->h, st, dst->L, n, dst->ldl, Bu, dst->kr, n, false));
+        GP_TRY(launch_transpose(st, Bu, n, dst->kr, n, dst->L + n, dst->ldl));
+    }
+    dst->iter = src->iter;
+    return 0;
 }
 
 int gpirt_sampler_get(gpirt_sampler_t s, const char* name, double* h_out, int64_t count)
@@ -703,7 +792,13 @@ int gpirt_sampler_get(gpirt_sampler_t s, const char* name, double* h_out, int64_
     GP_TRY(lookup(s, name, &p, &c));
     GP_ARG(count <= c);
     const size_t esz = strcmp(name, "ess_k") == 0 ? sizeof(int) : sizeof(double);
-    GP_HIP(hipMemcpyAsync(h_out, p, esz * (size_t)count, hipMemcpyDeviceToHost, s->h->stream));
+    if (strcmp(name, "L") == 0 && s->ldl != s->n) {       // n x n out of the (n + ext) x n buffer
+        GP_ARG(count == s->n * s->n);
+        GP_HIP(hipMemcpy2DAsync(h_out, (size_t)s->n * 8, p, (size_t)s->ldl * 8, (size_t)s->n * 8, (size_t)s->n,
+                                hipMemcpyDeviceToHost, s->h->stream));
+    } else {
+        GP_HIP(hipMemcpyAsync(h_out, p, esz * (size_t)count, hipMemcpyDeviceToHost, s->h->stream));
+    }
     GP_HIP(hipStreamSynchronize(s->h->stream));
     return 0;
 }
@@ -714,7 +809,13 @@ int gpirt_sampler_set(gpirt_sampler_t s, const char* name, const double* h_in, i
     void* p; int64_t c;
     GP_TRY(lookup(s, name, &p, &c));
     GP_ARG(count <= c && strcmp(name, "ess_k") != 0);
-    GP_HIP(hipMemcpyAsync(p, h_in, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, s->h->stream));
+    if (strcmp(name, "L") == 0 && s->ldl != s->n) {
+        GP_ARG(count == s->n * s->n);
+        GP_HIP(hipMemcpy2DAsync(p, (size_t)s->ldl * 8, h_in, (size_t)s->n * 8, (size_t)s->n * 8, (size_t)s->n,
+                                hipMemcpyHostToDevice, s->h->stream));
+    } else {
+        GP_HIP(hipMemcpyAsync(p, h_in, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, s->h->stream));
+    }
     GP_HIP(hipStreamSynchronize(s->h->stream));
     return 0;
 }

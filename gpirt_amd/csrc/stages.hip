@@ -386,6 +386,34 @@ int launch_linear_mean(hipStream_t stream, const double* x, int64_t n, const dou
     return 0;
 }
 
+__global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ in, int64_t rows, int64_t cols, int64_t ldi,
+                                                        double* __restrict__ out, int64_t ldo)
+{
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    const int64_t r0 = (int64_t)blockIdx.x * 32, c0 = (int64_t)blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t r = r0 + tx, c = c0 + ty + 8 * k;
+        tile[ty + 8 * k][tx] = (r < rows && c < cols) ? in[r + c * ldi] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t c = c0 + tx, r = r0 + ty + 8 * k;
+        if (r < rows && c < cols) out[c + r * ldo] = tile[tx][ty + 8 * k];
+    }
+}
+
+int launch_transpose(hipStream_t stream, const double* in, int64_t rows, int64_t cols, int64_t ldi, double* out, int64_t ldo)
+{
+    if (rows <= 0 || cols <= 0) return 0;
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((rows + 31) / 32), (unsigned)((cols + 31) / 32)), dim3(256), 0, stream,
+                       in, rows, cols, ldi, out, ldo);
+    GP_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_axpy_irf(hipStream_t stream, double* acc, const double* fstar, int64_t count)
 {
     if (count <= 0) return 0;

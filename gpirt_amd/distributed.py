@@ -99,11 +99,12 @@ class ShardedSampler:
         import torch
         e, W, n = self.engine, self.engine.panel_width, self.n
         NP = (n + W - 1) // W
+        rows = e.panel_rows                         # n, plus the rows of a bordered factorisation
         owner = lambda p: p % self.world
         if self._panel_bufs is None:
             # two broadcast buffers (panel p + 1 travels while panel p is still being applied)
-            self._panel_bufs = [torch.empty(n * min(W, n), dtype=torch.float64, device=e.torch_device) for _ in range(2)]
-        buf = lambda p: self._panel_bufs[p % 2][: (n - p * W) * min(W, n - p * W)]
+            self._panel_bufs = [torch.empty(rows * min(W, n), dtype=torch.float64, device=e.torch_device) for _ in range(2)]
+        buf = lambda p: self._panel_bufs[p % 2][: (rows - p * W) * min(W, n - p * W)]
         e.build_cov()
         work = None
 

@@ -170,21 +170,26 @@ class Sampler:
         import torch
         return torch.device("cuda", self.handle.device)
 
-    def _Lptr(self):
-        if not hasattr(self, "_L_ptr"):
-            self._L_ptr = C.c_void_p(self.devptr("L")[0])
-        return self._L_ptr
+    @property
+    def panel_rows(self) -> int:
+        """rows of L's column blocks that travel with a panel (n, plus the rows of the bordered factorisation)"""
+        r = C.c_int64()
+        check(self.lib.gpirt_sampler_panel_rows(self._s, C.byref(r)))
+        return r.value
 
     def panel_factor(self, p: int):
-        check(self.lib.gpirt_potrf_panel_factor(self.handle.ptr, self._Lptr(), self.n, self.n, int(p)))
+        check(self.lib.gpirt_sampler_panel_factor(self._s, int(p)))
 
     def panel_update(self, p: int, c: int):
-        check(self.lib.gpirt_potrf_panel_update(self.handle.ptr, self._Lptr(), self.n, self.n, int(p), int(c)))
+        check(self.lib.gpirt_sampler_panel_update(self._s, int(p), int(c)))
 
     def panel_copy(self, p: int, buf, to_buf: bool):
-        """rows [pW, n) of outer panel p <-> the dense torch buffer `buf` (what the host broadcasts)"""
-        check(self.lib.gpirt_potrf_panel_copy(self.handle.ptr, self._Lptr(), self.n, self.n, int(p),
-                                              C.c_void_p(buf.data_ptr()), int(bool(to_buf))))
+        """rows [pW, panel_rows) of outer panel p <-> the dense torch buffer `buf` (what the host broadcasts)"""
+        check(self.lib.gpirt_sampler_panel_copy(self._s, int(p), C.c_void_p(buf.data_ptr()), int(bool(to_buf))))
+
+    def copy_state_from(self, other: "Sampler"):
+        check(self.lib.gpirt_sampler_copy_state(self._s, other._s))
+
     def accumulate_irf(self): self._call("gpirt_sampler_accumulate_irf")
     def check(self): self._call("gpirt_sampler_check")
 

@@ -236,6 +236,12 @@ int gpirt_sampler_factor(gpirt_sampler_t s);             /* :76-78 / :95-97 */
  * factorisation the host distributes with the gpirt_potrf_panel_* pieces on the "L" devptr; gpirt_sampler_skip_factor
  * then closes the iteration. */
 int gpirt_sampler_build_cov(gpirt_sampler_t s);
+/* The pieces on this sampler's own "L" (which may carry extra rows below the n x n factor, see gpirt_sampler_ldl):
+ * panel_rows = number of rows of a panel's column block that travel (n + extra - p W rows for panel p). */
+int gpirt_sampler_panel_factor(gpirt_sampler_t s, int64_t p);
+int gpirt_sampler_panel_update(gpirt_sampler_t s, int64_t p, int64_t c);
+int gpirt_sampler_panel_copy(gpirt_sampler_t s, int64_t p, double* d_buf, int to_buf);
+int gpirt_sampler_panel_rows(gpirt_sampler_t s, int64_t* rows);
 /* closes the iteration WITHOUT factoring: for ranks that receive L by broadcast ("L" devptr) */
 int gpirt_sampler_skip_factor(gpirt_sampler_t s);
 int gpirt_sampler_accumulate_irf(gpirt_sampler_t s);     /* :103 */
@@ -247,6 +253,13 @@ int gpirt_sampler_check(gpirt_sampler_t s);              /* syncs; returns potrf
 /* Device pointer of a named state array ("theta","f","beta","mu","mu_star","fstar","L","logpost",
  * "irf_sum","ess_k") and its element count; the pointer stays valid until destroy. */
 int gpirt_sampler_devptr(gpirt_sampler_t s, const char* name, void** d_ptr, int64_t* count);
+/* Leading dimension of the "L" device array.  With the rank-r K* (gpirt_options.reserved[2]) and n % 64 == 0 the array
+ * is (n + r) x n: the r rows below the factor enter the factorisation as K(c, theta) and leave it as
+ * (L^-1 K(theta, c))^T -- draw_fstar's forward solve (src/draw-fstar.cpp:19) comes out of a bordered factorisation.
+ * gpirt_sampler_get / _set("L") always move the n x n factor. */
+int gpirt_sampler_ldl(gpirt_sampler_t s, int64_t* ldl);
+/* dst's chain state := src's (theta, f, beta, mu, mu_star, fstar, L, iteration counter); same handle, same n and m. */
+int gpirt_sampler_copy_state(gpirt_sampler_t dst, gpirt_sampler_t src);
 int gpirt_sampler_get(gpirt_sampler_t s, const char* name, double* h_out, int64_t count);
 int gpirt_sampler_set(gpirt_sampler_t s, const char* name, const double* h_in, int64_t count);
 int gpirt_sampler_finish_irfs(gpirt_sampler_t s, int sample_iterations, double* h_irfs); /* :106-111 */

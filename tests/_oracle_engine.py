@@ -136,6 +136,10 @@ class OracleEngine:
     panel_width = 16
     torch_device = torch.device("cpu")
 
+    @property
+    def panel_rows(self):
+        return self.n
+
     def build_cov(self):
         S = O.se_kernel(self.theta, self.theta)
         S[np.diag_indices_from(S)] += 0.001

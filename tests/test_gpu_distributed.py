@@ -14,6 +14,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _case(chol):
+    """(n, sampler options, ShardedSampler chol mode).  distributed: three 1024-column outer panels, the last ragged;
+    distributed_lowrank: the bordered factorisation (64 extra rows riding through every panel and broadcast)."""
+    if chol == "distributed":
+        return 2500, {}, "distributed"
+    if chol == "distributed_lowrank":
+        return 2560, dict(fstar_fused=True, kstar_rank=64), "distributed"
+    return 300, {}, chol
+
+
 def _run(rank, world, port, chol, outdir):
     sys.path.insert(0, ROOT)
     import torch
@@ -26,14 +36,14 @@ def _run(rank, world, port, chol, outdir):
     from gpirt_amd.ops import Handle
     from gpirt_amd.sampler import Sampler
     from gpirt_amd.synthetic import make_responses
-    n = 2500 if chol == "distributed" else 300      # distributed: three 1024-column outer panels (the last ragged)
+    n, kw, mode = _case(chol)
     y, th0 = make_responses(n, 22, seed=6)
     h = Handle(0)
 
     def factory(yl, th, pm, ps, st, item0, m_total):
-        return Sampler(h, yl, th, pm, ps, st, rng="item", seed=77, item0=item0, m_total=m_total)
+        return Sampler(h, yl, th, pm, ps, st, rng="item", seed=77, item0=item0, m_total=m_total, **kw)
 
-    ss = ShardedSampler(factory, y, th0, dist=dist, chol=chol)
+    ss = ShardedSampler(factory, y, th0, dist=dist, chol=mode)
     ss.init()
     for _ in range(2):
         ss.step()
@@ -45,16 +55,17 @@ def _run(rank, world, port, chol, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("chol", ["replicated", "bcast", "distributed"])
+@pytest.mark.parametrize("chol", ["replicated", "bcast", "distributed", "distributed_lowrank"])
 def test_two_ranks_one_gpu_match_single_process(handle, tmp_path, chol):
     import torch.multiprocessing as mp
     from gpirt_amd.sampler import Sampler
     from gpirt_amd.synthetic import make_responses
-    port = 29700 + (os.getpid() % 1000) + {"replicated": 0, "bcast": 1, "distributed": 2}[chol]
+    port = 29700 + (os.getpid() % 1000) + {"replicated": 0, "bcast": 1, "distributed": 2, "distributed_lowrank": 3}[chol]
     mp.spawn(_run, args=(2, port, chol, str(tmp_path)), nprocs=2, join=True)
     got = np.load(tmp_path / f"gpu_sharded_{chol}.npz")
-    y, th0 = make_responses(2500 if chol == "distributed" else 300, 22, seed=6)
-    ref = Sampler(handle, y, th0, rng="item", seed=77)
+    n, kw, _ = _case(chol)
+    y, th0 = make_responses(n, 22, seed=6)
+    ref = Sampler(handle, y, th0, rng="item", seed=77, **kw)
     ref.init()
     for _ in range(2):
         ref.step()
