@@ -91,6 +91,12 @@ int potrf_panel_copy(hipStream_t stream, double* A, int64_t n, int64_t lda, int6
 
 using namespace gpirt;
 
+static int create_own_stream(gpirt_handle_t* out, int device, bool high_priority);
+namespace gpirt {
+// a handle on a high-priority stream of its own: the sampler's side work must win free slots against resident kernels
+int create_side_handle(gpirt_handle_t* out, int device) { return create_own_stream(out, device, true); }
+}
+
 extern "C" {
 
 int gpirt_version(void) { return 100; }
@@ -179,14 +185,19 @@ int gpirt_synchronize(gpirt_handle_t h)
     return 0;
 }
 
-int gpirt_create_own_stream(gpirt_handle_t* out, int device)
+static int create_own_stream(gpirt_handle_t* out, int device, bool high_priority)
 {
     GP_ARG(out != nullptr);
     *out = nullptr;
     GP_TRY(check_device(device < 0 ? 0 : device));
     if (device >= 0) GP_HIP(hipSetDevice(device));
     hipStream_t st = nullptr;
-    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    int lo_pri = 0, hi_pri = 0;
+    hipError_t e = hipSuccess;
+    if (high_priority) e = hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri);
+    if (e == hipSuccess)
+        e = high_priority ? hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi_pri)
+                          : hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
     if (e != hipSuccess) { set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); return GPIRT_E_HIP; }
     // the handle is set up ON this stream (gpirt_create clears its workspace there and drains it)
     const int rc = gpirt_create(out, device, st);
@@ -194,6 +205,8 @@ int gpirt_create_own_stream(gpirt_handle_t* out, int device)
     (*out)->own_stream = true;
     return 0;
 }
+
+int gpirt_create_own_stream(gpirt_handle_t* out, int device) { return create_own_stream(out, device, false); }
 
 int gpirt_set_stream(gpirt_handle_t h, void* stream)
 {

@@ -283,18 +283,20 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
     }
     static const int hold_rest = env_int("GPIRT_HOLD_REST", 2);     // 1: always, 2: never (default), 3: only before 128-tile updates
     const int64_t nbp_la = (env_int("GPIRT_NBP", NBP) / NBI) * NBI > 0 ? (env_int("GPIRT_NBP", NBP) / NBI) * NBI : NBP;
-    // Deferred trailing updates (opt-in, GPIRT_DEFER=3).  Panel q's update of a block column r >= q + 2 is not
-    // needed before panel r is factored.  Applying it to the whole rest of the matrix at once (right-looking,
-    // the default) loads the main stream with 38.7 GFLOP behind panel 0 and 1.1 behind panel 5, while the side
+    // Deferred trailing updates (GPIRT_DEFER=3, the default since round 2; =2 is the plain right-looking order).
+    // Panel q's update of a block column r >= q + 2 is not
+    // needed before panel r is factored.  Applying it to the whole rest of the matrix at once (right-looking)
+    // loads the main stream with 38.7 GFLOP behind panel 0 and 1.1 behind panel 5, while the side
     // chain needs the same ~0.55 ms every time.  With =3 each step only brings ONE more block column (GPIRT_DEFER_AHEAD)
     // up to date, one launch per finished panel that has not reached it yet: 11.8 / 19.3 / 22.6 / 21.5 / 16.1 /
     // 6.4 GFLOP per step at n = 8192.  Every block of C still receives its rank-1024 updates in ascending panel
-    // order, so L is bit-identical (tools/defer_check.py).  Measured: 120 it/s instead of 116 -- but those
-    // block-column launches are too small for the 128-tile kernel (356 tiles at most) and run on 64-tiles at
-    // 0.48 of the MFMA peak beside the panel kernel, against 0.53 for the undeferred 128-tile launches; =1 fuses a
-    // step's launches into one product of depth (q + 1) * 1024 (one read-modify-write of C, but 1.2 rounds of
-    // long tiles: 116 it/s).
-    static const int defer = env_int("GPIRT_DEFER", 2);      // 2: off (default), 3: one launch per panel, 1: fused
+    // order, so L is bit-identical (tools/defer_check.py; the factorisation in pieces of the distributed hosts is
+    // tested against it bit for bit).  Measured in round 2: 119.8 it/s against 115.4, all syrk launches together at
+    // 0.48 of the MFMA peak against 0.45 -- the block-column launches are 64-tile launches (356 128-tiles at most)
+    // whose work-groups turn over every ~40 us, so the panel kernel's work-groups (each needs a whole CU) find room
+    // sooner than beside 128-tile updates; =1 fuses a step's launches into one product of depth (q + 1) * 1024
+    // (one read-modify-write of C, but 1.2 rounds of long tiles: slower).
+    static const int defer = env_int("GPIRT_DEFER", 3);      // 3: one launch per panel and block column (default), 2: off, 1: fused
     std::vector<int64_t> done_col;                   // (mode 3) columns < done_col[q] carry panel q's update
     GP_TRY(factor_panel(h, stream, A, nr, lda, 0, nbo < n ? nbo : n));
     for (int64_t K0 = 0; K0 < n; K0 += nbo) {

@@ -50,6 +50,14 @@ struct gpirt_sampler_s {
     // extra rows enter the factorisation holding K(c, theta) (r x n) and leave it holding (L^-1 K(theta, c))^T -- the
     // forward solve of draw_fstar comes out of the bordered factorisation (potrf.hip) for ~1 % more work.
     int64_t ext = 0, ldl = 0;
+    // Work that needs only L (not this iteration's f) runs on a stream of the sampler's own, beside draw_f's elliptical
+    // slice kernel: the part of the low-rank draw_fstar that depends on the factor alone (C = L^-T B, G = B^T B).
+    // haux is a private handle on that stream (its own trsm / split-K workspaces: several
+    // samplers may share `h`).  prep_valid: C and G belong to the current L; *_pending: the main stream has not yet
+    // waited for the event.
+    gpirt_handle_t haux = nullptr;
+    hipEvent_t ev_trmm = nullptr, ev_prep = nullptr;
+    bool prep_valid = false, prep_pending = false;
     // respondent-block form of draw_theta for item-sharded runs (gpirt_sampler_set_theta_block): this rank's
     // block of respondents with ALL items
     int64_t blk_i0 = 0, blk_n = 0, blk_m = 0;
@@ -142,6 +150,8 @@ __global__ void trmv_lower_kernel(const double* __restrict__ L, int64_t n, int64
     out[i] = acc;
 }
 
+int fstar_prep(gpirt_sampler_s* s, gpirt_handle_t hh);
+
 int do_draw_f(gpirt_sampler_s* s)
 {
     gpirt_handle_t h = s->h;
@@ -151,10 +161,23 @@ int do_draw_f(gpirt_sampler_s* s)
     if (!stream_mode(s)) {
         GP_TRY(launch_item_uniforms(st, s->opt.seed, iter, GPIRT_ST_F_Z, (uint32_t)s->opt.item0, m, n, s->Z, true));
         GP_TRY(launch_gemm(h, st, false, false, TRI_A_LOWER, n, m, n, 1.0, s->L, s->ldl, s->Z, n, 0.0, s->NU, n));
+        const bool prep = s->haux && s->ext > 0 && !s->prep_valid;
+        if (prep) GP_HIP(hipEventRecord(s->ev_trmm, st));
         EssArgs a{};
         a.f = s->f; a.nu = s->NU; a.y = s->y; a.mu = s->mu; a.n = n; a.m = m; a.k_out = s->ess_k;
         a.err = s->flags; a.seed = s->opt.seed; a.iter = iter; a.item0 = (uint32_t)s->opt.item0;
-        return launch_ess(st, a);
+        GP_TRY(launch_ess(st, a));
+        if (prep) {
+            // Beside the slice kernel (VALU-bound; the matrix pipes idle): what the low-rank draw_fstar needs from L
+            // alone, on the sampler's own stream.  (Not beside the product above: its 256 work-groups hold every CU for
+            // ~1 ms and anything dispatched next to them starves.)
+            hipStream_t ax = s->haux->stream;
+            GP_HIP(hipStreamWaitEvent(ax, s->ev_trmm, 0));
+            GP_TRY(fstar_prep(s, s->haux));
+            GP_HIP(hipEventRecord(s->ev_prep, ax));
+            s->prep_valid = true; s->prep_pending = true;
+        }
+        return 0;
     }
     // exact R order: item j draws its n normals, then u, eps0 and one uniform per rejection
     for (int64_t j = 0; j < m; ++j) {
@@ -167,6 +190,25 @@ int do_draw_f(gpirt_sampler_s* s)
         GP_TRY(launch_ess(st, a));
     }
     return 0;
+}
+
+// The factor-only part of the low-rank draw_fstar (bordered layout): B^T (r x n) sits in the rows below L;
+//   Cu = L^-T B  (n x r: transpose, then the transposed solve through the block inverses of L),
+//   G  = B^T B   (r x r, split-K over n).
+// Runs on hh->stream with hh's workspaces: the sampler's private handle beside draw_f, or the caller's handle inline.
+int fstar_prep(gpirt_sampler_s* s, gpirt_handle_t hh)
+{
+    hipStream_t st = hh->stream;
+    const int64_t n = s->n;
+    const int r = s->kr;
+    double* Cu = s->rhs + (size_t)n * r;
+    const double* Bt = s->L + n;
+    GP_TRY(launch_transpose(st, Bt, r, n, s->ldl, Cu, n));
+    // the block inverses of L are reused when this handle already holds them (built panel by panel behind the
+    // factorisation, do_factor; or by an earlier call) -- invalidate_factor_products() clears that whenever L changes
+    GP_TRY(launch_trsm_lower(hh, st, s->L, n, s->ldl, Cu, r, n, true, true));
+    return launch_gemm_splitk(st, false, true, r, r, n, 1.0, Bt, s->ldl, Bt, s->ldl, s->kparts, r, (int64_t)r * r, KSPLIT,
+                              s->kP, r, 0.0);
 }
 
 int do_draw_fstar(gpirt_sampler_s* s, uint32_t iter)
@@ -188,10 +230,10 @@ int do_draw_fstar(gpirt_sampler_s* s, uint32_t iter)
         double* Cu = s->rhs + (size_t)n * r;                  // n x r : B, then C
         const bool bordered = s->ext > 0;
         if (bordered) {
-            // B^T (r x n) already sits in the rows below L: the bordered factorisation produced it (do_factor)
-            const double* Bt = s->L + n;
-            GP_TRY(launch_transpose(st, Bt, r, n, s->ldl, Cu, n));                       // Cu = B
-            GP_TRY(launch_trsm_lower(h, st, s->L, n, s->ldl, Cu, r, n, true));
+            // C = L^-T B and G = B^T B depend on the factor alone: usually already under way on the sampler's own
+            // stream since draw_f's product finished (do_draw_f); otherwise computed here
+            if (!s->prep_valid) { GP_TRY(fstar_prep(s, h)); s->prep_valid = true; }
+            else if (s->prep_pending) { GP_HIP(hipStreamWaitEvent(st, s->ev_prep, 0)); s->prep_pending = false; }
         } else {
             GP_TRY(launch_se_kernel(st, s->theta, n, s->knodes, r, Bu, n, 0.0));
             GP_TRY(launch_trsm_lower(h, st, s->L, n, s->ldl, Bu, r, n, false));
@@ -200,10 +242,7 @@ int do_draw_fstar(gpirt_sampler_s* s, uint32_t iter)
         }
         double* G = s->kP;                                    // r x r
         double* Q = s->kP + (size_t)r * r;                    // r x m
-        if (bordered)   // G = B^T B from the r x n rows (NT form)
-            GP_TRY(launch_gemm_splitk(st, false, true, r, r, n, 1.0, s->L + n, s->ldl, s->L + n, s->ldl, s->kparts, r,
-                                      (int64_t)r * r, KSPLIT, G, r, 0.0));
-        else
+        if (!bordered)
             GP_TRY(launch_gemm_splitk(st, true, false, r, r, n, 1.0, Bu, n, Bu, n, s->kparts, r, (int64_t)r * r, KSPLIT, G, r, 0.0));
         GP_TRY(launch_gemm_splitk(st, true, false, r, m, n, 1.0, Cu, n, s->f, n, s->kparts, r, (int64_t)r * m, KSPLIT, Q, r, 0.0));
         GP_TRY(launch_lowrank_s(st, s->kV, N, r, G, r, s->s));
@@ -294,6 +333,22 @@ int do_draw_beta(gpirt_sampler_s* s)
     return 0;
 }
 
+// everything derived from the factor (C, G, cached block inverses on either handle) is stale once L changes
+void invalidate_factor_products(gpirt_sampler_s* s)
+{
+    s->prep_valid = false;
+    if (s->h->trsm_winv_L == s->L) s->h->trsm_winv_L = nullptr;
+    if (s->haux && s->haux->trsm_winv_L == s->L) s->haux->trsm_winv_L = nullptr;
+}
+
+// the main stream waits for whatever the sampler's own stream still has in flight
+int aux_join(gpirt_sampler_s* s)
+{
+    hipStream_t st = s->h->stream;
+    if (s->prep_pending) { GP_HIP(hipStreamWaitEvent(st, s->ev_prep, 0)); s->prep_pending = false; }
+    return 0;
+}
+
 // S = K(theta, theta) + jitter into the lower blocks of L; with the bordered layout also K(c, theta) into the rows below
 int build_cov(gpirt_sampler_s* s)
 {
@@ -306,6 +361,8 @@ int build_cov(gpirt_sampler_s* s)
 int do_factor(gpirt_sampler_s* s)
 {
     hipStream_t st = s->h->stream;
+    GP_TRY(aux_join(s));                  // nothing of the old factor may still be read when it is overwritten
+    invalidate_factor_products(s);
     GP_TRY(build_cov(s));                                                                                  // :76-77
     return launch_potrf_lower(s->h, st, s->L, s->n, s->ldl, false, !s->sticky_info, s->ext);              // :78
 }
@@ -462,6 +519,15 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
     if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) {
         set_error("sampler upload failed"); gpirt_sampler_destroy(s); return GPIRT_E_HIP;
     }
+    if (!stream_mode(s) && !(getenv("GPIRT_AUX") && atoi(getenv("GPIRT_AUX")) == 2)) {
+        if ((getenv("GPIRT_AUX_PRIO") && atoi(getenv("GPIRT_AUX_PRIO")) == 2 ? gpirt_create_own_stream(&s->haux, h->device)
+                                                                            : create_side_handle(&s->haux, h->device)) != 0 ||
+            hipEventCreateWithFlags(&s->ev_trmm, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s->ev_prep, hipEventDisableTiming) != hipSuccess) {
+            gpirt_sampler_destroy(s);
+            return GPIRT_E_HIP;
+        }
+    }
     // keep pm/ps on the host for the R-stream init of beta
     s->host_tmp.assign(h_pm, h_pm + 2 * m);
     s->host_tmp.insert(s->host_tmp.end(), h_ps, h_ps + 2 * m);
@@ -473,6 +539,9 @@ int gpirt_sampler_destroy(gpirt_sampler_t s)
 {
     if (!s) return 0;
     if (s->h) hipStreamSynchronize(s->h->stream);
+    if (s->haux) { hipStreamSynchronize(s->haux->stream); gpirt_destroy(s->haux); }
+    if (s->ev_trmm) hipEventDestroy(s->ev_trmm);
+    if (s->ev_prep) hipEventDestroy(s->ev_prep);
     for (void* p : s->allocs) hipFree(p);
     if (s->hU) hipHostFree(s->hU);
     if (s->h_pos) hipHostFree(s->h_pos);
@@ -625,12 +694,15 @@ int gpirt_sampler_build_cov(gpirt_sampler_t s)
     GP_ARG(s && s->initialised);
     hipStream_t st = s->h->stream;
     if (!s->sticky_info) GP_HIP(hipMemsetAsync(s->h->d_info, 0, sizeof(int), st));
+    GP_TRY(aux_join(s));
+    invalidate_factor_products(s);
     return build_cov(s);                                                                                   // :76-77
 }
 
 int gpirt_sampler_skip_factor(gpirt_sampler_t s)
 {
     GP_ARG(s && s->initialised);
+    invalidate_factor_products(s);       // L arrived from elsewhere (broadcast / distributed pieces)
     s->iter += 1;
     return 0;
 }
@@ -676,6 +748,7 @@ int gpirt_sampler_set_iteration(gpirt_sampler_t s, int iter)
 {
     GP_ARG(s && s->initialised && iter >= 0);
     if (stream_mode(s)) { set_error("the R-stream replay has no iteration-keyed sub-streams"); return GPIRT_E_ARG; }
+    GP_TRY(aux_join(s));
     s->iter = iter;
     return 0;
 }
@@ -766,6 +839,8 @@ int gpirt_sampler_copy_state(gpirt_sampler_t dst, gpirt_sampler_t src)
     GP_ARG(dst && src && dst->initialised && src->initialised && dst->n == src->n && dst->m == src->m && dst->h == src->h);
     hipStream_t st = dst->h->stream;
     const int64_t n = dst->n, m = dst->m, N = dst->N;
+    GP_TRY(aux_join(dst)); GP_TRY(aux_join(src));
+    invalidate_factor_products(dst);
     GP_HIP(hipMemcpyAsync(dst->theta, src->theta, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
     GP_HIP(hipMemcpyAsync(dst->f, src->f, sizeof(double) * (size_t)(n * m), hipMemcpyDeviceToDevice, st));
     GP_HIP(hipMemcpyAsync(dst->beta, src->beta, sizeof(double) * (size_t)(2 * m), hipMemcpyDeviceToDevice, st));
@@ -792,6 +867,7 @@ int gpirt_sampler_get(gpirt_sampler_t s, const char* name, double* h_out, int64_
     GP_TRY(lookup(s, name, &p, &c));
     GP_ARG(count <= c);
     const size_t esz = strcmp(name, "ess_k") == 0 ? sizeof(int) : sizeof(double);
+    GP_TRY(aux_join(s));
     if (strcmp(name, "L") == 0 && s->ldl != s->n) {       // n x n out of the (n + ext) x n buffer
         GP_ARG(count == s->n * s->n);
         GP_HIP(hipMemcpy2DAsync(h_out, (size_t)s->n * 8, p, (size_t)s->ldl * 8, (size_t)s->n * 8, (size_t)s->n,
@@ -809,6 +885,8 @@ int gpirt_sampler_set(gpirt_sampler_t s, const char* name, const double* h_in, i
     void* p; int64_t c;
     GP_TRY(lookup(s, name, &p, &c));
     GP_ARG(count <= c && strcmp(name, "ess_k") != 0);
+    GP_TRY(aux_join(s));
+    invalidate_factor_products(s);
     if (strcmp(name, "L") == 0 && s->ldl != s->n) {
         GP_ARG(count == s->n * s->n);
         GP_HIP(hipMemcpy2DAsync(p, (size_t)s->ldl * 8, h_in, (size_t)s->n * 8, (size_t)s->n * 8, (size_t)s->n,

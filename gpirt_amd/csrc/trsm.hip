@@ -332,6 +332,110 @@ int trsm_rec(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t ldl,
 
 }  // namespace
 
+// Workspaces for the block inverses of an n x n factor (512-blocks; 1024-blocks too when `thin`) and the product
+// buffer; grown on demand (synchronises `stream` when it reallocates).
+int trsm_inverses_reserve(gpirt_handle_t h, hipStream_t stream, int64_t n, int64_t nrhs, bool thin)
+{
+    const int64_t nfull = n / NL4, npair = nfull / 2;
+    const size_t wbytes = (size_t)(npair + 1) * NI * NI * sizeof(double);
+    size_t tbytes = (size_t)NI * (size_t)nrhs * sizeof(double);
+    if (tbytes < (size_t)npair * NL4 * NL4 * sizeof(double)) tbytes = (size_t)npair * NL4 * NL4 * sizeof(double);
+    if (thin && tbytes < (size_t)(npair / 2) * NI * NI * sizeof(double)) tbytes = (size_t)(npair / 2) * NI * NI * sizeof(double);
+    if (h->trsm_winv_bytes < wbytes || h->trsm_tmp_bytes < tbytes) {
+        GP_HIP(hipStreamSynchronize(stream));
+        if (h->trsm_winv_bytes < wbytes) {
+            if (h->d_trsm_winv) GP_HIP(hipFree(h->d_trsm_winv));
+            h->d_trsm_winv = nullptr; h->trsm_winv_bytes = 0;
+            GP_HIP(hipMalloc(&h->d_trsm_winv, wbytes));
+            GP_HIP(hipMemsetAsync(h->d_trsm_winv, 0, wbytes, stream));   // upper-right quarters stay zero for good
+            GP_HIP(hipStreamSynchronize(stream));
+            h->trsm_winv_bytes = wbytes;
+        }
+        if (h->trsm_tmp_bytes < tbytes) {
+            if (h->d_trsm_tmp) GP_HIP(hipFree(h->d_trsm_tmp));
+            h->d_trsm_tmp = nullptr; h->trsm_tmp_bytes = 0;
+            GP_HIP(hipMalloc(&h->d_trsm_tmp, tbytes));
+            h->trsm_tmp_bytes = tbytes;
+        }
+    }
+    if (thin && npair >= 2) {
+        const size_t qbytes = (size_t)(npair / 2) * NQ * NQ * sizeof(double);
+        if (h->trsm_wquad_bytes < qbytes) {
+            GP_HIP(hipStreamSynchronize(stream));
+            if (h->d_trsm_wquad) GP_HIP(hipFree(h->d_trsm_wquad));
+            h->d_trsm_wquad = nullptr; h->trsm_wquad_bytes = 0;
+            GP_HIP(hipMalloc(&h->d_trsm_wquad, qbytes));
+            h->trsm_wquad_bytes = qbytes;
+        }
+    }
+    return 0;
+}
+
+// Inverses of L's diagonal blocks for the 512-block pairs [p0, p1) (p = index of a 512 x 512 diagonal block; the odd
+// 256-row block behind the last pair rides with the last range), into h->d_trsm_winv / d_trsm_wquad:
+//  1. the full 256 x 256 diagonal blocks: ONE batched launch of the fused leaf on identity right-hand sides
+//     (4 work-groups per block), written straight into the diagonal quarters of the 512 x 512 slots;
+//  2. the lower-left quarter of each slot,  -W2 (L21 W1),  as two batched 256^3 MFMA products;
+//  3. thin solves (few right-hand sides are launch-bound, not flop-bound): pairs of 512-blocks merged into 1024 x 1024
+//     inverses (two more batched products), which halves the leaves and drops a recursion level.
+// A range only reads the diagonal blocks it inverts, so the ranges of a factor can be built as its outer panels finish
+// (the sampler does, on its own stream, while the factorisation is still running).  p0 must be even when `thin`.
+int trsm_inverses_build(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t n, int64_t ldl, bool thin,
+                        int64_t p0, int64_t p1)
+{
+    const int64_t nfull = n / NL4, npair = nfull / 2;
+    if (p1 > npair) p1 = npair;
+    if (p0 >= p1 && !(p1 == npair && (nfull & 1))) return 0;
+    double* W = h->d_trsm_winv;
+    // 256-blocks 2 p0 .. 2 p1 - 1 (+ the odd one when this range closes the matrix)
+    const int64_t b0 = 2 * p0, b1 = (p1 == npair) ? nfull : 2 * p1;
+    if (b1 > b0)
+        hipLaunchKernelGGL((trsm_leaf256_kernel<false, true>), dim3(NL4 / CB, (unsigned)(b1 - b0)), dim3(256), 0, stream,
+                           L + b0 * (int64_t)NL4 * (ldl + 1), ldl, NL4, W + p0 * (int64_t)NI * NI, (int64_t)NI, (int64_t)NL4,
+                           (long long*)nullptr, (int64_t)NL4 * (ldl + 1), (int64_t)NI * NI, (int64_t)NL4 * (NI + 1));
+    const int np = (int)(p1 - p0);
+    if (np > 0) {
+        const double* Lp = L + p0 * (int64_t)NI * (ldl + 1);
+        double* Wp = W + p0 * (int64_t)NI * NI;
+        double* Tp = h->d_trsm_tmp + p0 * (int64_t)NL4 * NL4;
+        // T_b = L21 W1
+        GP_TRY(launch_gemm_batched(stream, false, false, TRI_NONE, NL4, NL4, NL4, 1.0,
+                                   Lp + NL4, ldl, (int64_t)NI * (ldl + 1), Wp, NI, (int64_t)NI * NI,
+                                   0.0, Tp, NL4, (int64_t)NL4 * NL4, np));
+        // W21 = -W2 T_b
+        GP_TRY(launch_gemm_batched(stream, false, false, TRI_A_LOWER, NL4, NL4, NL4, -1.0,
+                                   Wp + (int64_t)NL4 * (NI + 1), NI, (int64_t)NI * NI, Tp, NL4,
+                                   (int64_t)NL4 * NL4, 0.0, Wp + NL4, NI, (int64_t)NI * NI, np));
+    }
+    if (thin && npair >= 2) {
+        const int64_t q0 = p0 / 2, q1 = (p1 / 2 < npair / 2) ? p1 / 2 : npair / 2;
+        const int nq = (int)(q1 - q0);
+        if (nq > 0) {
+            double* Wq = h->d_trsm_wquad + q0 * (int64_t)NQ * NQ;
+            const double* Lq = L + q0 * (int64_t)NQ * (ldl + 1);
+            double* Tq = h->d_trsm_tmp + q0 * (int64_t)NI * NI;
+            hipLaunchKernelGGL(assemble_quad_kernel, dim3((unsigned)((int64_t)NQ * NQ / 256), (unsigned)nq), dim3(256), 0, stream,
+                               W + 2 * q0 * (int64_t)NI * NI, Wq);
+            // T = L_ba W_a (512^3, W_a lower triangular), then the lower-left quarter  -W_b T
+            GP_TRY(launch_gemm_batched(stream, false, false, TRI_NONE, NI, NI, NI, 1.0,
+                                       Lq + NI, ldl, (int64_t)NQ * (ldl + 1), Wq, NQ, (int64_t)NQ * NQ,
+                                       0.0, Tq, NI, (int64_t)NI * NI, nq));
+            GP_TRY(launch_gemm_batched(stream, false, false, TRI_A_LOWER, NI, NI, NI, -1.0,
+                                       Wq + (int64_t)NI * (NQ + 1), NQ, (int64_t)NQ * NQ, Tq, NI,
+                                       (int64_t)NI * NI, 0.0, Wq + NI, NQ, (int64_t)NQ * NQ, nq));
+        }
+    }
+    GP_HIP(hipGetLastError());
+    return 0;
+}
+
+void trsm_inverses_mark(gpirt_handle_t h, const double* L, int64_t n, int64_t ldl, bool thin)
+{
+    const int64_t npair = (n / NL4) / 2;
+    h->trsm_winv_L = L; h->trsm_winv_n = n; h->trsm_winv_ld = ldl;
+    h->trsm_quads = (thin && npair >= 2) ? npair / 2 : 0;
+}
+
 // reuse_inverses: the block inverses built by the previous call on this handle are still those of L (same L,
 // n and ldl, not modified since) -- the sampler's second solve of a draw_fstar skips rebuilding them.
 int launch_trsm_lower(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t n, int64_t ldl,
@@ -348,70 +452,11 @@ int launch_trsm_lower(gpirt_handle_t h, hipStream_t stream, const double* L, int
     if (use_inv && nfull >= 2 && nrhs >= 64 && have) {
         winv = h->d_trsm_winv;
     } else if (use_inv && nfull >= 2 && nrhs >= 64) {
-        // 1. the full 256 x 256 diagonal blocks: ONE batched launch of the fused leaf on identity right-hand
-        //    sides (4 work-groups per block, ~50 us for the whole matrix), written straight into the diagonal
-        //    quarters of the 512 x 512 slots;
-        // 2. the lower-left quarter of each slot,  -W2 (L21 W1),  as two batched 256^3 MFMA products.
-        const size_t wbytes = (size_t)(npair + 1) * NI * NI * sizeof(double);
-        size_t tbytes = (size_t)NI * (size_t)nrhs * sizeof(double);
-        if (tbytes < (size_t)npair * NL4 * NL4 * sizeof(double)) tbytes = (size_t)npair * NL4 * NL4 * sizeof(double);
-        if (thin && tbytes < (size_t)(npair / 2) * NI * NI * sizeof(double)) tbytes = (size_t)(npair / 2) * NI * NI * sizeof(double);
-        if (h->trsm_winv_bytes < wbytes || h->trsm_tmp_bytes < tbytes) {
-            GP_HIP(hipStreamSynchronize(stream));
-            if (h->trsm_winv_bytes < wbytes) {
-                if (h->d_trsm_winv) GP_HIP(hipFree(h->d_trsm_winv));
-                h->d_trsm_winv = nullptr; h->trsm_winv_bytes = 0;
-                GP_HIP(hipMalloc(&h->d_trsm_winv, wbytes));
-                GP_HIP(hipMemsetAsync(h->d_trsm_winv, 0, wbytes, stream));   // upper-right quarters stay zero for good
-                h->trsm_winv_bytes = wbytes;
-            }
-            if (h->trsm_tmp_bytes < tbytes) {
-                if (h->d_trsm_tmp) GP_HIP(hipFree(h->d_trsm_tmp));
-                h->d_trsm_tmp = nullptr; h->trsm_tmp_bytes = 0;
-                GP_HIP(hipMalloc(&h->d_trsm_tmp, tbytes));
-                h->trsm_tmp_bytes = tbytes;
-            }
-        }
-        double* W = h->d_trsm_winv;
-        hipLaunchKernelGGL((trsm_leaf256_kernel<false, true>), dim3(NL4 / CB, (unsigned)nfull), dim3(256), 0, stream,
-                           L, ldl, NL4, W, (int64_t)NI, (int64_t)NL4, (long long*)nullptr,
-                           (int64_t)NL4 * (ldl + 1), (int64_t)NI * NI, (int64_t)NL4 * (NI + 1));
-        if (npair > 0) {
-            // T_b = L21 W1
-            GP_TRY(launch_gemm_batched(stream, false, false, TRI_NONE, NL4, NL4, NL4, 1.0,
-                                       L + NL4, ldl, (int64_t)NI * (ldl + 1), W, NI, (int64_t)NI * NI,
-                                       0.0, h->d_trsm_tmp, NL4, (int64_t)NL4 * NL4, (int)npair));
-            // W21 = -W2 T_b
-            GP_TRY(launch_gemm_batched(stream, false, false, TRI_A_LOWER, NL4, NL4, NL4, -1.0,
-                                       W + (int64_t)NL4 * (NI + 1), NI, (int64_t)NI * NI, h->d_trsm_tmp, NL4,
-                                       (int64_t)NL4 * NL4, 0.0, W + NL4, NI, (int64_t)NI * NI, (int)npair));
-        }
-        winv = W;
+        GP_TRY(trsm_inverses_reserve(h, stream, n, nrhs, thin));
+        GP_TRY(trsm_inverses_build(h, stream, L, n, ldl, thin, 0, npair));
+        winv = h->d_trsm_winv;
         h->trsm_winv_L = L; h->trsm_winv_n = n; h->trsm_winv_ld = ldl;
-        h->trsm_quads = 0;
-        if (thin && npair >= 2) {
-            // 3. thin solves (few right-hand sides are launch-bound, not flop-bound): pairs of 512-blocks are
-            //    merged into 1024 x 1024 inverses, halving the number of leaves and dropping a recursion level
-            const int64_t nq = npair / 2;
-            const size_t qbytes = (size_t)nq * NQ * NQ * sizeof(double);
-            if (h->trsm_wquad_bytes < qbytes) {
-                GP_HIP(hipStreamSynchronize(stream));
-                if (h->d_trsm_wquad) GP_HIP(hipFree(h->d_trsm_wquad));
-                h->d_trsm_wquad = nullptr; h->trsm_wquad_bytes = 0;
-                GP_HIP(hipMalloc(&h->d_trsm_wquad, qbytes));
-                h->trsm_wquad_bytes = qbytes;
-            }
-            double* Wq = h->d_trsm_wquad;
-            hipLaunchKernelGGL(assemble_quad_kernel, dim3((unsigned)((int64_t)NQ * NQ / 256), (unsigned)nq), dim3(256), 0, stream, W, Wq);
-            // T = L_ba W_a (512^3, W_a lower triangular), then the lower-left quarter  -W_b T
-            GP_TRY(launch_gemm_batched(stream, false, false, TRI_NONE, NI, NI, NI, 1.0,
-                                       L + NI, ldl, (int64_t)NQ * (ldl + 1), Wq, NQ, (int64_t)NQ * NQ,
-                                       0.0, h->d_trsm_tmp, NI, (int64_t)NI * NI, (int)nq));
-            GP_TRY(launch_gemm_batched(stream, false, false, TRI_A_LOWER, NI, NI, NI, -1.0,
-                                       Wq + (int64_t)NI * (NQ + 1), NQ, (int64_t)NQ * NQ, h->d_trsm_tmp, NI,
-                                       (int64_t)NI * NI, 0.0, Wq + NI, NQ, (int64_t)NQ * NQ, (int)nq));
-            h->trsm_quads = nq;
-        }
+        h->trsm_quads = (thin && npair >= 2) ? npair / 2 : 0;
     }
     if (winv) {
         // the leaf products park a 512 x nrhs block in the workspace
