@@ -209,8 +209,10 @@ def main():
         tot_fl = sum(v[2] for v in prof.values())
         tot_n = sum(v[1] for v in prof.values())
         achieved = (tot_fl / (tot_ms * 1e-3) / 1e12) if tot_ms > 0 else 0.0
+        tot_by = sum(v[3] for v in prof.values())
         by_class = {k: {"launches": int(v[1]), "avg_launch_ms": (v[0] / v[1]) if v[1] else None,
                         "flops_per_launch": (v[2] / v[1]) if v[1] else None,
+                        "algorithmic_bytes_per_launch": (v[3] / v[1]) if v[1] else None,
                         "achieved": (v[2] / (v[0] * 1e-3) / 1e12) if v[0] > 0 else None,
                         "frac": (v[2] / (v[0] * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS) if v[0] > 0 else None,
                         "ms_per_step": v[0] / args.steps}
@@ -279,6 +281,8 @@ def main():
                 "launches": int(tot_n),
                 "avg_launch_ms": (tot_ms / tot_n) if tot_n else None,
                 "flops_per_launch": (tot_fl / tot_n) if tot_n else None,
+                "algorithmic_bytes_per_launch": (tot_by / tot_n) if tot_n else None,
+                "traffic_over_algorithmic": (traffic / (tot_by / tot_n)) if (traffic and tot_n and tot_by) else None,
                 "by_class": by_class,
                 "note": "HIP events around each launch on its own stream (main or look-ahead side stream) inside the timed region; "
                         "launches of the two streams overlap each other and the panel kernel, so per-launch times include that contention",

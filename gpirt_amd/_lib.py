@@ -32,7 +32,7 @@ class Options(C.Structure):
         ("theta_stabilise", C.c_int),
         ("fstar_fused", C.c_int),
         ("device", C.c_int),
-        ("use_graph", C.c_int),
+        ("reserved0", C.c_int),
         ("item0", C.c_int64),
         ("m_total", C.c_int64),
         ("reserved", C.c_int * 8),
@@ -117,6 +117,7 @@ SIGNATURES = {
     "gpirt_prof_trailing": (_i32, [_vp, _i32, _dp, C.POINTER(_i64), _dp]),
     "gpirt_prof_enable": (_i32, [_vp, _i32]),
     "gpirt_prof_syrk": (_i32, [_vp, _i32, _i32, _dp, C.POINTER(_i64), _dp]),
+    "gpirt_prof_syrk_bytes": (_i32, [_vp, _i32, _dp]),
     "gpirt_sampler_set_iteration": (_i32, [_vp, _i32]),
 }
 

@@ -469,6 +469,7 @@ static int prof_resolve(gpirt_handle_t h)
         h->prof.ms[pp.cls] += ms;
         h->prof.launches[pp.cls] += 1;
         h->prof.flops[pp.cls] += pp.flops;
+        h->prof.bytes[pp.cls] += pp.bytes;
         h->prof.free_pairs.push_back(pp);
     }
     h->prof.pending.clear();
@@ -482,7 +483,15 @@ int gpirt_prof_syrk(gpirt_handle_t h, int cls, int reset, double* total_ms, int6
     if (total_ms) *total_ms = h->prof.ms[cls];
     if (launches) *launches = h->prof.launches[cls];
     if (flops) *flops = h->prof.flops[cls];
-    if (reset) { h->prof.ms[cls] = 0.0; h->prof.launches[cls] = 0; h->prof.flops[cls] = 0.0; }
+    if (reset) { h->prof.ms[cls] = 0.0; h->prof.launches[cls] = 0; h->prof.flops[cls] = 0.0; h->prof.bytes[cls] = 0.0; }
+    return 0;
+}
+
+int gpirt_prof_syrk_bytes(gpirt_handle_t h, int cls, double* bytes)
+{
+    GP_ARG(h != nullptr && bytes != nullptr && cls >= 0 && cls < PROF_CLASSES);
+    GP_TRY(prof_resolve(h));
+    *bytes = h->prof.bytes[cls];
     return 0;
 }
 
@@ -552,7 +561,7 @@ void gpirt_default_options(gpirt_options* o)
     o->theta_stabilise = 0;
     o->fstar_fused = 0;
     o->device = -1;
-    o->use_graph = 0;
+    o->reserved0 = 0;
     o->item0 = 0;
     o->m_total = 0;
 }

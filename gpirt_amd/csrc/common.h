@@ -44,12 +44,13 @@ void set_error(const char* fmt, ...);
 // on the launch stream without synchronising and resolved later by gpirt_prof_syrk().  Classes:
 //   0  trailing update, 128-tile kernel   1  trailing update, 64-tile kernel   2  update inside an outer panel (K = 512)
 constexpr int PROF_CLASSES = 3;
-struct ProfPair { hipEvent_t e0, e1; double flops; int cls; };
+struct ProfPair { hipEvent_t e0, e1; double flops; int cls; double bytes; };
 struct Prof {
     bool        enabled = false;
     double      ms[PROF_CLASSES] = {};
     int64_t     launches[PROF_CLASSES] = {};
     double      flops[PROF_CLASSES] = {};
+    double      bytes[PROF_CLASSES] = {};     // algorithmic: C trapezoid read + written once, the panel operand read once
     std::vector<ProfPair> pending;
     std::vector<ProfPair> free_pairs;
 };

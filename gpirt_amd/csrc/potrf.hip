@@ -108,7 +108,7 @@ namespace {
 // event pair around one syrk launch of the factorisation (only while gpirt_prof_enable is on)
 int prof_begin(gpirt_handle_t h, hipStream_t stream, ProfPair& pp)
 {
-    pp = ProfPair{nullptr, nullptr, 0.0, 0};
+    pp = ProfPair{nullptr, nullptr, 0.0, 0, 0.0};
     if (!h->prof.enabled) return 0;
     if (!h->prof.free_pairs.empty()) { pp = h->prof.free_pairs.back(); h->prof.free_pairs.pop_back(); }
     else { GP_HIP(hipEventCreate(&pp.e0)); GP_HIP(hipEventCreate(&pp.e1)); }
@@ -120,7 +120,9 @@ int prof_end(gpirt_handle_t h, hipStream_t stream, ProfPair& pp, int cls, int64_
     if (!pp.e0) return 0;
     GP_HIP(hipEventRecord(pp.e1, stream));
     // algorithmic flops of the lower trapezoid: 2 K (M N - N (N - 1) / 2)
-    pp.flops = 2.0 * (double)K * ((double)M * (double)N - 0.5 * (double)N * (double)(N - 1));
+    const double trap = (double)M * (double)N - 0.5 * (double)N * (double)(N - 1);
+    pp.flops = 2.0 * (double)K * trap;
+    pp.bytes = 8.0 * (2.0 * trap + (double)M * (double)K);     // C read + written, P (M x K; its first N rows are the B operand) once
     pp.cls = cls;
     h->prof.pending.push_back(pp);
     return 0;

@@ -237,12 +237,14 @@ class Handle:
     SYRK_CLASSES = ("trailing_128tile", "trailing_64tile", "in_panel_k512")
 
     def prof_syrk(self, reset: bool = False) -> dict:
-        """Event-timed syrk launches of the factorisation per class: {name: (ms, launches, algorithmic flops)}."""
+        """Event-timed syrk launches of the factorisation per class:
+        {name: (ms, launches, algorithmic flops, algorithmic bytes)}."""
         out = {}
         for cls, name in enumerate(self.SYRK_CLASSES):
-            ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+            ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+            check(self.lib.gpirt_prof_syrk_bytes(self._h, cls, C.byref(by)))
             check(self.lib.gpirt_prof_syrk(self._h, cls, int(reset), C.byref(ms), C.byref(n), C.byref(fl)))
-            out[name] = (ms.value, n.value, fl.value)
+            out[name] = (ms.value, n.value, fl.value, by.value)
         return out
 
 

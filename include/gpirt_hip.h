@@ -177,7 +177,9 @@ typedef struct gpirt_options {
     int      theta_stabilise; /* 1 = subtract the row maximum before exp in draw_theta */
     int      fstar_fused;     /* see gpirt_draw_fstar */
     int      device;          /* < 0: current device */
-    int      use_graph;       /* 1 = replay one captured hipGraph per iteration (item RNG only) */
+    int      reserved0;       /* must be 0 (round 1 reserved this slot for a hipGraph replay switch that was never
+                               * built: the host enqueues one iteration in 0.40 ms against 8.3 ms on the device,
+                               * tools/host_time_probe.py, so a graph has nothing to win; the slot keeps the layout) */
     /* item sharding (one process per GPU): this rank owns item columns [item0, item0 + m) of a
      * global problem with m_total items; y / priors / outputs passed in are the LOCAL columns. */
     int64_t  item0;
@@ -277,6 +279,9 @@ int gpirt_prof_trailing(gpirt_handle_t h, int reset, double* total_ms, int64_t* 
  * 64-tile kernel, 2 = the K = 512 update between the two sub-panels of an outer panel.  flops are the
  * algorithmic ones of the lower trapezoid, 2 K (M N - N (N - 1) / 2). */
 int gpirt_prof_syrk(gpirt_handle_t h, int cls, int reset, double* total_ms, int64_t* launches, double* flops);
+/* algorithmic bytes of the same launches (call before the resetting gpirt_prof_syrk): the C trapezoid read and
+ * written once, the M x K panel operand read once -- what the launch must move if nothing is re-read */
+int gpirt_prof_syrk_bytes(gpirt_handle_t h, int cls, double* bytes);
 int gpirt_prof_enable(gpirt_handle_t h, int on);
 
 #ifdef __cplusplus
