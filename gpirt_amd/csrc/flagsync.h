@@ -1,5 +1,14 @@
-// flagsync.h -- progress counters between the work-groups of ONE persistent kernel (panel.hip): release /
-// acquire at agent scope through device memory.
+// flagsync.h -- progress counters between the work-groups of ONE persistent kernel (panel.hip) through device memory.
+//
+// Hand-off protocol (MI355X_MICROARCH.md, "Valid forms", the sc1 row for one work-group per CU and hipMalloc memory;
+// GPIRT_PANEL_FENCES=2 at build time keeps the fenced form this replaced):
+//   producer: EVERY handed-off byte is stored sc1 (write-through at agent scope: __hip_atomic_store relaxed/agent),
+//             every storing wave waits s_waitcnt vmcnt(0), the work-group's barrier, then ONE lane stores the counter sc1;
+//   consumer: one lane polls the counter with sc1 loads, the work-group's barrier, then EVERY load of the handed-off
+//             bytes is an sc1 load to registers (__hip_atomic_load relaxed/agent on a global pointer).
+// No agent-scope release (buffer_wbl2: it would write back every dirty line of the XCD's L2, the other work-groups'
+// private results included) and no acquire (buffer_inv: it empties the XCD's L2 for all 16 work-groups sharing it,
+// twice per step each) -- measured in round 2: 216 -> ... us per 512-column sub-panel.
 //
 // Rules that keep such kernels safe on this hardware:
 //   * a work-group only ever waits for work-groups with a SMALLER block index (dispatched earlier), and the
@@ -49,19 +58,27 @@ __device__ __forceinline__ bool wait_prog(const unsigned long long* p, unsigned 
     }
     __syncthreads();
     const unsigned long long v = *s_seen;
+#ifdef GPIRT_PANEL_FENCES
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop stale L1/L2 lines before reading the data
+#endif
     __syncthreads();                                  // s_seen may be rewritten by the next wait
     if (v < need) return false;
     have = v;
     return true;
 }
 
-// make this work-group's global stores visible, then raise the row block's counter
+// every wave's (sc1) stores have been accepted, then one lane raises the row block's counter
 __device__ __forceinline__ void publish(unsigned long long* p, unsigned long long value)
 {
+#ifdef GPIRT_PANEL_FENCES
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(p, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(p, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 }
 
 }  // namespace gpirt

@@ -56,6 +56,21 @@ __device__ __forceinline__ double ldg_off(const double* sbase, uint32_t voff)
 {
     return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(sbase) + voff);
 }
+// ... and what ANOTHER work-group stored (its X blocks, L_jj) is read with sc1 loads: straight from memory, never from a
+// line this XCD's L2 may have kept from before the store (flagsync.h)
+__device__ __forceinline__ double ldg_sc1(const double* sbase, uint32_t voff)
+{
+#ifdef GPIRT_PANEL_FENCES
+    return ldg_off(sbase, voff);
+#else
+    return __hip_atomic_load(reinterpret_cast<const double*>(reinterpret_cast<const char*>(sbase) + voff), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ void stg_plain(double* sbase, uint32_t voff, double x)
+{
+    *reinterpret_cast<double*>(reinterpret_cast<char*>(sbase) + voff) = x;
+}
 // Results other work-groups will read are stored write-through at agent scope (sc1): nothing of ours stays
 // dirty in the XCD's L2, so the release fence before a counter update has (almost) nothing to write back.
 __device__ __forceinline__ void stg_off(double* sbase, uint32_t voff, double x)
@@ -75,11 +90,11 @@ __device__ __forceinline__ void load_block_regs(double (&v)[16], const double* A
     const uint32_t voff = (uint32_t)(((live ? r : last) + (int64_t)(t >> 6) * lda) * 8);
     if (row0 + PB <= n) {        // full block (uniform): plain loads, nothing between them and their first use
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = ldg_off(A + row0 + (col0 + 4 * q) * lda, voff);
+        for (int q = 0; q < 16; ++q) v[q] = ldg_sc1(A + row0 + (col0 + 4 * q) * lda, voff);
     } else {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const double x = ldg_off(A + row0 + (col0 + 4 * q) * lda, voff);
+            const double x = ldg_sc1(A + row0 + (col0 + 4 * q) * lda, voff);
             v[q] = live ? x : 0.0;
         }
     }
@@ -133,8 +148,10 @@ __device__ __forceinline__ void load_strip(d4 (&X)[4], const double* A, int64_t 
             }
     }
 }
+// shared: other work-groups will read the strip (a diagonal owner's X) -> sc1 write-through; a row block nobody else
+// reads inside this kernel stores plainly, so its own re-reads (XI) hit the L2
 __device__ __forceinline__ void store_strip(const d4 (&X)[4], double* A, int64_t lda, int64_t n,
-                                            int64_t row0, int64_t col0, int ncols, bool lower_only)
+                                            int64_t row0, int64_t col0, int ncols, bool lower_only, bool shared = true)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, g = lane >> 4;
@@ -146,7 +163,14 @@ __device__ __forceinline__ void store_strip(const d4 (&X)[4], double* A, int64_t
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int c = 16 * J + 4 * g + r;
-            if (c < ncols && (!lower_only || rr >= c)) stg_off(A + row0 + (col0 + 16 * J + r) * lda, voff, X[J][r]);
+            if (c < ncols && (!lower_only || rr >= c)) {
+#ifdef GPIRT_PANEL_FENCES
+                stg_off(A + row0 + (col0 + 16 * J + r) * lda, voff, X[J][r]);
+#else
+                if (shared) stg_off(A + row0 + (col0 + 16 * J + r) * lda, voff, X[J][r]);
+                else stg_plain(A + row0 + (col0 + 16 * J + r) * lda, voff, X[J][r]);
+#endif
+            }
         }
 }
 
@@ -225,12 +249,12 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
                 const uint32_t voff = (uint32_t)(((r <= last ? r : last) + (int64_t)cq * lda) * 8);
                 if (jcols == PB) {                    // 16 plain loads in flight, masks applied afterwards
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) v[q] = ldg_off(A + orow0 + (col0 + 4 * q) * lda, voff);
+                    for (int q = 0; q < 16; ++q) v[q] = ldg_sc1(A + orow0 + (col0 + 4 * q) * lda, voff);
                 } else {                              // ragged last block of the matrix
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
                         const int c = cq + 4 * q;
-                        v[q] = A[orow0 + (r <= last ? r : last) + (col0 + (c < jcols ? c : 0)) * lda];
+                        v[q] = ldg_sc1(A + orow0 + (r <= last ? r : last) + (col0 + (c < jcols ? c : 0)) * lda, 0u);
                     }
                 }
 #pragma unroll
@@ -247,7 +271,7 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
             PANEL_STAMP(4);
             solve64_lower_inv(T, sM);
             PANEL_STAMP(5);
-            store_strip(T, A, lda, n, row0, col0, jcols, false);
+            store_strip(T, A, lda, n, row0, col0, jcols, false, is_diag);
             if (is_diag) {
                 // D -= X X^T with X straight from the registers: the four strips meet in LDS
                 __syncthreads();                      // all waves finished reading L_jj from sM

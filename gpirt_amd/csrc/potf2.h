@@ -264,7 +264,10 @@ __device__ __forceinline__ void potf2_64_lds(double* __restrict__ sD, double* __
         // for the next block column -- writes the L2 back (release fence, ~2.5 us) and raises the counter,
         // while wave 0 is already deep in the next pivots.
         if (b == 0 && late_flag && wave == 3) {
+#ifdef GPIRT_PANEL_FENCES
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
+            // (fence-free form, flagsync.h: every wave waited vmcnt(0) on its sc1 stores before the barrier above)
             if (lane == 0) __hip_atomic_store(late_flag, late_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (wave >= 1) {

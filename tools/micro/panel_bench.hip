@@ -20,7 +20,8 @@ int main(int argc, char** argv)
         for (int64_t r = 0; r < n; ++r) S[r + c * n] = exp(-0.5 * (th[r] - th[c]) * (th[r] - th[c])) + (r == c ? 1e-3 : 0.0);
     double* dA; CK(hipMalloc(&dA, (size_t)n * n * 8));
     gpirt_handle_s h;
-    CK(hipMalloc(&h.d_info, 64)); CK(hipMemset(h.d_info, 0, 64));
+    { hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0)); h.n_cu = prop.multiProcessorCount; }
+    CK(hipMalloc(&h.d_info, 64)); CK(hipMemset(h.d_info, 0, 64)); CK(hipDeviceSynchronize());
     const int nrb = (int)((n + 63) / 64);
     CK(hipMalloc(&h.panel_trace, (size_t)nrb * 40 * 8 * 8));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
