@@ -131,6 +131,14 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise GpirtError(E_NODEVICE, f"{LIB_PATH} is missing: build it with "
                                          "`python -m gpirt_amd.build` (hipcc, gfx950). There is no CPU fallback.")
+        # Load order matters in a Python process that also uses PyTorch-ROCm: torch bundles its own HIP runtime, and a
+        # process that initialises the system runtime first (through this library) and torch's second ends with one of
+        # them reporting "no ROCm-capable device".  Importing torch first makes the order the same everywhere
+        # (the R host of INTEGRATION.md has no torch and no such issue).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the library does not export it
