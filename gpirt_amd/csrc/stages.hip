@@ -249,6 +249,7 @@ __global__ __launch_bounds__(256) void draw_beta_kernel(BetaArgs a)
     double pv[2] = { cv[0], cv[1] };
     uint64_t q = 0;
     if (a.U) q = *a.pos + a.item_off[j];
+    double kept_ll = 0.0;                 // ll(y | current beta) after the last accept / reject
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const double step = a.step[k + 2 * j];
@@ -261,23 +262,28 @@ __global__ __launch_bounds__(256) void draw_beta_kernel(BetaArgs a)
         const double pm = a.pm[k + 2 * j], ps = a.ps[k + 2 * j];
         const double pv_prior = r_dnorm_log(pv[k], pm, ps);                 // :25
         const double cv_prior = r_dnorm_log(cv[k], pm, ps);                 // :26
+        // ll(current) of the second coefficient is a sum already formed in the first step: the proposal's if it was
+        // accepted (same mu expression, same reduction tree), the current one's otherwise -- 3 passes over y, f instead of 4
         double accp = 0.0, accc = 0.0;
+        const bool reuse = (k == 1);
         for (int64_t i = threadIdx.x; i < n; i += 256) {
             const double yy = yj[i];
             if (yy != yy) continue;
             const double th = a.theta[i], f = fj[i];
             const double mup = pv[0] + th * pv[1];
-            const double muc = cv[0] + th * cv[1];
             accp += ll_term(yy * (f + mup));                                // :27
-            accc += ll_term(yy * (f + muc));                                // :28
+            if (!reuse) {
+                const double muc = cv[0] + th * cv[1];
+                accc += ll_term(yy * (f + muc));                            // :28
+            }
         }
         const double pv_ll = -block_sum_256(accp, red);
-        const double cv_ll = -block_sum_256(accc, red);
+        const double cv_ll = reuse ? kept_ll : -block_sum_256(accc, red);
         const double r = pv_prior + pv_ll - cv_prior - cv_ll;               // :29
         double u;
         if (a.U) { u = a.U[q]; q += 1; }
         else u = item_uniform(a.seed, a.iter, GPIRT_ST_BETA, item, (uint32_t)(2 * k + 1));
-        if (log(u) < r) cv[k] = pv[k]; else pv[k] = cv[k];                  // :30-35
+        if (log(u) < r) { cv[k] = pv[k]; kept_ll = pv_ll; } else { pv[k] = cv[k]; kept_ll = cv_ll; }   // :30-35
     }
     if (threadIdx.x == 0) { a.beta[0 + 2 * j] = cv[0]; a.beta[1 + 2 * j] = cv[1]; }
     if (a.mu)
