@@ -76,3 +76,62 @@ def test_two_ranks_one_gpu_match_single_process(handle, tmp_path, chol):
     assert np.abs(got["beta"] - ref.get("beta")).max() < 1e-10
     assert np.abs(got["fstar"] - ref.get("fstar")).max() < 1e-10
     ref.close()
+
+
+def _run_rccl(rank, world, port, chol, outdir):
+    """One rank per GPU over RCCL (backend "nccl"): what bench.py --gpus N runs."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    from gpirt_amd.distributed import ShardedSampler
+    from gpirt_amd.ops import Handle
+    from gpirt_amd.sampler import Sampler
+    from gpirt_amd.synthetic import make_responses
+    y, th0 = make_responses(2560, 24, seed=6)
+    h = Handle(rank)
+
+    def factory(yl, th, pm, ps, st, item0, m_total):
+        return Sampler(h, yl, th, pm, ps, st, rng="item", seed=77, item0=item0, m_total=m_total, fstar_fused=True,
+                       kstar_rank=64)
+
+    ss = ShardedSampler(factory, y, th0, dist=dist, chol=chol)
+    ss.init()
+    for _ in range(2):
+        ss.step()
+    ss.engine.check()
+    f, beta, fstar = ss.gather("f"), ss.gather("beta"), ss.gather("fstar")
+    if rank == 0:
+        np.savez(os.path.join(outdir, f"rccl_{chol}.npz"), f=f, beta=beta, fstar=fstar, theta=ss.engine.get("theta"),
+                 L=ss.engine.get("L"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("chol", ["replicated", "distributed"])
+def test_two_gpus_over_rccl_match_one_gpu(handle, tmp_path, chol):
+    """Needs two MI355X in the box (skipped on the one-GPU test box): item shards on two devices, the f* all-gather,
+    the theta combine and -- for chol = distributed -- the panel broadcasts all travel over RCCL; theta and L must be
+    bit-identical to the single-GPU run."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("RCCL parity needs two GPUs")
+    import torch.multiprocessing as mp
+    from gpirt_amd.sampler import Sampler
+    from gpirt_amd.synthetic import make_responses
+    port = 29900 + (os.getpid() % 1000) + (0 if chol == "replicated" else 1)
+    mp.spawn(_run_rccl, args=(2, port, chol, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / f"rccl_{chol}.npz")
+    y, th0 = make_responses(2560, 24, seed=6)
+    ref = Sampler(handle, y, th0, rng="item", seed=77, fstar_fused=True, kstar_rank=64)
+    ref.init()
+    for _ in range(2):
+        ref.step()
+    ref.check()
+    assert np.array_equal(got["theta"], ref.get("theta"))
+    assert np.abs(got["L"] - ref.get("L")).max() == 0
+    assert np.abs(got["f"] - ref.get("f")).max() < 1e-10
+    assert np.abs(got["fstar"] - ref.get("fstar")).max() < 1e-10
+    ref.close()
