@@ -49,7 +49,12 @@ struct gpirt_sampler_s {
     // L is stored (n + ext) x n with leading dimension ldl.  ext = kr when the low-rank K* is on and n % 64 == 0: the
     // extra rows enter the factorisation holding K(c, theta) (r x n) and leave it holding (L^-1 K(theta, c))^T -- the
     // forward solve of draw_fstar comes out of the bordered factorisation (potrf.hip) for ~1 % more work.
+    // Without the low-rank K* (ext_grid): the rows are K(theta*, theta) for the 1001 grid points (padded to 1024 zero
+    // rows) and come out as (L^-1 k*)^T -- the 1001-column forward solve of src/draw-fstar.cpp:19 rides through the
+    // factorisation the same way.  rows_valid: the rows belong to the current (theta, L); cleared when either is set
+    // from outside, rebuilt by an explicit solve on demand (rebuild_rows).
     int64_t ext = 0, ldl = 0;
+    bool ext_grid = false, rows_valid = false;
     // Work that needs only L (not this iteration's f) runs on a stream of the sampler's own, beside draw_f's elliptical
     // slice kernel: the part of the low-rank draw_fstar that depends on the factor alone (C = L^-T B, G = B^T B).
     // haux is a private handle on that stream (its own trsm / split-K workspaces: several
@@ -151,6 +156,7 @@ __global__ void trmv_lower_kernel(const double* __restrict__ L, int64_t n, int64
 }
 
 int fstar_prep(gpirt_sampler_s* s, gpirt_handle_t hh);
+int rebuild_rows(gpirt_sampler_s* s);
 
 int do_draw_f(gpirt_sampler_s* s)
 {
@@ -161,7 +167,7 @@ int do_draw_f(gpirt_sampler_s* s)
     if (!stream_mode(s)) {
         GP_TRY(launch_item_uniforms(st, s->opt.seed, iter, GPIRT_ST_F_Z, (uint32_t)s->opt.item0, m, n, s->Z, true));
         GP_TRY(launch_gemm(h, st, false, false, TRI_A_LOWER, n, m, n, 1.0, s->L, s->ldl, s->Z, n, 0.0, s->NU, n));
-        const bool prep = s->haux && s->ext > 0 && !s->prep_valid;
+        const bool prep = s->haux && s->ext > 0 && !s->ext_grid && s->rows_valid && !s->prep_valid;
         if (prep) GP_HIP(hipEventRecord(s->ev_trmm, st));
         EssArgs a{};
         a.f = s->f; a.nu = s->NU; a.y = s->y; a.mu = s->mu; a.n = n; a.m = m; a.k_out = s->ess_k;
@@ -219,6 +225,7 @@ int do_draw_fstar(gpirt_sampler_s* s, uint32_t iter)
     double* tmp = s->rhs;                    // n x N : L^-1 kstar
     double* W = s->rhs + (size_t)n * N;      // n x m : L^-1 f, then L^-T L^-1 f
     const bool fused = s->opt.fstar_fused != 0;
+    GP_TRY(rebuild_rows(s));
     if (s->kr > 0) {
         // K*^T = U V^T exactly (see gpirt_sampler_create), so with B = L^-1 U and C = L^-T B = S^-1 U:
         //   ||L^-1 k*_j||^2 = v_j^T (B^T B) v_j          (src/draw-fstar.cpp:19-20)
@@ -232,7 +239,7 @@ int do_draw_fstar(gpirt_sampler_s* s, uint32_t iter)
         if (bordered) {
             // C = L^-T B and G = B^T B depend on the factor alone: usually already under way on the sampler's own
             // stream since draw_f's product finished (do_draw_f); otherwise computed here
-            if (!s->prep_valid) { GP_TRY(fstar_prep(s, h)); s->prep_valid = true; }
+            if (!s->prep_valid) { GP_TRY(fstar_prep(s, h)); s->prep_valid = true; }   // (rows rebuilt above if they were stale)
             else if (s->prep_pending) { GP_HIP(hipStreamWaitEvent(st, s->ev_prep, 0)); s->prep_pending = false; }
         } else {
             GP_TRY(launch_se_kernel(st, s->theta, n, s->knodes, r, Bu, n, 0.0));
@@ -253,14 +260,22 @@ int do_draw_fstar(gpirt_sampler_s* s, uint32_t iter)
         if (stream_mode(s)) { a.U = s->U; a.pos = s->pos; a.cap = s->U_cap; a.off_scratch = s->fstar_off; }
         return launch_fstar_epilogue(st, a);
     }
-    if (fused) {
-        GP_TRY(launch_se_kernel(st, s->theta, n, s->tstar, N, tmp, n, 0.0));                   // :17
-    } else {
-        GP_TRY(launch_se_kernel(st, s->theta, n, s->tstar, N, s->kstar, n, 0.0));
-        GP_HIP(hipMemcpyAsync(tmp, s->kstar, sizeof(double) * (size_t)n * N, hipMemcpyDeviceToDevice, st));
-    }
     GP_HIP(hipMemcpyAsync(W, s->f, sizeof(double) * (size_t)n * m, hipMemcpyDeviceToDevice, st));
-    GP_TRY(launch_trsm_lower(h, st, s->L, n, s->ldl, s->rhs, N + m, n, false));                    // :19, :7 inner
+    if (s->ext_grid) {
+        // tmp = L^-1 k* came out of the bordered factorisation as the rows below L (N x n): one transpose puts it
+        // where the solve used to leave it; only the m item columns are still solved for                      :19
+        if (!fused) GP_TRY(launch_se_kernel(st, s->theta, n, s->tstar, N, s->kstar, n, 0.0));  // :17 (for :25)
+        GP_TRY(launch_transpose(st, s->L + n, N, n, s->ldl, tmp, n));
+        GP_TRY(launch_trsm_lower(h, st, s->L, n, s->ldl, W, m, n, false));                    // :7 inner
+    } else {
+        if (fused) {
+            GP_TRY(launch_se_kernel(st, s->theta, n, s->tstar, N, tmp, n, 0.0));               // :17
+        } else {
+            GP_TRY(launch_se_kernel(st, s->theta, n, s->tstar, N, s->kstar, n, 0.0));
+            GP_HIP(hipMemcpyAsync(tmp, s->kstar, sizeof(double) * (size_t)n * N, hipMemcpyDeviceToDevice, st));
+        }
+        GP_TRY(launch_trsm_lower(h, st, s->L, n, s->ldl, s->rhs, N + m, n, false));                // :19, :7 inner
+    }
     GP_TRY(launch_colnorm_s(st, tmp, n, N, n, s->s));                                         // :20
     if (fused) {
         GP_TRY(launch_gemm(h, st, true, false, TRI_NONE, N, m, n, 1.0, tmp, n, W, n, 0.0, s->mean, N));
@@ -354,7 +369,22 @@ int build_cov(gpirt_sampler_s* s)
 {
     hipStream_t st = s->h->stream;
     GP_TRY(launch_se_kernel_lower(st, s->theta, s->n, s->L, s->ldl, GPIRT_JITTER, s->opt.reserved[1] != 0));
-    if (s->ext > 0) GP_TRY(launch_se_kernel(st, s->knodes, s->ext, s->theta, s->n, s->L + s->n, s->ldl, 0.0));
+    if (s->ext > 0 && !s->ext_grid) GP_TRY(launch_se_kernel(st, s->knodes, s->ext, s->theta, s->n, s->L + s->n, s->ldl, 0.0));
+    if (s->ext_grid) GP_TRY(launch_se_kernel(st, s->tstar, s->N, s->theta, s->n, s->L + s->n, s->ldl, 0.0));
+    return 0;
+}
+
+// the rows below L for the CURRENT (theta, L) by the explicit forward solve (after L or theta was set from outside)
+int rebuild_rows(gpirt_sampler_s* s)
+{
+    if (s->ext == 0 || s->rows_valid) return 0;
+    hipStream_t st = s->h->stream;
+    const int64_t n = s->n, cols = s->ext_grid ? s->N : s->kr;
+    double* Bu = s->rhs;
+    GP_TRY(launch_se_kernel(st, s->theta, n, s->ext_grid ? s->tstar : s->knodes, cols, Bu, n, 0.0));
+    GP_TRY(launch_trsm_lower(s->h, st, s->L, n, s->ldl, Bu, cols, n, false));
+    GP_TRY(launch_transpose(st, Bu, n, cols, n, s->L + n, s->ldl));
+    s->rows_valid = true;
     return 0;
 }
 
@@ -364,6 +394,7 @@ int do_factor(gpirt_sampler_s* s)
     GP_TRY(aux_join(s));                  // nothing of the old factor may still be read when it is overwritten
     invalidate_factor_products(s);
     GP_TRY(build_cov(s));                                                                                  // :76-77
+    s->rows_valid = true;
     return launch_potrf_lower(s->h, st, s->L, s->n, s->ldl, false, !s->sticky_info, s->ext);              // :78
 }
 
@@ -416,7 +447,12 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
         gpirt_sampler_destroy(s);
         return GPIRT_E_ARG;
     }
-    s->ext = (s->kr > 0 && s->opt.fstar_fused && (n % 64) == 0 && !(getenv("GPIRT_BORDERED") && atoi(getenv("GPIRT_BORDERED")) == 2)) ? s->kr : 0;
+    const bool bordered_ok = (n % 64) == 0 && !(getenv("GPIRT_BORDERED") && atoi(getenv("GPIRT_BORDERED")) == 2);
+    s->ext = (s->kr > 0 && bordered_ok) ? s->kr : 0;
+    if (s->kr == 0 && bordered_ok && n >= 1024 && !(getenv("GPIRT_BORDERED_GRID") && atoi(getenv("GPIRT_BORDERED_GRID")) == 2)) {
+        s->ext = (N + 63) / 64 * 64;          // 1001 grid rows + 23 rows that stay zero
+        s->ext_grid = true;
+    }
     s->ldl = n + s->ext;
     GP_A(s->mu, n * m);      GP_A(s->mu_star, N * m + 1); GP_A(s->fstar, N * m + 1); GP_A(s->L, s->ldl * n);
     GP_A(s->tstar, N + 1);   GP_A(s->rhs, n * (N + m) + 2); GP_A(s->mean, N * m + 1); GP_A(s->s, N + 1);
@@ -702,7 +738,8 @@ int gpirt_sampler_build_cov(gpirt_sampler_t s)
 int gpirt_sampler_skip_factor(gpirt_sampler_t s)
 {
     GP_ARG(s && s->initialised);
-    invalidate_factor_products(s);       // L arrived from elsewhere (broadcast / distributed pieces)
+    invalidate_factor_products(s);       // L arrived from elsewhere (broadcast / distributed pieces), its rows with it
+    s->rows_valid = true;
     s->iter += 1;
     return 0;
 }
@@ -849,13 +886,8 @@ int gpirt_sampler_copy_state(gpirt_sampler_t dst, gpirt_sampler_t src)
     GP_HIP(hipMemcpyAsync(dst->fstar, src->fstar, sizeof(double) * (size_t)(N * m), hipMemcpyDeviceToDevice, st));
     GP_HIP(hipMemcpy2DAsync(dst->L, (size_t)dst->ldl * 8, src->L, (size_t)src->ldl * 8, (size_t)n * 8, (size_t)n,
                             hipMemcpyDeviceToDevice, st));
-    if (dst->ext > 0) {
-        // the rows below L are (L^-1 K(theta, c))^T: rebuild them for the copied (theta, L) by the forward solve
-        double* Bu = dst->rhs;
-        GP_TRY(launch_se_kernel(st, dst->theta, n, dst->knodes, dst->kr, Bu, n, 0.0));
-        GP_TRY(launch_trsm_lower(dst->h, st, dst->L, n, dst->ldl, Bu, dst->kr, n, false));
-        GP_TRY(launch_transpose(st, Bu, n, dst->kr, n, dst->L + n, dst->ldl));
-    }
+    dst->rows_valid = false;
+    GP_TRY(rebuild_rows(dst));            // the rows below L for the copied (theta, L)
     dst->iter = src->iter;
     return 0;
 }
@@ -887,6 +919,7 @@ int gpirt_sampler_set(gpirt_sampler_t s, const char* name, const double* h_in, i
     GP_ARG(count <= c && strcmp(name, "ess_k") != 0);
     GP_TRY(aux_join(s));
     invalidate_factor_products(s);
+    if (strcmp(name, "L") == 0 || strcmp(name, "theta") == 0) s->rows_valid = false;
     if (strcmp(name, "L") == 0 && s->ldl != s->n) {
         GP_ARG(count == s->n * s->n);
         GP_HIP(hipMemcpy2DAsync(p, (size_t)s->ldl * 8, h_in, (size_t)s->n * 8, (size_t)s->n * 8, (size_t)s->n,

@@ -255,9 +255,10 @@ int gpirt_sampler_check(gpirt_sampler_t s);              /* syncs; returns potrf
 /* Device pointer of a named state array ("theta","f","beta","mu","mu_star","fstar","L","logpost",
  * "irf_sum","ess_k") and its element count; the pointer stays valid until destroy. */
 int gpirt_sampler_devptr(gpirt_sampler_t s, const char* name, void** d_ptr, int64_t* count);
-/* Leading dimension of the "L" device array.  With the rank-r K* (gpirt_options.reserved[2]) and n % 64 == 0 the array
- * is (n + r) x n: the r rows below the factor enter the factorisation as K(c, theta) and leave it as
- * (L^-1 K(theta, c))^T -- draw_fstar's forward solve (src/draw-fstar.cpp:19) comes out of a bordered factorisation.
+/* Leading dimension of the "L" device array.  With n % 64 == 0 the array is (n + e) x n: e rows below the factor enter
+ * the factorisation as K(c, theta) (rank-r K*, e = r) or K(theta*, theta) (e = 1024: the 1001 grid points, n >= 1024)
+ * and leave it as (L^-1 K(theta, .))^T -- draw_fstar's forward solve (src/draw-fstar.cpp:19) comes out of a bordered
+ * factorisation.
  * gpirt_sampler_get / _set("L") always move the n x n factor. */
 int gpirt_sampler_ldl(gpirt_sampler_t s, int64_t* ldl);
 /* dst's chain state := src's (theta, f, beta, mu, mu_star, fstar, L, iteration counter); same handle, same n and m. */
