@@ -304,3 +304,58 @@ def test_lowrank_kstar_equals_full_solve(handle, n, m, rank):
         s.close()
     assert np.isfinite(out[0]).all() and np.isfinite(out[1]).all()
     assert np.abs(out[0] - out[1]).max() <= 1e-9
+
+
+@pytest.mark.parametrize("form", ["lowrank", "fused", "double_solve"])
+def test_bordered_factorisation_equals_explicit_solve(handle, form, monkeypatch):
+    """L^-1 K(theta, c) (rank-64 form) and L^-1 k* (the 1001 grid columns; fused and as-written forms) come out of the
+    factorisation as extra rows below S (potrf.hip, extra_rows).  With GPIRT_BORDERED=2 the same sampler solves for them
+    explicitly (src/draw-fstar.cpp:19 as a trsm): same theta, f, L and RNG keys, so f*, theta and f must agree to
+    rounding over whole iterations."""
+    from gpirt_amd.sampler import Sampler
+    from gpirt_amd.synthetic import make_responses
+    n, m = 2048, 48
+    y, th0 = make_responses(n, m, seed=21)
+    kw = dict(lowrank=dict(fstar_fused=True, kstar_rank=64), fused=dict(fstar_fused=True), double_solve=dict())[form]
+    out = []
+    for bordered in ("1", "2"):
+        monkeypatch.setenv("GPIRT_BORDERED", bordered)
+        s = Sampler(handle, y, th0, rng="item", seed=9, theta_stabilise=True, **kw)
+        s.init()
+        for _ in range(3):
+            s.step()
+        s.check()
+        out.append({k: np.array(s.get(k)) for k in ("fstar", "theta", "f", "L")})
+        s.close()
+    a, b = out
+    assert np.array_equal(a["theta"], b["theta"]) and np.array_equal(a["L"], b["L"]) and np.array_equal(a["f"], b["f"])
+    assert np.abs(a["fstar"] - b["fstar"]).max() <= 1e-9 * max(1.0, np.abs(b["fstar"]).max())
+
+
+@pytest.mark.parametrize("form", ["lowrank", "fused"])
+def test_copy_state_and_set_theta_rebuild_the_border_rows(handle, form):
+    """gpirt_sampler_copy_state / gpirt_sampler_set("theta") leave the rows below L stale; the next draw_fstar must
+    rebuild them by the explicit solve: a sampler that received another one's state draws the same f* (same RNG keys)."""
+    from gpirt_amd.sampler import Sampler
+    from gpirt_amd.synthetic import make_responses
+    n, m = 1024, 24
+    y, th0 = make_responses(n, m, seed=22)
+    kw = dict(lowrank=dict(fstar_fused=True, kstar_rank=64), fused=dict(fstar_fused=True))[form]
+    a = Sampler(handle, y, th0, rng="item", seed=4, theta_stabilise=True, **kw)
+    b = Sampler(handle, y, th0[::-1].copy(), rng="item", seed=4, theta_stabilise=True, **kw)     # another chain
+    a.init(); b.init()
+    for _ in range(2):
+        a.step()
+    b.step()
+    b.copy_state_from(a)
+    assert b.iteration == a.iteration
+    a.draw_fstar(); b.draw_fstar()
+    a.check(); b.check()
+    fa, fb = a.get("fstar"), b.get("fstar")
+    assert np.abs(fa - fb).max() <= 1e-9 * max(1.0, np.abs(fa).max())
+    # set("theta") alone: the rows follow theta at the next draw (compared with a sampler built on that theta and L)
+    th = a.get("theta")
+    b.set("theta", th)
+    b.draw_fstar(); b.check()
+    assert np.abs(b.get("fstar") - fa).max() <= 1e-9 * max(1.0, np.abs(fa).max())
+    a.close(); b.close()
