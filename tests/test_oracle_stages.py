@@ -163,3 +163,25 @@ def test_senate116_fixture_shape():
     y = d["y"]
     assert y.shape == (100, 418) and set(np.unique(y)) == {-1, 0, 1}
     assert abs((y == 0).mean() - 0.0574) < 1e-3
+
+
+def test_cpu_baseline_leg_runs_on_a_small_problem(oracle):
+    """bench.py's cpu_baseline leg (oracle/cpu_baseline.py): both legs produce finite, positive rates and say how far
+    each sample was stretched."""
+    from oracle import cpu_baseline as CB
+    from gpirt_amd.synthetic import make_responses
+    n, m = 256, 24
+    y, th = make_responses(n, m, seed=3)
+    L, info = oracle.factor(th)
+    assert info == 0
+    rng = np.random.default_rng(0)
+    f = np.asfortranarray(L @ rng.standard_normal((n, m)))
+    beta = np.asfortranarray(rng.standard_normal((2, m)))
+    mu = np.asfortranarray(beta[0][None, :] + th[:, None] * beta[1][None, :])
+    fstar = np.asfortranarray(rng.standard_normal((1001, m)))
+    r = CB.run(n, m, y, th, L, f, beta, mu, fstar, nthreads=2)
+    assert r["kind"] == "port" and r["cores"] == 1 and r["extrapolated"] is True and r["value"] > 0 and np.isfinite(r["value"])
+    a = r["all_cores"]
+    assert a["cores"] == 2 and a["value"] > 0 and np.isfinite(a["value"])
+    assert set(r["stage_seconds"]) == {"K", "chol", "draw_f", "draw_fstar", "draw_theta", "draw_beta"}
+    assert r["extrapolation_factors"]["all.chol"] == 1.0      # the all-core potrf runs at the full size
