@@ -139,10 +139,10 @@ int gpirt_create(gpirt_handle_t* out, int device, void* stream)
     // so a kernel launched there could start on recycled, uncleared words or have its counters zeroed under it.
     const size_t prog_cap = 2048;        // 64-row blocks: n <= 131008 without growing
     hipError_t e = hipMalloc(&h->d_info, 64);
-    if (e == hipSuccess) e = hipMalloc(&h->d_prog, prog_cap * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&h->d_prog, 2 * prog_cap * sizeof(unsigned long long));   // row-block counters | column counters (panel.hip)
     if (e == hipSuccess) e = hipHostMalloc(&h->h_info, 64, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMemsetAsync(h->d_info, 0, 64, h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(h->d_prog, 0, prog_cap * sizeof(unsigned long long), h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->d_prog, 0, 2 * prog_cap * sizeof(unsigned long long), h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) {
         set_error("handle workspace setup failed: %s", hipGetErrorString(e));
@@ -162,6 +162,7 @@ int gpirt_destroy(gpirt_handle_t h)
     if (h->h_info) hipHostFree(h->h_info);
     if (h->d_work) hipFree(h->d_work);
     if (h->d_prog) hipFree(h->d_prog);
+    if (h->d_winv) hipFree(h->d_winv);
     if (h->d_splitk) hipFree(h->d_splitk);
     if (h->d_trsm_winv) hipFree(h->d_trsm_winv);
     if (h->d_trsm_tmp) hipFree(h->d_trsm_tmp);

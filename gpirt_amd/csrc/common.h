@@ -72,6 +72,7 @@ struct gpirt_handle_s {
     hipEvent_t   ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr, ev_a = nullptr;
     // persistent panel kernel (panel.hip): one progress counter per 64-row block, epoch-tagged
     unsigned long long* d_prog = nullptr;
+    double*      d_winv = nullptr;        // panel.hip: inverses of the diagonal blocks' 16 x 16 blocks, handed along the pivot chain
     size_t       prog_cap = 0;
     unsigned long long prog_seq = 0;
     long long*   panel_trace = nullptr;   // debug stamps (micro-benchmarks only)

@@ -67,6 +67,28 @@ __device__ __forceinline__ bool wait_prog(const unsigned long long* p, unsigned 
     return true;
 }
 
+// ONE thread polls (back to back) until the counter reaches `need`; returns the value seen, 0 when the wait expired
+// (the guard is recorded as in wait_prog).  The caller hands the result to the work-group through LDS + a barrier.
+__device__ __forceinline__ unsigned long long poll_prog(const unsigned long long* p, unsigned long long need, int* info,
+                                                        int waiter, int awaited)
+{
+    unsigned long long v = ld_prog(p);
+    int spins = 0;
+    while (v < need && ++spins < SPIN_LIMIT) {
+        __builtin_amdgcn_s_sleep(1);
+        v = ld_prog(p);
+    }
+    if (v < need) {
+        if (atomicCAS(info + 1, 0, 1) == 0) {
+            info[2] = waiter; info[3] = awaited;
+            info[4] = (int)(need & 0xffffffffu); info[5] = (int)(need >> 32);
+            info[6] = (int)(v & 0xffffffffu);    info[7] = (int)(v >> 32);
+        }
+        v = 0;
+    }
+    return v;
+}
+
 // every wave's (sc1) stores have been accepted, then one lane raises the row block's counter
 __device__ __forceinline__ void publish(unsigned long long* p, unsigned long long value)
 {

@@ -37,6 +37,8 @@ struct PanelArgs {
     double* A; int64_t lda; int64_t n;
     int64_t K0, c1;                        // panel columns [K0, c1)
     unsigned long long* prog;              // one counter per absolute 64-row block
+    unsigned long long* qprog;             // a second one: finished 16-column blocks of the row block's L_RR (base + 1..3)
+    double* winv;                          // [panel column block][4][256]: inverses of the 16 x 16 diagonal blocks of L_jj
     unsigned long long base;               // epoch of this launch: counters below base are stale
     int* info;
     int nrb;                               // row blocks of this panel (rows K0 .. n-1)
@@ -79,6 +81,11 @@ __device__ __forceinline__ void stg_off(double* sbase, uint32_t voff, double x)
                        __HIP_MEMORY_SCOPE_AGENT);
 }
 
+#ifdef EXP_PLAIN_X
+#define LDG_X ldg_off
+#else
+#define LDG_X ldg_sc1
+#endif
 // 64 x 64 block of A at (row0, col0), all 64 columns valid -> 16 doubles per thread, ready for store_block_lds
 __device__ __forceinline__ void load_block_regs(double (&v)[16], const double* A, int64_t lda,
                                                 int64_t n, int64_t row0, int64_t col0)
@@ -90,11 +97,11 @@ __device__ __forceinline__ void load_block_regs(double (&v)[16], const double* A
     const uint32_t voff = (uint32_t)(((live ? r : last) + (int64_t)(t >> 6) * lda) * 8);
     if (row0 + PB <= n) {        // full block (uniform): plain loads, nothing between them and their first use
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = ldg_sc1(A + row0 + (col0 + 4 * q) * lda, voff);
+        for (int q = 0; q < 16; ++q) v[q] = LDG_X(A + row0 + (col0 + 4 * q) * lda, voff);
     } else {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const double x = ldg_sc1(A + row0 + (col0 + 4 * q) * lda, voff);
+            const double x = LDG_X(A + row0 + (col0 + 4 * q) * lda, voff);
             v[q] = live ? x : 0.0;
         }
     }
@@ -174,6 +181,26 @@ __device__ __forceinline__ void store_strip(const d4 (&X)[4], double* A, int64_t
         }
 }
 
+// ---- progressive hand-off of L_jj to the NEXT diagonal owner (the pivot chain) ---------------------------------
+// 16-column block b of L_jj (full 64-row block), 4 doubles per thread, sc1 loads / the same staged into LDS
+__device__ __forceinline__ void load_lcol(double (&v)[4], const double* A, int64_t lda, int64_t orow0, int64_t col0, const int b)
+{
+    const int t = threadIdx.x;
+    const uint32_t voff = (uint32_t)(((t & 63) + (int64_t)(t >> 6) * lda) * 8);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = ldg_sc1(A + orow0 + (col0 + 16 * b + 4 * q) * lda, voff);
+}
+__device__ __forceinline__ void stage_lcol(const double (&v)[4], double* sM, const int b)
+{
+    const int t = threadIdx.x, r = t & 63, cq = t >> 6;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = 16 * b + cq + 4 * q;
+        if (r >= 16 * b + 16) sM[c * S64_LS + r] = v[q];       // the diagonal block arrives as its inverse
+    }
+}
+
+template <bool PROG>
 __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -222,24 +249,139 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
                 if (!wait_prog(o_prog, p.base + 1, have, &s_seen, p.info, false, cb0 + Rr, cb0 + j)) return;
                 load_block_regs(breg, A, lda, n, orow0, p.K0);
                 load_strip(XI, A, lda, n, row0, p.K0, PB);
+                const bool full_blocks = (row0 + PB <= n) && (orow0 + PB <= n);
+                const uint32_t voffB = (uint32_t)(((t & 63) + (int64_t)(t >> 6) * lda) * 8);
+                const uint32_t voffX = (uint32_t)((16 * wave + i + (int64_t)(4 * g) * lda) * 8);
+#define CHUNK_STAMP(slot) do { if (p.trace && threadIdx.x == 0 && Rr == j + 1) p.trace[((int64_t)Rr * 40 + 20 + k) * 8 + (slot)] = wall_clock64(); } while (0)
                 for (int k = 0; k < j; ++k) {
                     double* sT = (k & 1) ? sT1 : sT0;
+                    CHUNK_STAMP(0);
                     store_block_lds(breg, sT);
-                    __syncthreads();
+                    CHUNK_STAMP(1);
                     d4 XC[4];
 #pragma unroll
                     for (int J = 0; J < 4; ++J) XC[J] = XI[J];
-                    if (k + 1 < j) {
-                        if (!wait_prog(o_prog, p.base + (unsigned long long)(k + 2), have, &s_seen, p.info, false, cb0 + Rr, cb0 + j)) return;
-                        const int64_t kc = p.K0 + (int64_t)(k + 1) * PB;
-                        load_block_regs(breg, A, lda, n, orow0, kc);
-                        load_strip(XI, A, lda, n, row0, kc, PB);
+                    const bool more = (k + 1 < j);
+                    if (more && !wait_prog(o_prog, p.base + (unsigned long long)(k + 2), have, &s_seen, p.info, false, cb0 + Rr, cb0 + j)) return;
+                    CHUNK_STAMP(2);
+                    __syncthreads();
+                    CHUNK_STAMP(3);
+                    if (PROG && full_blocks) {
+                        // chunk k's 64 MFMAs with the 32 loads of chunk k + 1 issued between them, two behind each group of
+                        // four (one basic block: the loads of the last chunk are repeated rather than branched around) --
+                        // a chunk is MFMA-bound (64 x 64 cycles = 1.8 us), the loads' address arithmetic and issue (1 us)
+                        // used to sit in front of it
+                        const int64_t kc = p.K0 + (int64_t)(more ? k + 1 : k) * PB;
+                        const double* gB = A + orow0 + kc * lda;
+                        const double* gX = A + row0 + kc * lda;
+                        const int pi = 4 * (i & 3) + (i >> 2);
+                        // (I, s) outside, J inside: consecutive MFMAs go to four DIFFERENT accumulators, so none waits for
+                        // its predecessor's result; per accumulator the order of the terms is unchanged
+                        // the LDS operands are read one group ahead, so the MFMA pipe never waits for the LDS either
+                        double an[4];
+#pragma unroll
+                        for (int J = 0; J < 4; ++J) an[J] = -sT[(4 * g) * S64_LS + 16 * J + pi];
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            const int I = q >> 2, s2 = q & 3;
+                            double a[4];
+#pragma unroll
+                            for (int J = 0; J < 4; ++J) a[J] = an[J];
+                            if (q + 1 < 16) {
+                                const int In = (q + 1) >> 2, sn = (q + 1) & 3;
+#pragma unroll
+                                for (int J = 0; J < 4; ++J) an[J] = -sT[(16 * In + 4 * g + sn) * S64_LS + 16 * J + pi];
+                            }
+#pragma unroll
+                            for (int J = 0; J < 4; ++J) T[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[J], XC[I][s2], T[J], 0, 0, 0);
+                            breg[q] = LDG_X(gB + (int64_t)(4 * q) * lda, voffB);
+                            XI[I][s2] = ldg_off(gX + (int64_t)(16 * I + s2) * lda, voffX);
+                            if (q + 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // next group's DS reads
+                            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                   // 4 MFMAs
+                            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                   // 2 VMEM reads
+                        }
+                    } else {
+                        if (more) {
+                            const int64_t kc = p.K0 + (int64_t)(k + 1) * PB;
+                            load_block_regs(breg, A, lda, n, orow0, kc);
+                            load_strip(XI, A, lda, n, row0, kc, PB);
+                        }
+                        strip64_update(T, XC, sT);
                     }
-                    strip64_update(T, XC, sT);
+                    CHUNK_STAMP(4);
                 }
             }
             // ---- X = T L_jj^{-T}
             PANEL_STAMP(1);
+            if (PROG && Rr == j + 1 && jcols == PB && row0 + PB <= n) {
+                // The pivot chain: this row block is the next diagonal owner.  L_jj arrives one 16-column block at
+                // a time (potf2_64_lds raises qprog[j] behind block columns 0, 1, 2 and the row block's counter
+                // behind the last; the inverse W_b of each 16 x 16 diagonal block comes with its column) and each
+                // block is consumed while the owner still pivots the next one:
+                //   X_b = T_b W_b^T,   T_J -= X_b L_Jb^T (J > b),   D -= X_b X_b^T
+                // -- the MFMAs of solve64_lower_inv and strip64_update in the same order per accumulator.  The
+                // loads of block b + 1 are issued as soon as its counter is up (one thread polls while the others
+                // compute) and land during block b's diagonal update.  Behind the LAST block only its own stage is
+                // left on the chain: load, 4 + 16 MFMAs, two barriers.
+                double* sO = (sM == sT0) ? sT1 : sT0;     // X, transposed, for the diagonal update
+                const unsigned long long* o_q = p.qprog + cb0 + j;
+                const double* o_w = p.winv + (int64_t)j * 1024;
+                unsigned long long qhave = 0;
+                if (!wait_prog(o_q, p.base + 1, qhave, &s_seen, p.info, true, cb0 + Rr, cb0 + j)) return;
+                PANEL_STAMP(2);
+                const int pi = 4 * (i & 3) + (i >> 2);
+                const uint32_t svoff = (uint32_t)((16 * wave + i + (int64_t)(4 * g) * lda) * 8);
+                double lv[4], wv;
+                load_lcol(lv, A, lda, orow0, col0, 0);
+                wv = ldg_sc1(o_w, (uint32_t)(t * 8));
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    stage_lcol(lv, sM, b);
+                    sM[(16 * b + (t >> 4)) * S64_LS + 16 * b + (t & 15)] = wv;
+                    __syncthreads();
+                    double a[4];
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) a[s2] = sM[(16 * b + 4 * g + s2) * S64_LS + 16 * b + pi];
+                    d4 Y = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s2], T[b][s2], Y, 0, 0, 0);
+                    T[b] = Y;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sO[(16 * b + 4 * g + r) * S64_LS + 16 * wave + i] = Y[r];
+#pragma unroll
+                    for (int J = b + 1; J < 4; ++J) {
+#pragma unroll
+                        for (int s2 = 0; s2 < 4; ++s2) a[s2] = -sM[(16 * b + 4 * g + s2) * S64_LS + 16 * J + pi];
+#pragma unroll
+                        for (int s2 = 0; s2 < 4; ++s2) T[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s2], T[b][s2], T[J], 0, 0, 0);
+                    }
+                    if (b < 3 && t == 64)
+                        s_seen = (b < 2) ? poll_prog(o_q, p.base + (unsigned long long)(b + 2), p.info, cb0 + Rr, cb0 + j)
+                                         : poll_prog(o_prog, p.base + (unsigned long long)(j + 1), p.info, cb0 + Rr, cb0 + j);
+                    __syncthreads();
+                    if (b < 3) {
+                        if (s_seen == 0) return;          // the poll expired (uniform)
+                        load_lcol(lv, A, lda, orow0, col0, b + 1);
+                        wv = ldg_sc1(o_w + 256 * (b + 1), (uint32_t)(t * 8));
+                        if (b == 2) PANEL_STAMP(4);
+                    } else {
+                        PANEL_STAMP(5);
+                    }
+#pragma unroll
+                    for (int J = 0; J < 4; ++J) {
+#pragma unroll
+                        for (int s2 = 0; s2 < 4; ++s2) a[s2] = -sO[(16 * b + 4 * g + s2) * S64_LS + 16 * J + pi];
+#pragma unroll
+                        for (int s2 = 0; s2 < 4; ++s2) D[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s2], T[b][s2], D[J], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) stg_off(A + row0 + (col0 + 16 * b + r) * lda, svoff, T[b][r]);
+                }
+                PANEL_STAMP(6);
+                __syncthreads();                          // both buffers are free for potf2's staging
+                PANEL_STAMP(3);
+                continue;
+            }
             if (!wait_prog(o_prog, p.base + (unsigned long long)(j + 1), have, &s_seen, p.info, Rr == j + 1, cb0 + Rr, cb0 + j)) return;
             PANEL_STAMP(2);
             {
@@ -263,11 +405,28 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
                     const bool ok = r >= c && r <= last && c < jcols;
                     v[q] = ok ? v[q] : ((r == c) ? 1.0 : 0.0);
                 }
-                __syncthreads();                      // every wave is done with sM (previous diagonal update)
-                store_block_lds(v, sM);
+                if (PROG) {
+                    // the diagonal 16 x 16 blocks arrive as their inverses, built once by L_jj's owner (potf2_64_lds)
+                    // instead of by every row block of the panel for itself
+                    const double* o_w = p.winv + (int64_t)j * 1024;
+                    double wq[4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) wq[b] = ldg_sc1(o_w + 256 * b, (uint32_t)(t * 8));
+                    __syncthreads();                  // every wave is done with sM (previous diagonal update)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int c = cq + 4 * q;
+                        if ((r >> 4) != (c >> 4)) sM[c * S64_LS + r] = v[q];
+                    }
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) sM[(16 * b + (t >> 4)) * S64_LS + 16 * b + (t & 15)] = wq[b];
+                } else {
+                    __syncthreads();                  // every wave is done with sM (previous diagonal update)
+                    store_block_lds(v, sM);
+                }
             }
             __syncthreads();
-            invert_diag16(sM);
+            if (!PROG) invert_diag16(sM);
             PANEL_STAMP(4);
             solve64_lower_inv(T, sM);
             PANEL_STAMP(5);
@@ -307,10 +466,18 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
                     if (rr >= dcols || c >= dcols) v = (rr == c) ? 1.0 : 0.0;
                     sM[c * S64_LS + rr] = v;
                 }
+            if (PROG && t < 64) sXT[t * POTF2_XS + 16] = 0.0;               // potf2's hand-shake slots (potf2.h)
             __syncthreads();
             PANEL_STAMP(2);
-            potf2_64_lds<S64_LS>(sM, sXT, A + row0 + row0 * lda, lda, dcols, (int)row0, p.info,
-                                 Rr > 0 ? my_prog : nullptr, p.base + (unsigned long long)Rr);
+            if (PROG)
+                potf2_64_lds<S64_LS, true>(sM, sXT, A + row0 + row0 * lda, lda, dcols, (int)row0, p.info,
+                                           Rr > 0 ? my_prog : nullptr, p.base + (unsigned long long)Rr,
+                                           p.trace ? p.trace + ((int64_t)Rr * 40 + 30) * 8 : nullptr,
+                                           p.qprog + cb0 + Rr, p.base, p.winv + (int64_t)Rr * 1024, sT1);
+            else
+                potf2_64_lds<S64_LS, false>(sM, sXT, A + row0 + row0 * lda, lda, dcols, (int)row0, p.info,
+                                            Rr > 0 ? my_prog : nullptr, p.base + (unsigned long long)Rr,
+                                            p.trace ? p.trace + ((int64_t)Rr * 40 + 30) * 8 : nullptr);
             PANEL_STAMP(3);
             publish(my_prog, p.base + (unsigned long long)(Rr + 1));
             PANEL_STAMP(1);
@@ -339,13 +506,15 @@ int launch_panel_ll(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, 
         if (h->d_prog) GP_HIP(hipFree(h->d_prog));
         h->d_prog = nullptr;
         h->prog_cap = 0;
-        GP_HIP(hipMalloc(&h->d_prog, (size_t)need * sizeof(unsigned long long)));
-        GP_HIP(hipMemsetAsync(h->d_prog, 0, (size_t)need * sizeof(unsigned long long), stream));
+        GP_HIP(hipMalloc(&h->d_prog, 2 * (size_t)need * sizeof(unsigned long long)));      // prog | qprog
+        GP_HIP(hipMemsetAsync(h->d_prog, 0, 2 * (size_t)need * sizeof(unsigned long long), stream));
         GP_HIP(hipStreamSynchronize(stream));
         h->prog_cap = (size_t)need;
     }
     if (!h->panel_attr_set) {
-        GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_ll_kernel),
+        GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_ll_kernel<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel_ll_smem_bytes()));
+        GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_ll_kernel<false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel_ll_smem_bytes()));
         h->panel_attr_set = true;
     }
@@ -353,6 +522,10 @@ int launch_panel_ll(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, 
     PanelArgs p;
     p.A = A; p.lda = lda; p.n = n; p.K0 = K0; p.c1 = c1;
     p.prog = h->d_prog;
+    static const bool progressive = !(getenv("GPIRT_PANEL_COLS") && atoi(getenv("GPIRT_PANEL_COLS")) == 0);
+    p.qprog = progressive ? h->d_prog + h->prog_cap : nullptr;
+    if (progressive && !h->d_winv) GP_HIP(hipMalloc(&h->d_winv, (size_t)32 * 1024 * sizeof(double)));
+    p.winv = h->d_winv;
     h->prog_seq += 1;
     p.base = h->prog_seq * 64ull;                    // a panel publishes at most ncb + 1 <= 17 steps
     p.info = h->d_info;
@@ -361,7 +534,8 @@ int launch_panel_ll(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, 
     p.ncb = (int)((c1 - K0 + PB - 1) / PB);
     if (p.ncb > 32) { set_error("panel wider than 2048 columns"); return GPIRT_E_ARG; }
     const int grid = p.nrb < n_cu ? p.nrb : n_cu;
-    hipLaunchKernelGGL(panel_ll_kernel, dim3((unsigned)grid), dim3(256), panel_ll_smem_bytes(), stream, p);
+    if (progressive) hipLaunchKernelGGL(panel_ll_kernel<true>, dim3((unsigned)grid), dim3(256), panel_ll_smem_bytes(), stream, p);
+    else             hipLaunchKernelGGL(panel_ll_kernel<false>, dim3((unsigned)grid), dim3(256), panel_ll_smem_bytes(), stream, p);
     GP_HIP(hipGetLastError());
     return 0;
 }

@@ -142,6 +142,13 @@ namespace gpirt {
 // left in sD.  A non-positive pivot records k0 + (1-based column) in *info (first failure wins) and NaNs
 // propagate, like LAPACK dpotf2 + the old kernel.  All 256 threads must call it.  late_flag / late_value:
 // optional progress counter of the caller to raise once every wave's EARLIER global stores are visible.
+// col_flag / col_base: optional second counter, raised to col_base + b + 1 as soon as block column b (b = 0, 1, 2)
+// of L is in memory -- the next diagonal owner solves against L column block by column block while the later
+// pivots are still running (panel.hip).  Such a column is stored by wave 3 ALONE, which waits for its own stores
+// (one block column later) and raises the counter without a barrier.  winv (4 x 256 doubles of global memory) / sW (the same in LDS):
+// the inverses W_b of the four 16 x 16 diagonal blocks, dense column-major, built by wave 1 in step with the pivots and
+// stored in front of the counter that announces their column -- the consumer applies them with MFMAs and never inverts
+// anything itself (COLS = true; all three pointers are then required).  The caller zeroes the hand-shake slots (sXT[p * 18 + 16], p = 0..63) before its barrier in front of the call.
 template <int LS>
 __device__ __forceinline__ void potf2_lds_update_block(double* __restrict__ sD, int b, int R, int C)
 {
@@ -163,6 +170,19 @@ __device__ __forceinline__ void potf2_lds_update_block(double* __restrict__ sD, 
     for (int r = 0; r < 4; ++r) sD[(16 * C + 4 * g + r) * LS + 16 * R + i] = acc[r];
 }
 
+// block column b of the factored block (rows >= column) from LDS to global memory, one row per lane: 16 sc1 stores
+template <int LS>
+__device__ __forceinline__ void potf2_store_column(const double* __restrict__ sD, double* Aout, int64_t lda, int nb, int b)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+        const int c = 16 * b + cc;
+        if (lane >= c && lane < nb && c < nb)
+            __hip_atomic_store(&Aout[lane + (int64_t)c * lda], sD[c * LS + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // 1/sqrt(d) for the pivot chain: hardware estimate + one third-order correction (the same arithmetic as the
 // library rsqrt, minus its special-case select): d <= 0, NaN and Inf all come out as NaN/Inf and propagate.
 __device__ __forceinline__ double rsqrt_chain(double d)
@@ -173,19 +193,25 @@ __device__ __forceinline__ double rsqrt_chain(double d)
 }
 
 constexpr int POTF2_XS = 18;      // row stride of the multiplier copy sXT (64 x 18 doubles of LDS)
-template <int LS>
+template <int LS, bool COLS = false>
 __device__ __forceinline__ void potf2_64_lds(double* __restrict__ sD, double* __restrict__ sXT, double* Aout,
                                              int64_t lda, int nb, int k0, int* __restrict__ info,
                                              unsigned long long* late_flag = nullptr, unsigned long long late_value = 0,
-                                             long long* dbg = nullptr)
+                                             long long* dbg = nullptr,
+                                             unsigned long long* col_flag = nullptr, unsigned long long col_base = 0,
+                                             double* winv = nullptr, double* __restrict__ sW = nullptr)
 {
     constexpr int XS = POTF2_XS;
 #define POTF2_STAMP(slot) do { if (dbg && threadIdx.x == 0) dbg[4 * b + (slot)] = wall_clock64(); } while (0)
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     int fail = 0;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
+    double mine = 0.0;                 // (COLS) 1 / L_pp of this lane's own pivot, once it is known
+    // One block column.  COLS = false: unrolled four times (block index a constant everywhere).  COLS = true: a real
+    // loop -- with all four waves busy in different code, four copies of it no longer fit the instruction cache
+    // (measured inside the panel kernel: 2.0-2.3 us of pivots per block column unrolled, 1.6 rolled; 1.3-1.6 for the
+    // COLS = false kernel, whose waves 1..3 mostly sit at barriers).
+    auto block_column = [&](const int b) {
         if (wave == 0) {
             __builtin_amdgcn_s_setprio(3);
             POTF2_STAMP(0);
@@ -227,7 +253,21 @@ __device__ __forceinline__ void potf2_64_lds(double* __restrict__ sD, double* __
                     pre = s0 + s1;
                 }
                 x[c] = acc * rinv;                     // (d)
-                sXT[lane * XS + c] = x[c];
+                if (COLS) {
+                    // hand column p to the inverse wave: the column, then 1/L_pp into row p's pad slot 16, which the
+                    // inverse wave polls (zero = not yet; the caller zeroes the slots).  Every lane rewrites ITS OWN
+                    // slot with `mine` (its pivot's reciprocal once it has happened, zero before): no branch and no
+                    // pivot-dependent address on the chain.  The LDS executes one wave's accesses in order and the
+                    // empty asm keeps the compiler from reordering them (volatile accesses would each be waited for:
+                    // measured 36 us per block instead of 10).
+                    sXT[lane * XS + c] = x[c];
+                    asm volatile("" ::: "memory");
+                    mine = (lane == p) ? rinv : mine;
+                    sXT[lane * XS + 16] = mine;
+                    asm volatile("" ::: "memory");
+                } else {
+                    sXT[lane * XS + c] = x[c];
+                }
 #pragma unroll
                 for (int k = 0; k < 16; ++k) mA[k] = mB[k];
             }
@@ -239,11 +279,45 @@ __device__ __forceinline__ void potf2_64_lds(double* __restrict__ sD, double* __
             // deferred publication (see below): every wave makes sure its earlier global stores have been
             // accepted by the L2 (long done by now) before the first barrier
             if (b == 0 && late_flag) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else if (b == 0) {
-            if (late_flag) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
-            // rest of the previous block column's update (columns b + 1 ..), hidden behind wave 0's pivots
-            if (b == 1) {                                  // (wave 3 is busy publishing, see below)
+            if (b == 0 && late_flag) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (COLS) {
+                // rest of the previous block column's update (columns b + 1 ..) on wave 2, hidden behind wave 0's pivots
+                if (wave == 2) {
+                    if (b == 1) { potf2_lds_update_block<LS>(sD, 0, 2, 2); potf2_lds_update_block<LS>(sD, 0, 3, 3); potf2_lds_update_block<LS>(sD, 0, 3, 2); }
+                    if (b == 2) potf2_lds_update_block<LS>(sD, 1, 3, 3);
+                }
+                // W_b = L_bb^-1 on wave 1, one column of L behind wave 0's pivots: lane j runs the forward substitution on
+                // e_j, step k as soon as pivot 16b + k is out (LDS counter), so W_b is complete ~one step after the last pivot
+                if (wave == 1 && lane < 16) {
+                    double w[16];
+#pragma unroll
+                    for (int i2 = 0; i2 < 16; ++i2) w[i2] = (i2 == lane) ? 1.0 : 0.0;
+                    int zero;                                        // opaque: keeps the addresses below as
+                    asm volatile("v_mov_b32 %0, 0" : "=v"(zero));     // (one VGPR base) + immediate offsets
+                    const double* blk = sXT + (16 * b) * XS + zero;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        double rk;
+                        while (true) {
+                            asm volatile("" ::: "memory");
+                            rk = blk[k * XS + 16];
+                            if (rk != 0.0) break;                  // (NaN from a failed pivot passes too)
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        asm volatile("" ::: "memory");
+                        double lk[16];
+#pragma unroll
+                        for (int i2 = k + 1; i2 < 16; ++i2) lk[i2] = blk[i2 * XS + k];
+                        const double wk = w[k] * rk;
+                        w[k] = wk;
+#pragma unroll
+                        for (int i2 = k + 1; i2 < 16; ++i2) w[i2] = fma(-lk[i2], wk, w[i2]);
+                    }
+#pragma unroll
+                    for (int i2 = 0; i2 < 16; ++i2) sW[256 * b + lane * 16 + i2] = w[i2];
+                }
+            } else if (b == 1) {                           // (wave 3 is busy publishing, see below)
                 if (wave == 1) { potf2_lds_update_block<LS>(sD, 0, 2, 2); potf2_lds_update_block<LS>(sD, 0, 3, 3); }
                 if (wave == 2) potf2_lds_update_block<LS>(sD, 0, 3, 2);
             } else if (b == 2) {
@@ -270,7 +344,46 @@ __device__ __forceinline__ void potf2_64_lds(double* __restrict__ sD, double* __
             // (fence-free form, flagsync.h: every wave waited vmcnt(0) on its sc1 stores before the barrier above)
             if (lane == 0) __hip_atomic_store(late_flag, late_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (wave >= 1) {
+        if (COLS && b < 3) {
+            // progressive hand-off: column b and W_b go out on wave 3 alone, which waits for its own stores and raises
+            // the column counter without a barrier
+            if (wave == 3) {
+                // (the counter of column b - 1 first: its stores went out a whole block column ago, so the wait is
+                // over before it starts -- waiting right behind the stores held wave 3, and with it the next barrier
+                // of the pivot wave, for the 2-3 us a write-through takes while the panel's other work-groups stream)
+                if (b >= 1) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(col_flag, col_base + (unsigned long long)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                potf2_store_column<LS>(sD, Aout, lda, nb, b);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    __hip_atomic_store(&winv[256 * b + lane + 64 * q], sW[256 * b + lane + 64 * q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else if (COLS) {
+            // last block column: W_3 on wave 1, the column itself on waves 2 and 3 (the caller publishes)
+            if (wave == 3) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(col_flag, col_base + 3ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (wave == 1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    __hip_atomic_store(&winv[256 * 3 + lane + 64 * q], sW[256 * 3 + lane + 64 * q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (wave >= 2) {
+                // one row per lane, eight columns per wave: the column index is wave-uniform, so the address is
+                // (scalar column offset) + lane -- a per-lane column index costs a 64-bit multiply per store, which
+                // the compiler hoists to the top of the kernel and spills
+                const int c0 = 48 + 8 * (__builtin_amdgcn_readfirstlane(wave) - 2);
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) {
+                    const int c = c0 + cc;
+                    if (lane >= c && lane < nb && c < nb)
+                        __hip_atomic_store(&Aout[lane + (int64_t)c * lda], sD[c * LS + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        } else if (wave >= 1) {
             const int u = (wave - 1) * 64 + lane;          // 0 .. 191
 #pragma unroll
             for (int q = 0; q < 6; ++q) {
@@ -281,6 +394,13 @@ __device__ __forceinline__ void potf2_64_lds(double* __restrict__ sD, double* __
             }
         }
         POTF2_STAMP(3);
+    };
+    if (COLS) {
+#pragma unroll 1
+        for (int b = 0; b < 4; ++b) block_column(b);
+    } else {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) block_column(b);
     }
 #undef POTF2_STAMP
     if (wave == 0 && lane == 0 && fail != 0) atomicCAS(info, 0, k0 + fail);

@@ -49,12 +49,30 @@ int main(int argc, char** argv)
                (q[2] - q[0]) / 100.0, (q[3] - q[2]) / 100.0, (q[1] - q[3]) / 100.0);
         if (R > 0) {
             const long long* s = &tr[(R * 40 + R - 1) * 8];
-            printf("  last step: L seen %.2f [staged +%.2f, solved +%.2f, stored +%.2f, D updated+published +%.2f]", us(s[2]),
+            // progressive hand-off (GPIRT_PANEL_COLS != 0): slot 2 = first column block seen, 4 = last one seen,
+            // 5 = last X block exchanged, 6 = D updated; otherwise: 2 = L seen, 4 = staged + inverted, 5 = solved, 6 = stored
+            printf("  last step: began %.2f, gemm done %.2f, L seen %.2f [+%.2f, +%.2f, +%.2f, +%.2f]", us(s[0]), us(s[1]), us(s[2]),
                    (s[4] - s[2]) / 100.0, (s[5] - s[4]) / 100.0, (s[6] - s[5]) / 100.0, (s[3] - s[6]) / 100.0);
         }
         printf("\n");
     }
+    {
+        const int R = ncb - 1;
+        printf("chunks of owner %d's last step [regs->LDS, copy+wait, barrier, MFMAs+loads] and gap to the next chunk:\n", R);
+        for (int k = 0; k < R - 1; ++k) {
+            const long long* c = &tr[((size_t)R * 40 + 20 + k) * 8];
+            const long long* c2 = &tr[((size_t)R * 40 + 20 + k + 1) * 8];
+            printf("   k=%d at %.2f: %.2f %.2f %.2f %.2f | %.2f\n", k, us(c[0]), (c[1] - c[0]) / 100.0, (c[2] - c[1]) / 100.0, (c[3] - c[2]) / 100.0,
+                   (c[4] - c[3]) / 100.0, k + 1 < R - 1 ? (c2[0] - c[4]) / 100.0 : 0.0);
+        }
+    }
     const int show[3] = { ncb - 1, ncb, nrb - 1 };
+    for (int R : { 1, 2, 5 }) {
+        const long long* d = &tr[((size_t)R * 40 + 30) * 8];
+        printf("potf2 of R=%d, per block column [pivots, write-back, barrier+U1+stores]:", R);
+        for (int b = 0; b < 4; ++b) printf("  [%.2f %.2f %.2f]", (d[4 * b + 1] - d[4 * b]) / 100.0, (d[4 * b + 2] - d[4 * b + 1]) / 100.0, (d[4 * b + 3] - d[4 * b + 2]) / 100.0);
+        printf("\n");
+    }
     for (int R : show) {
         if (R < 0 || R >= nrb) continue;
         printf("row block %d: step j: start, gemm done, L_jj seen, step done\n", R);

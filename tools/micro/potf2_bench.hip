@@ -39,6 +39,27 @@ __global__ __launch_bounds__(256) void k_lds(double* A, int64_t lda, int* info, 
     }
 }
 
+// the same with the progressive hand-off (COLS): inverse wave, per-column stores + counters
+__global__ __launch_bounds__(256) void k_cols(double* A, int64_t lda, int* info, long long* ts, int reps,
+                                              unsigned long long* flags, double* winv)
+{
+    constexpr int LS = 68;
+    __shared__ __attribute__((aligned(16))) double sD[64 * LS];
+    __shared__ __attribute__((aligned(16))) double sXT[64 * POTF2_XS];
+    __shared__ __attribute__((aligned(16))) double sW[4 * 256];
+    for (int r = 0; r < reps; ++r) {
+        double* Ar = A + (int64_t)r * 64 * lda;
+        for (int idx = threadIdx.x; idx < 4096; idx += 256) sD[(idx >> 6) * LS + (idx & 63)] = Ar[(idx & 63) + (idx >> 6) * lda];
+        if (threadIdx.x < 64) sXT[threadIdx.x * POTF2_XS + 16] = 0.0;
+        __syncthreads();
+        long long t0 = wall_clock64();
+        potf2_64_lds<LS, true>(sD, sXT, Ar, lda, 64, 0, info, nullptr, 0, ts + 16, flags + 1, 64ull * r, winv, sW);
+        __syncthreads();
+        long long t1 = wall_clock64();
+        if (threadIdx.x == 0) ts[r] = t1 - t0;
+    }
+}
+
 __global__ void k_pingpong(int* flags, double* data, long long* ts, int iters)
 {
     // block 0 and block 1 alternate: publish data + flag (release), the other spins (acquire) and checks the data
@@ -102,6 +123,35 @@ int main()
         printf("\n   per block column [pivots, write-back, barrier+U1]:");
         for (int b = 0; b < 4; ++b) printf("  [%.2f %.2f %.2f]", (ts[16 + 4 * b + 1] - ts[16 + 4 * b]) / 100.0, (ts[16 + 4 * b + 2] - ts[16 + 4 * b + 1]) / 100.0, (ts[16 + 4 * b + 3] - ts[16 + 4 * b + 2]) / 100.0);
         printf("\n");
+    }
+    {
+        unsigned long long* dfl; double* dw;
+        CK(hipMalloc(&dfl, 64)); CK(hipMemset(dfl, 0, 64)); CK(hipMalloc(&dw, 1024 * 8));
+        for (int pass = 0; pass < 2; ++pass) {
+            CK(hipMemcpy(dA, S.data(), S.size() * 8, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_cols, dim3(1), dim3(256), 0, 0, dA, (int64_t)lda, dinfo, dts, reps, dfl, dw);
+            CK(hipDeviceSynchronize());
+            long long ts[64];
+            CK(hipMemcpy(ts, dts, sizeof(ts), hipMemcpyDeviceToHost));
+            printf("potf2_64_lds<COLS>, in-kernel (us):");
+            for (int r = 0; r < reps; ++r) printf(" %.2f", ts[r] / 100.0);
+            printf("\n   per block column [pivots, write-back, barrier+U1+stores]:");
+            for (int b = 0; b < 4; ++b) printf("  [%.2f %.2f %.2f]", (ts[16 + 4 * b + 1] - ts[16 + 4 * b]) / 100.0, (ts[16 + 4 * b + 2] - ts[16 + 4 * b + 1]) / 100.0, (ts[16 + 4 * b + 3] - ts[16 + 4 * b + 2]) / 100.0);
+            printf("\n");
+        }
+        // W_3 of the last block against L
+        std::vector<double> W(1024), Lh(64 * 64);
+        CK(hipMemcpy(W.data(), dw, 1024 * 8, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(Lh.data(), dA + (size_t)(reps - 1) * 64 * lda, 64 * 64 * 8, hipMemcpyDeviceToHost));
+        double werr = 0;
+        for (int b = 0; b < 4; ++b)
+            for (int i = 0; i < 16; ++i)
+                for (int j = 0; j < 16; ++j) {
+                    double sacc = 0;
+                    for (int k = 0; k < 16; ++k) sacc += ((i >= k) ? Lh[(16 * b + i) + 64 * (16 * b + k)] : 0.0) * W[256 * b + j * 16 + k];
+                    werr = fmax(werr, fabs(sacc - (i == j ? 1.0 : 0.0)));
+                }
+        printf("max |L_bb W_b - I| = %.3e\n", werr);
     }
     // residual of the last block
     std::vector<double> Lh(S.size());
