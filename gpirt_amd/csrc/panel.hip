@@ -252,20 +252,15 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
                 const bool full_blocks = (row0 + PB <= n) && (orow0 + PB <= n);
                 const uint32_t voffB = (uint32_t)(((t & 63) + (int64_t)(t >> 6) * lda) * 8);
                 const uint32_t voffX = (uint32_t)((16 * wave + i + (int64_t)(4 * g) * lda) * 8);
-#define CHUNK_STAMP(slot) do { if (p.trace && threadIdx.x == 0 && Rr == j + 1) p.trace[((int64_t)Rr * 40 + 20 + k) * 8 + (slot)] = wall_clock64(); } while (0)
                 for (int k = 0; k < j; ++k) {
                     double* sT = (k & 1) ? sT1 : sT0;
-                    CHUNK_STAMP(0);
                     store_block_lds(breg, sT);
-                    CHUNK_STAMP(1);
                     d4 XC[4];
 #pragma unroll
                     for (int J = 0; J < 4; ++J) XC[J] = XI[J];
                     const bool more = (k + 1 < j);
                     if (more && !wait_prog(o_prog, p.base + (unsigned long long)(k + 2), have, &s_seen, p.info, false, cb0 + Rr, cb0 + j)) return;
-                    CHUNK_STAMP(2);
                     __syncthreads();
-                    CHUNK_STAMP(3);
                     if (PROG && full_blocks) {
                         // chunk k's 64 MFMAs with the 32 loads of chunk k + 1 issued between them, two behind each group of
                         // four (one basic block: the loads of the last chunk are repeated rather than branched around) --
@@ -308,7 +303,6 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
                         }
                         strip64_update(T, XC, sT);
                     }
-                    CHUNK_STAMP(4);
                 }
             }
             // ---- X = T L_jj^{-T}

@@ -56,16 +56,6 @@ int main(int argc, char** argv)
         }
         printf("\n");
     }
-    {
-        const int R = ncb - 1;
-        printf("chunks of owner %d's last step [regs->LDS, copy+wait, barrier, MFMAs+loads] and gap to the next chunk:\n", R);
-        for (int k = 0; k < R - 1; ++k) {
-            const long long* c = &tr[((size_t)R * 40 + 20 + k) * 8];
-            const long long* c2 = &tr[((size_t)R * 40 + 20 + k + 1) * 8];
-            printf("   k=%d at %.2f: %.2f %.2f %.2f %.2f | %.2f\n", k, us(c[0]), (c[1] - c[0]) / 100.0, (c[2] - c[1]) / 100.0, (c[3] - c[2]) / 100.0,
-                   (c[4] - c[3]) / 100.0, k + 1 < R - 1 ? (c2[0] - c[4]) / 100.0 : 0.0);
-        }
-    }
     const int show[3] = { ncb - 1, ncb, nrb - 1 };
     for (int R : { 1, 2, 5 }) {
         const long long* d = &tr[((size_t)R * 40 + 30) * 8];
