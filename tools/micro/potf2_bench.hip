@@ -27,6 +27,7 @@ __global__ __launch_bounds__(256) void k_lds(double* A, int64_t lda, int* info, 
     constexpr int LS = 68;
     __shared__ __attribute__((aligned(16))) double sD[64 * LS];
     __shared__ __attribute__((aligned(16))) double sXT[64 * POTF2_XS];
+    const long long w0 = wall_clock64(), c0 = clock64();
     for (int r = 0; r < reps; ++r) {
         double* Ar = A + (int64_t)r * 64 * lda;
         for (int idx = threadIdx.x; idx < 4096; idx += 256) sD[(idx >> 6) * LS + (idx & 63)] = Ar[(idx & 63) + (idx >> 6) * lda];
@@ -37,6 +38,7 @@ __global__ __launch_bounds__(256) void k_lds(double* A, int64_t lda, int* info, 
         long long t1 = wall_clock64();
         if (threadIdx.x == 0) ts[r] = t1 - t0;
     }
+    if (threadIdx.x == 0) { ts[40] = wall_clock64() - w0; ts[41] = clock64() - c0; }   // shader clock against the 100 MHz wall clock
 }
 
 // the same with the progressive hand-off (COLS): inverse wave, per-column stores + counters
@@ -120,6 +122,7 @@ int main()
         CK(hipMemcpy(ts, dts, sizeof(ts), hipMemcpyDeviceToHost));
         printf("potf2_64_lds, in-kernel (us):");
         for (int r = 0; r < reps; ++r) printf(" %.2f", ts[r] / 100.0);
+        printf("\n   shader clock during the kernel: %.0f MHz", 100.0 * (double)ts[41] / (double)ts[40]);
         printf("\n   per block column [pivots, write-back, barrier+U1]:");
         for (int b = 0; b < 4; ++b) printf("  [%.2f %.2f %.2f]", (ts[16 + 4 * b + 1] - ts[16 + 4 * b]) / 100.0, (ts[16 + 4 * b + 2] - ts[16 + 4 * b + 1]) / 100.0, (ts[16 + 4 * b + 3] - ts[16 + 4 * b + 2]) / 100.0);
         printf("\n");
