@@ -200,6 +200,26 @@ __device__ __forceinline__ void stage_lcol(const double (&v)[4], double* sM, con
     }
 }
 
+// the wave's 16-row strip of a 64 x 64 block kept column-major in LDS (accumulator layout <-> sB[c * S64_LS + row])
+__device__ __forceinline__ void strip_from_lds(d4 (&X)[4], const double* sB)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int J = 0; J < 4; ++J)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) X[J][r] = sB[(16 * J + 4 * g + r) * S64_LS + 16 * wave + i];
+}
+__device__ __forceinline__ void strip_to_lds(const d4 (&X)[4], double* sB)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int J = 0; J < 4; ++J)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sB[(16 * J + 4 * g + r) * S64_LS + 16 * wave + i] = X[J][r];
+}
+
 template <bool PROG>
 __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
 {
@@ -210,6 +230,10 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
     double* sT0 = smem;
     double* sT1 = smem + PB * S64_LS;
     double* sXT = smem + 2 * PB * S64_LS;             // potf2's multiplier copy
+    // (PROG) the diagonal block D of a diagonal owner lives HERE between its steps, not in 32 accumulator registers:
+    // each step reads its strip, updates it and writes it back (own rows only: no barrier), potf2 factors it in place,
+    // and the register allocator no longer spills D around the chunk loop (its reload sat on the pivot chain)
+    double* sDD = smem + 2 * PB * S64_LS + PB * POTF2_XS;
     __shared__ unsigned long long s_seen;
 
     const int t = threadIdx.x;
@@ -230,6 +254,16 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
             const int64_t left = p.c1 - row0;
             dcols = (int)(left < PB ? left : PB);
             load_strip(D, A, lda, n, row0, row0, dcols);
+            if (PROG) {
+#pragma unroll
+                for (int J = 0; J < 4; ++J)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = 16 * J + 4 * g + r, rr = 16 * wave + i;
+                        if (rr >= dcols || c >= dcols) D[J][r] = (rr == c) ? 1.0 : 0.0;      // identity past a ragged end
+                    }
+                strip_to_lds(D, sDD);
+            }
         }
         for (int j = 0; j < jend; ++j) {
             const int64_t col0 = p.K0 + (int64_t)j * PB;
@@ -291,9 +325,14 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
                             for (int J = 0; J < 4; ++J) T[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[J], XC[I][s2], T[J], 0, 0, 0);
                             breg[q] = LDG_X(gB + (int64_t)(4 * q) * lda, voffB);
                             XI[I][s2] = ldg_off(gX + (int64_t)(16 * I + s2) * lda, voffX);
-                            if (q + 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // next group's DS reads
-                            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                   // 4 MFMAs
-                            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                   // 2 VMEM reads
+                            // issue order: MFMA, DS read, (VMEM read), MFMA, ... -- everything that is not an MFMA goes
+                            // out while the pipe is busy with the one in front of it
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                if (q + 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                                if (u & 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                            }
                         }
                     } else {
                         if (more) {
@@ -326,6 +365,8 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
                 const int pi = 4 * (i & 3) + (i >> 2);
                 const uint32_t svoff = (uint32_t)((16 * wave + i + (int64_t)(4 * g) * lda) * 8);
                 double lv[4], wv;
+                d4 Dd[4];
+                strip_from_lds(Dd, sDD);
                 load_lcol(lv, A, lda, orow0, col0, 0);
                 wv = ldg_sc1(o_w, (uint32_t)(t * 8));
 #pragma unroll
@@ -366,13 +407,14 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
 #pragma unroll
                         for (int s2 = 0; s2 < 4; ++s2) a[s2] = -sO[(16 * b + 4 * g + s2) * S64_LS + 16 * J + pi];
 #pragma unroll
-                        for (int s2 = 0; s2 < 4; ++s2) D[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s2], T[b][s2], D[J], 0, 0, 0);
+                        for (int s2 = 0; s2 < 4; ++s2) Dd[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s2], T[b][s2], Dd[J], 0, 0, 0);
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) stg_off(A + row0 + (col0 + 16 * b + r) * lda, svoff, T[b][r]);
                 }
+                strip_to_lds(Dd, sDD);
                 PANEL_STAMP(6);
-                __syncthreads();                          // both buffers are free for potf2's staging
+                __syncthreads();                          // both buffers are free for potf2's scratch
                 PANEL_STAMP(3);
                 continue;
             }
@@ -434,7 +476,14 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
                     for (int r = 0; r < 4; ++r) sM[(16 * J + 4 * g + r) * S64_LS + 16 * wave + i] = T[J][r];
                 __syncthreads();
                 PANEL_STAMP(6);
-                strip64_update(D, T, sM);
+                if (PROG) {
+                    d4 Dd[4];
+                    strip_from_lds(Dd, sDD);
+                    strip64_update(Dd, T, sM);
+                    strip_to_lds(Dd, sDD);
+                } else {
+                    strip64_update(D, T, sM);
+                }
                 // X[R,j] is published only now: its global stores drained behind the MFMAs, so the release
                 // fence is cheaper, and the barrier inside publish() also frees sM for its next use.  The
                 // last one (j == Rr - 1) sits on the pivot chain: potf2_64_lds publishes it one barrier in.
@@ -450,16 +499,18 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
             // potf2_64_lds factors them there, storing L to global on the way
             const int tstep = 39;
             PANEL_STAMP(0);
-            double* sM = sT0;                         // both buffers are free (barrier at the end of the last step)
+            double* sM = PROG ? sDD : sT0;            // both buffers are free (barrier at the end of the last step)
+            if (!PROG) {
 #pragma unroll
-            for (int J = 0; J < 4; ++J)
+                for (int J = 0; J < 4; ++J)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int c = 16 * J + 4 * g + r, rr = 16 * wave + i;
-                    double v = D[J][r];
-                    if (rr >= dcols || c >= dcols) v = (rr == c) ? 1.0 : 0.0;
-                    sM[c * S64_LS + rr] = v;
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = 16 * J + 4 * g + r, rr = 16 * wave + i;
+                        double v = D[J][r];
+                        if (rr >= dcols || c >= dcols) v = (rr == c) ? 1.0 : 0.0;
+                        sM[c * S64_LS + rr] = v;
+                    }
+            }
             if (PROG && t < 64) sXT[t * POTF2_XS + 16] = 0.0;               // potf2's hand-shake slots (potf2.h)
             __syncthreads();
             PANEL_STAMP(2);
@@ -482,7 +533,7 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
 
 }  // namespace
 
-size_t panel_ll_smem_bytes() { return (size_t)(2 * PB * S64_LS + PB * POTF2_XS) * sizeof(double); }
+size_t panel_ll_smem_bytes() { return (size_t)(3 * PB * S64_LS + PB * POTF2_XS) * sizeof(double); }
 
 // factor panel columns [K0, c1) (all rows below) with the persistent kernel
 int launch_panel_ll(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t K0, int64_t c1)
