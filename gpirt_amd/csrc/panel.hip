@@ -51,6 +51,17 @@ struct PanelArgs {
         if (p.trace && threadIdx.x == 0) p.trace[((int64_t)Rr * 40 + (tstep)) * 8 + (slot)] = wall_clock64(); \
     } while (0)
 
+// The thread index as the helpers below see it: re-materialised at every call (the empty asm cannot be hoisted or merged),
+// so the per-lane offsets derived from it are recomputed where they are used -- a few VALU operations -- instead of being
+// hoisted to the top of the kernel, where dozens of them stay alive for its whole length and push the accumulators of the
+// hot loops out to scratch (the kernel runs at 512 registers per lane).
+__device__ __forceinline__ int tid_here()
+{
+    int v = (int)threadIdx.x;
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 // Global accesses are written as (wave-uniform base) + (32-bit per-lane byte offset): the column part of
 // every address is scalar arithmetic, the lane offset is computed once, and out-of-range rows are clamped
 // to the last row and zeroed after the load -- no predicated loads, so a block's 16 loads fly together.
@@ -90,7 +101,7 @@ __device__ __forceinline__ void stg_off(double* sbase, uint32_t voff, double x)
 __device__ __forceinline__ void load_block_regs(double (&v)[16], const double* A, int64_t lda,
                                                 int64_t n, int64_t row0, int64_t col0)
 {
-    const int t = threadIdx.x;
+    const int t = tid_here();
     const int r = t & 63;
     const int last = (int)(n - 1 - row0);
     const bool live = r <= last;
@@ -108,7 +119,7 @@ __device__ __forceinline__ void load_block_regs(double (&v)[16], const double* A
 }
 __device__ __forceinline__ void store_block_lds(const double (&v)[16], double* __restrict__ sT)
 {
-    const int t = threadIdx.x;
+    const int t = tid_here();
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int idx = t + 256 * q;
@@ -122,7 +133,7 @@ __device__ __forceinline__ void store_block_lds(const double (&v)[16], double* _
 __device__ __forceinline__ void load_strip(d4 (&X)[4], const double* A, int64_t lda, int64_t n,
                                            int64_t row0, int64_t col0, int ncols)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t_ = tid_here(), lane = t_ & 63, wave = t_ >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int rr = 16 * wave + i;
     const int last = (int)(n - 1 - row0);
@@ -160,7 +171,7 @@ __device__ __forceinline__ void load_strip(d4 (&X)[4], const double* A, int64_t 
 __device__ __forceinline__ void store_strip(const d4 (&X)[4], double* A, int64_t lda, int64_t n,
                                             int64_t row0, int64_t col0, int ncols, bool lower_only, bool shared = true)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t_ = tid_here(), lane = t_ & 63, wave = t_ >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int rr = 16 * wave + i;
     if (row0 + rr >= n) return;
@@ -185,14 +196,14 @@ __device__ __forceinline__ void store_strip(const d4 (&X)[4], double* A, int64_t
 // 16-column block b of L_jj (full 64-row block), 4 doubles per thread, sc1 loads / the same staged into LDS
 __device__ __forceinline__ void load_lcol(double (&v)[4], const double* A, int64_t lda, int64_t orow0, int64_t col0, const int b)
 {
-    const int t = threadIdx.x;
+    const int t = tid_here();
     const uint32_t voff = (uint32_t)(((t & 63) + (int64_t)(t >> 6) * lda) * 8);
 #pragma unroll
     for (int q = 0; q < 4; ++q) v[q] = ldg_sc1(A + orow0 + (col0 + 16 * b + 4 * q) * lda, voff);
 }
 __device__ __forceinline__ void stage_lcol(const double (&v)[4], double* sM, const int b)
 {
-    const int t = threadIdx.x, r = t & 63, cq = t >> 6;
+    const int t = tid_here(), r = t & 63, cq = t >> 6;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int c = 16 * b + cq + 4 * q;
@@ -203,7 +214,7 @@ __device__ __forceinline__ void stage_lcol(const double (&v)[4], double* sM, con
 // the wave's 16-row strip of a 64 x 64 block kept column-major in LDS (accumulator layout <-> sB[c * S64_LS + row])
 __device__ __forceinline__ void strip_from_lds(d4 (&X)[4], const double* sB)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t_ = tid_here(), lane = t_ & 63, wave = t_ >> 6;
     const int i = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int J = 0; J < 4; ++J)
@@ -212,7 +223,7 @@ __device__ __forceinline__ void strip_from_lds(d4 (&X)[4], const double* sB)
 }
 __device__ __forceinline__ void strip_to_lds(const d4 (&X)[4], double* sB)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t_ = tid_here(), lane = t_ & 63, wave = t_ >> 6;
     const int i = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int J = 0; J < 4; ++J)
@@ -236,7 +247,7 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
     double* sDD = smem + 2 * PB * S64_LS + PB * POTF2_XS;
     __shared__ unsigned long long s_seen;
 
-    const int t = threadIdx.x;
+    const int t = tid_here();
     const int lane = t & 63, wave = t >> 6;
     const int i = lane & 15, g = lane >> 4;
     double* A = p.A;      // read and written by many work-groups: no restrict anywhere in this file
@@ -266,6 +277,9 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
             }
         }
         for (int j = 0; j < jend; ++j) {
+            const int t = tid_here();                 // (shadows the kernel's: per-lane offsets are rebuilt per step)
+            const int lane = t & 63, wave = t >> 6;
+            const int i = lane & 15, g = lane >> 4;
             const int64_t col0 = p.K0 + (int64_t)j * PB;
             const int64_t orow0 = col0;               // the diagonal owner of column block j sits at rows col0..
             const unsigned long long* o_prog = p.prog + cb0 + j;
