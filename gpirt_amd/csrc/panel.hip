@@ -92,11 +92,6 @@ __device__ __forceinline__ void stg_off(double* sbase, uint32_t voff, double x)
                        __HIP_MEMORY_SCOPE_AGENT);
 }
 
-#ifdef EXP_PLAIN_X
-#define LDG_X ldg_off
-#else
-#define LDG_X ldg_sc1
-#endif
 // 64 x 64 block of A at (row0, col0), all 64 columns valid -> 16 doubles per thread, ready for store_block_lds
 __device__ __forceinline__ void load_block_regs(double (&v)[16], const double* A, int64_t lda,
                                                 int64_t n, int64_t row0, int64_t col0)
@@ -108,11 +103,11 @@ __device__ __forceinline__ void load_block_regs(double (&v)[16], const double* A
     const uint32_t voff = (uint32_t)(((live ? r : last) + (int64_t)(t >> 6) * lda) * 8);
     if (row0 + PB <= n) {        // full block (uniform): plain loads, nothing between them and their first use
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = LDG_X(A + row0 + (col0 + 4 * q) * lda, voff);
+        for (int q = 0; q < 16; ++q) v[q] = ldg_sc1(A + row0 + (col0 + 4 * q) * lda, voff);
     } else {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const double x = LDG_X(A + row0 + (col0 + 4 * q) * lda, voff);
+            const double x = ldg_sc1(A + row0 + (col0 + 4 * q) * lda, voff);
             v[q] = live ? x : 0.0;
         }
     }
@@ -337,7 +332,7 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
                             }
 #pragma unroll
                             for (int J = 0; J < 4; ++J) T[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[J], XC[I][s2], T[J], 0, 0, 0);
-                            breg[q] = LDG_X(gB + (int64_t)(4 * q) * lda, voffB);
+                            breg[q] = ldg_sc1(gB + (int64_t)(4 * q) * lda, voffB);
                             XI[I][s2] = ldg_off(gX + (int64_t)(16 * I + s2) * lda, voffX);
                             // issue order: MFMA, DS read, (VMEM read), MFMA, ... -- everything that is not an MFMA goes
                             // out while the pipe is busy with the one in front of it
