@@ -298,7 +298,10 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
     // whose work-groups turn over every ~40 us, so the panel kernel's work-groups (each needs a whole CU) find room
     // sooner than beside 128-tile updates; =1 fuses a step's launches into one product of depth (q + 1) * 1024
     // (one read-modify-write of C, but 1.2 rounds of long tiles: slower).
-    static const int defer = env_int("GPIRT_DEFER", 3);      // 3: one launch per panel and block column (default), 2: off, 1: fused
+    // By size unless GPIRT_DEFER says otherwise: from ~14000 rows on the plain order's large 128-tile updates win
+    // (n = 16384: 28.3 against 29.6 ms, n = 20000: 54.7 against 59.9; n = 12288: 14.0 against 13.5, n = 8192: 5.3 against 5.0).
+    static const int defer_env = env_int("GPIRT_DEFER", 0);  // 3: one launch per panel and block column, 2: off, 1: fused; 0: by size
+    const int defer = defer_env ? defer_env : (n <= 14336 ? 3 : 2);
     std::vector<int64_t> done_col;                   // (mode 3) columns < done_col[q] carry panel q's update
     GP_TRY(factor_panel(h, stream, A, nr, lda, 0, nbo < n ? nbo : n));
     for (int64_t K0 = 0; K0 < n; K0 += nbo) {
