@@ -310,12 +310,10 @@ __device__ __forceinline__ void potf2_64_lds(double* __restrict__ sD, double* __
 #pragma unroll
                         for (int i2 = k + 1; i2 < 16; ++i2) lk[i2] = blk[i2 * XS + k];
                         const double wk = w[k] * rk;
-                        w[k] = wk;
+                        sW[256 * b + lane * 16 + k] = wk;          // (final: written as it appears, nothing is left for the end)
 #pragma unroll
                         for (int i2 = k + 1; i2 < 16; ++i2) w[i2] = fma(-lk[i2], wk, w[i2]);
                     }
-#pragma unroll
-                    for (int i2 = 0; i2 < 16; ++i2) sW[256 * b + lane * 16 + i2] = w[i2];
                 }
             } else if (b == 1) {                           // (wave 3 is busy publishing, see below)
                 if (wave == 1) { potf2_lds_update_block<LS>(sD, 0, 2, 2); potf2_lds_update_block<LS>(sD, 0, 3, 3); }
