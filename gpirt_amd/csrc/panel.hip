@@ -231,8 +231,9 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     // Two 64 x 64 buffers (34 KB each): the "other" GEMM operand alternates between them, and whichever
-    // one the last chunk did not use then takes L_jj for the solve, X for the diagonal update and D for potf2.
-    // ~79 KB in all, so a 128-tile GEMM work-group of a concurrent trailing update still fits on the CU.
+    // one the last chunk did not use then takes L_jj for the solve and X for the diagonal update; a third holds D
+    // (below).  114 KB in all: the work-group holds all 512 registers of its SIMDs' lane slices anyway, so no other
+    // work-group can share the CU and there is nobody to leave LDS for.
     double* sT0 = smem;
     double* sT1 = smem + PB * S64_LS;
     double* sXT = smem + 2 * PB * S64_LS;             // potf2's multiplier copy

@@ -255,8 +255,8 @@ int potrf_panel_update(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
 
 // Look-ahead schedule: the trailing update of panel p is split into the columns of panel p+1
 // (done first, on the main stream) and the rest; panel p+1 is then factored on a high-priority
-// side stream WHILE the rest of update p runs on the main stream.  The persistent panel kernel keeps
-// its LDS under 80 KB so that one 128-tile work-group of the update still fits on each of its CUs.
+// side stream WHILE the rest of update p runs on the main stream.  (A panel work-group holds a whole CU -- 512
+// registers per lane -- so update work-groups run on the CUs the panel kernel leaves.)
 // Measured gain ~6 % of the factorisation: the pivot chain is fp64-VALU latency-bound and slows down
 // (clocks, shared FP64 pipes) while the update runs; CU masks (hipExtStreamCreateWithCUMask) and
 // single-occupancy GEMM variants were measured and made it worse.
