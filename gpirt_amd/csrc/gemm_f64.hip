@@ -691,6 +691,12 @@ int gemm_split_count(gpirt_handle_t h, hipStream_t stream, int tri, int64_t M, i
     return split >= 2 ? (int)split : 1;
 }
 
+static int t128_min_or_default()
+{
+    static const int v = getenv("GPIRT_T128_MIN") ? atoi(getenv("GPIRT_T128_MIN")) : 448;
+    return v;
+}
+
 int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri, int64_t M,
                 int64_t N, int64_t K, double alpha, const double* A, int64_t lda, const double* B,
                 int64_t ldb, double beta, double* C, int64_t ldc, int64_t Mread)
@@ -726,8 +732,11 @@ int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri,
     // 128-tiles when they already give every CU >= 2 work-groups, 64-tiles otherwise
     const int64_t mb = (M + 127) / 128, nb = (N + 127) / 128;
     int64_t blocks128 = (tri == TRI_SYRK_LOWER) ? nb * mb - nb * (nb - 1) / 2 : mb * nb;
-    if (tri == TRI_A_LOWER || tri == TRI_A_UPPER) blocks128 *= 2;     // paired: one work-group per CU suffices
-    static const int t128_min = getenv("GPIRT_T128_MIN") ? atoi(getenv("GPIRT_T128_MIN")) : 448;
+    // triangular A: the work-groups take block rows in pairs (long + short K range), so there are mb * nb / 2 of them,
+    // each with the full K range -- 128-tiles only when those pairs fill the chip (8192 x 1024: 256 of them; 8192 x 512,
+    // the per-rank shape on two GPUs, has 128 and ran as long as 8192 x 1024: 1043 us instead of 540 with 64-tiles)
+    if (tri == TRI_A_LOWER || tri == TRI_A_UPPER) blocks128 = (blocks128 / 2 >= 224) ? t128_min_or_default() : 0;
+    const int t128_min = t128_min_or_default();
     if (blocks128 >= t128_min) return launch_gemm_t<128>(stream, ta, tb, p);
     // Few tiles and a long K: a lone work-group per CU runs its K loop at LDS / barrier latency (~1.1 us per
     // K-step against 0.43 us of MFMA), so the K range is cut into `split` parts computed side by side and added

@@ -165,10 +165,15 @@ int do_draw_f(gpirt_sampler_s* s)
     const int64_t n = s->n, m = s->m;
     const uint32_t iter = (uint32_t)(s->iter + 1);
     if (!stream_mode(s)) {
+        const bool prep = s->haux && s->ext > 0 && !s->ext_grid && s->rows_valid && !s->prep_valid;
+        // With few item columns on this rank (m <= 128: eight GPUs at the metric size) the product below does not
+        // fill the chip and the slice kernel is short, so the side work starts at once -- beside the fill and the product
+        // as well; with all 1024 columns it waits for the product (whose 256 work-groups would starve it).
+        const bool early = prep && m <= 128;
+        if (early) GP_HIP(hipEventRecord(s->ev_trmm, st));
         GP_TRY(launch_item_uniforms(st, s->opt.seed, iter, GPIRT_ST_F_Z, (uint32_t)s->opt.item0, m, n, s->Z, true));
         GP_TRY(launch_gemm(h, st, false, false, TRI_A_LOWER, n, m, n, 1.0, s->L, s->ldl, s->Z, n, 0.0, s->NU, n));
-        const bool prep = s->haux && s->ext > 0 && !s->ext_grid && s->rows_valid && !s->prep_valid;
-        if (prep) GP_HIP(hipEventRecord(s->ev_trmm, st));
+        if (prep && !early) GP_HIP(hipEventRecord(s->ev_trmm, st));
         EssArgs a{};
         a.f = s->f; a.nu = s->NU; a.y = s->y; a.mu = s->mu; a.n = n; a.m = m; a.k_out = s->ess_k;
         a.err = s->flags; a.seed = s->opt.seed; a.iter = iter; a.item0 = (uint32_t)s->opt.item0;
