@@ -447,6 +447,15 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int bi, con
     if (p.tri == TRI_A_LOWER) kend = min(p.K, bi * T + T);
     if (p.tri == TRI_A_UPPER) kbeg = ((bi * T) / BK) * BK;
     if (p.ksplit > 0) { kbeg = (int)blockIdx.y * p.ksplit; kend = min(p.K, kbeg + p.ksplit); }
+    if (p.ksplit < 0) {
+        // triangular A with few work-groups: blockIdx.y takes one of -ksplit equal parts of THIS tile's K range
+        // (an empty part writes zeros into its partial result)
+        const int S = -p.ksplit;
+        const int part = (((kend - kbeg + S - 1) / S) + BK - 1) / BK * BK;
+        kbeg += (int)blockIdx.y * part;
+        kend = min(kend, kbeg + part);
+        if (kend < kbeg) kend = kbeg;
+    }
     d4 acc[NT][NT];
 #pragma unroll
     for (int a = 0; a < NT; ++a)
@@ -738,6 +747,33 @@ int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri,
     if (tri == TRI_A_LOWER || tri == TRI_A_UPPER) blocks128 = (blocks128 / 2 >= 224) ? t128_min_or_default() : 0;
     const int t128_min = t128_min_or_default();
     if (blocks128 >= t128_min) return launch_gemm_t<128>(stream, ta, tb, p);
+    // Triangular A and few column tiles (nu = L z for the item columns of one rank of several): the paired work-groups
+    // -- each with the full K range -- do not fill the chip (8192 x 128: 128 of them, 290 us).  The K range of every
+    // tile is cut into S parts computed side by side and added in a fixed order, like the split below.
+    if ((tri == TRI_A_LOWER || tri == TRI_A_UPPER) && h != nullptr && stream == h->stream && K >= 1024) {
+        static const bool tri_split_on = !(getenv("GPIRT_SPLITK") && atoi(getenv("GPIRT_SPLITK")) == 2);
+        const int64_t pairs = (((M + 63) / 64 + 1) / 2) * ((N + 63) / 64);
+        int S = (int)(384 / (pairs > 0 ? pairs : 1));
+        if (S > 4) S = 4;
+        if (tri_split_on && S >= 2) {
+            const size_t need = (size_t)S * (size_t)M * (size_t)N * sizeof(double);
+            if (h->splitk_bytes < need) {
+                GP_HIP(hipStreamSynchronize(stream));
+                if (h->side) GP_HIP(hipStreamSynchronize(h->side));
+                if (h->d_splitk) GP_HIP(hipFree(h->d_splitk));
+                h->d_splitk = nullptr; h->splitk_bytes = 0;
+                GP_HIP(hipMalloc(&h->d_splitk, need));
+                h->splitk_bytes = need;
+            }
+            GemmParams q = p;
+            q.C = h->d_splitk; q.ldc = M; q.sC = M * N; q.beta = 0.0; q.ksplit = -S;
+            GP_TRY(launch_gemm_t<64>(stream, ta, tb, q, S));
+            hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, stream, h->d_splitk, M, N,
+                               M * N, S, beta, C, ldc);
+            GP_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     // Few tiles and a long K: a lone work-group per CU runs its K loop at LDS / barrier latency (~1.1 us per
     // K-step against 0.43 us of MFMA), so the K range is cut into `split` parts computed side by side and added
     // in a fixed order (GPIRT_SPLITK=2 switches it off).  Main stream only: the parts share one workspace.
