@@ -98,6 +98,7 @@ SIGNATURES = {
     "gpirt_sampler_draw_beta": (_i32, [_vp]),
     "gpirt_sampler_factor": (_i32, [_vp]),
     "gpirt_sampler_skip_factor": (_i32, [_vp]),
+    "gpirt_sampler_adopt_factor": (_i32, [_vp, _i32]),
     "gpirt_sampler_build_cov": (_i32, [_vp]),
     "gpirt_sampler_panel_factor": (_i32, [_vp, _i64]),
     "gpirt_sampler_panel_update": (_i32, [_vp, _i64, _i64]),

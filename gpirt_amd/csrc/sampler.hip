@@ -215,8 +215,8 @@ int fstar_prep(gpirt_sampler_s* s, gpirt_handle_t hh)
     double* Cu = s->rhs + (size_t)n * r;
     const double* Bt = s->L + n;
     GP_TRY(launch_transpose(st, Bt, r, n, s->ldl, Cu, n));
-    // the block inverses of L are reused when this handle already holds them (built panel by panel behind the
-    // factorisation, do_factor; or by an earlier call) -- invalidate_factor_products() clears that whenever L changes
+    // the block inverses of L are reused when this handle already holds them (built by an earlier solve against the
+    // same factor) -- invalidate_factor_products() clears that whenever L changes
     GP_TRY(launch_trsm_lower(hh, st, s->L, n, s->ldl, Cu, r, n, true, true));
     return launch_gemm_splitk(st, false, true, r, r, n, 1.0, Bt, s->ldl, Bt, s->ldl, s->kparts, r, (int64_t)r * r, KSPLIT,
                               s->kP, r, 0.0);
@@ -740,14 +740,21 @@ int gpirt_sampler_build_cov(gpirt_sampler_t s)
     return build_cov(s);                                                                                   // :76-77
 }
 
-int gpirt_sampler_skip_factor(gpirt_sampler_t s)
+// L arrived from elsewhere (a broadcast, the distributed pieces, gpirt_sampler_set): closes the iteration without
+// factoring.  rows_with_L says whether the rows below the n x n factor (bordered layout, gpirt_sampler_ldl) arrived
+// with it -- the WHOLE ldl x n buffer was received, as gpirt_amd/distributed.py does.  If not (a host that moved only
+// the n x n factor), they still belong to the previous (theta, L) and are rebuilt by the explicit forward solve before
+// draw_fstar reads them.
+int gpirt_sampler_adopt_factor(gpirt_sampler_t s, int rows_with_L)
 {
     GP_ARG(s && s->initialised);
-    invalidate_factor_products(s);       // L arrived from elsewhere (broadcast / distributed pieces), its rows with it
-    s->rows_valid = true;
+    invalidate_factor_products(s);
+    s->rows_valid = rows_with_L != 0;
     s->iter += 1;
     return 0;
 }
+
+int gpirt_sampler_skip_factor(gpirt_sampler_t s) { return gpirt_sampler_adopt_factor(s, 0); }
 
 int gpirt_sampler_step(gpirt_sampler_t s)
 {

@@ -371,33 +371,29 @@ int trsm_inverses_reserve(gpirt_handle_t h, hipStream_t stream, int64_t n, int64
     return 0;
 }
 
-// Inverses of L's diagonal blocks for the 512-block pairs [p0, p1) (p = index of a 512 x 512 diagonal block; the odd
-// 256-row block behind the last pair rides with the last range), into h->d_trsm_winv / d_trsm_wquad:
+// Inverses of ALL of L's 512 x 512 diagonal blocks (the odd 256-row block behind the last pair included), into
+// h->d_trsm_winv / d_trsm_wquad:
 //  1. the full 256 x 256 diagonal blocks: ONE batched launch of the fused leaf on identity right-hand sides
 //     (4 work-groups per block), written straight into the diagonal quarters of the 512 x 512 slots;
 //  2. the lower-left quarter of each slot,  -W2 (L21 W1),  as two batched 256^3 MFMA products;
 //  3. thin solves (few right-hand sides are launch-bound, not flop-bound): pairs of 512-blocks merged into 1024 x 1024
 //     inverses (two more batched products), which halves the leaves and drops a recursion level.
-// A range only reads the diagonal blocks it inverts, so the ranges of a factor can be built as its outer panels finish
-// (the sampler does, on its own stream, while the factorisation is still running).  p0 must be even when `thin`.
-int trsm_inverses_build(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t n, int64_t ldl, bool thin,
-                        int64_t p0, int64_t p1)
+// (Building them panel by panel behind the factorisation was measured in round 2 and dropped -- the backward solve
+// starts with the LAST diagonal block -- so there is no partial-range form.)
+int trsm_inverses_build(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t n, int64_t ldl, bool thin)
 {
     const int64_t nfull = n / NL4, npair = nfull / 2;
-    if (p1 > npair) p1 = npair;
-    if (p0 >= p1 && !(p1 == npair && (nfull & 1))) return 0;
+    if (nfull == 0) return 0;
     double* W = h->d_trsm_winv;
-    // 256-blocks 2 p0 .. 2 p1 - 1 (+ the odd one when this range closes the matrix)
-    const int64_t b0 = 2 * p0, b1 = (p1 == npair) ? nfull : 2 * p1;
-    if (b1 > b0)
-        hipLaunchKernelGGL((trsm_leaf256_kernel<false, true>), dim3(NL4 / CB, (unsigned)(b1 - b0)), dim3(256), 0, stream,
-                           L + b0 * (int64_t)NL4 * (ldl + 1), ldl, NL4, W + p0 * (int64_t)NI * NI, (int64_t)NI, (int64_t)NL4,
+    // every full 256-block (the odd one behind the last pair included)
+    hipLaunchKernelGGL((trsm_leaf256_kernel<false, true>), dim3(NL4 / CB, (unsigned)nfull), dim3(256), 0, stream,
+                           L, ldl, NL4, W, (int64_t)NI, (int64_t)NL4,
                            (long long*)nullptr, (int64_t)NL4 * (ldl + 1), (int64_t)NI * NI, (int64_t)NL4 * (NI + 1));
-    const int np = (int)(p1 - p0);
+    const int np = (int)npair;
     if (np > 0) {
-        const double* Lp = L + p0 * (int64_t)NI * (ldl + 1);
-        double* Wp = W + p0 * (int64_t)NI * NI;
-        double* Tp = h->d_trsm_tmp + p0 * (int64_t)NL4 * NL4;
+        const double* Lp = L;
+        double* Wp = W;
+        double* Tp = h->d_trsm_tmp;
         // T_b = L21 W1
         GP_TRY(launch_gemm_batched(stream, false, false, TRI_NONE, NL4, NL4, NL4, 1.0,
                                    Lp + NL4, ldl, (int64_t)NI * (ldl + 1), Wp, NI, (int64_t)NI * NI,
@@ -408,7 +404,7 @@ int trsm_inverses_build(gpirt_handle_t h, hipStream_t stream, const double* L, i
                                    (int64_t)NL4 * NL4, 0.0, Wp + NL4, NI, (int64_t)NI * NI, np));
     }
     if (thin && npair >= 2) {
-        const int64_t q0 = p0 / 2, q1 = (p1 / 2 < npair / 2) ? p1 / 2 : npair / 2;
+        const int64_t q0 = 0, q1 = npair / 2;
         const int nq = (int)(q1 - q0);
         if (nq > 0) {
             double* Wq = h->d_trsm_wquad + q0 * (int64_t)NQ * NQ;
@@ -429,21 +425,16 @@ int trsm_inverses_build(gpirt_handle_t h, hipStream_t stream, const double* L, i
     return 0;
 }
 
-void trsm_inverses_mark(gpirt_handle_t h, const double* L, int64_t n, int64_t ldl, bool thin)
-{
-    const int64_t npair = (n / NL4) / 2;
-    h->trsm_winv_L = L; h->trsm_winv_n = n; h->trsm_winv_ld = ldl;
-    h->trsm_quads = (thin && npair >= 2) ? npair / 2 : 0;
-}
-
 // reuse_inverses: the block inverses built by the previous call on this handle are still those of L (same L,
 // n and ldl, not modified since) -- the sampler's second solve of a draw_fstar skips rebuilding them.
 int launch_trsm_lower(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t n, int64_t ldl,
                       double* B, int64_t nrhs, int64_t ldb, bool trans, bool reuse_inverses)
 {
     if (n <= 0 || nrhs <= 0) return 0;
-    // GPIRT_TRSM_INV=2 keeps every leaf a substitution
-    static const bool use_inv = !(getenv("GPIRT_TRSM_INV") && atoi(getenv("GPIRT_TRSM_INV")) == 2);
+    // GPIRT_TRSM_INV=2 keeps every leaf a substitution (read per call: tests/test_gpu_configs.py switches it inside one
+    // process to price the block inverses against LAPACK)
+    const char* inv_env = getenv("GPIRT_TRSM_INV");
+    const bool use_inv = !(inv_env && atoi(inv_env) == 2);
     const double* winv = nullptr;
     const int64_t nfull = n / NL4, npair = nfull / 2;
     const bool odd = (nfull & 1) != 0;
@@ -453,7 +444,7 @@ int launch_trsm_lower(gpirt_handle_t h, hipStream_t stream, const double* L, int
         winv = h->d_trsm_winv;
     } else if (use_inv && nfull >= 2 && nrhs >= 64) {
         GP_TRY(trsm_inverses_reserve(h, stream, n, nrhs, thin));
-        GP_TRY(trsm_inverses_build(h, stream, L, n, ldl, thin, 0, npair));
+        GP_TRY(trsm_inverses_build(h, stream, L, n, ldl, thin));
         winv = h->d_trsm_winv;
         h->trsm_winv_L = L; h->trsm_winv_n = n; h->trsm_winv_ld = ldl;
         h->trsm_quads = (thin && npair >= 2) ? npair / 2 : 0;

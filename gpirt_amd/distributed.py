@@ -136,7 +136,7 @@ class ShardedSampler:
         # the last panel has nothing to update: it only has to reach everybody
         if NP > 1:
             receive(NP - 1, send(NP - 1))
-        e.skip_factor()
+        e.adopt_factor(True)                        # the panel copies carry the rows below the factor too (panel_rows)
 
     def _factor(self):
         if self.chol == "distributed" and self.world > 1:
@@ -147,7 +147,7 @@ class ShardedSampler:
             if self.rank == 0:
                 self.engine.factor()
             else:
-                self.engine.skip_factor()
+                self.engine.adopt_factor(True)      # the "L" view is the WHOLE ldl x n buffer: the bordered rows travel too
             self.dist.broadcast(self._view("L"), src=0)
 
     def init(self):

@@ -158,6 +158,11 @@ class Sampler:
     def draw_beta(self): self._call("gpirt_sampler_draw_beta")
     def factor(self): self._call("gpirt_sampler_factor")
     def skip_factor(self): self._call("gpirt_sampler_skip_factor")
+
+    def adopt_factor(self, rows_with_L: bool):
+        """L arrived from elsewhere; rows_with_L: the whole ldl x n buffer (the bordered rows too) was received."""
+        rc = self.lib.gpirt_sampler_adopt_factor(self._s, int(bool(rows_with_L)))
+        check(rc)
     def build_cov(self): self._call("gpirt_sampler_build_cov")
 
     # -- the factorisation in pieces (distributed hosts, include/gpirt_hip.h "gpirt_potrf_panel_*"), on "L" in place

@@ -192,6 +192,10 @@ typedef struct gpirt_options {
                                * right-hand sides instead of 1001 + m; 0 = every grid column is solved */
 } gpirt_options;
 
+/* The reference's contract: GPIRT_RNG_RSTREAM (draw-for-draw replay of R's stream), draw_theta and draw_fstar as
+ * written.  NOTE: these defaults REQUIRE an R stream -- gpirt_sampler_create / gpirt_mcmc called with opts == NULL
+ * (or with unmodified defaults) and rs == NULL fail with GPIRT_E_ARG ("GPIRT_RNG_RSTREAM needs an R stream state");
+ * a host without R's RNG state sets rng_kind = GPIRT_RNG_ITEM (and a seed) explicitly. */
 void gpirt_default_options(gpirt_options* o);
 
 /* Whole-call drop-in for .gpirtMCMC (src/gpirtMCMC.cpp:5-117), all pointers HOST:
@@ -244,7 +248,12 @@ int gpirt_sampler_panel_factor(gpirt_sampler_t s, int64_t p);
 int gpirt_sampler_panel_update(gpirt_sampler_t s, int64_t p, int64_t c);
 int gpirt_sampler_panel_copy(gpirt_sampler_t s, int64_t p, double* d_buf, int to_buf);
 int gpirt_sampler_panel_rows(gpirt_sampler_t s, int64_t* rows);
-/* closes the iteration WITHOUT factoring: for ranks that receive L by broadcast ("L" devptr) */
+/* Close the iteration WITHOUT factoring: "L" arrived from elsewhere (a broadcast into the "L" devptr, the distributed
+ * pieces, gpirt_sampler_set).  rows_with_L != 0: the rows below the n x n factor (gpirt_sampler_ldl) arrived with it,
+ * i.e. the whole ldl x n buffer was received; 0: only the n x n factor is current and the rows are rebuilt by the
+ * explicit forward solve (src/draw-fstar.cpp:19) before draw_fstar reads them.  gpirt_sampler_skip_factor(s) is
+ * gpirt_sampler_adopt_factor(s, 0), the form that is safe for any host. */
+int gpirt_sampler_adopt_factor(gpirt_sampler_t s, int rows_with_L);
 int gpirt_sampler_skip_factor(gpirt_sampler_t s);
 int gpirt_sampler_accumulate_irf(gpirt_sampler_t s);     /* :103 */
 int gpirt_sampler_iteration(gpirt_sampler_t s, int* iter);

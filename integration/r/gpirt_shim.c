@@ -11,6 +11,7 @@
  *     PKG_CPPFLAGS = -I<repo>/include      PKG_LIBS = -L<repo>/gpirt_amd -lgpirt_hip
  */
 #include <R.h>
+#include <string.h>
 #include <Rinternals.h>
 #include <R_ext/Random.h>
 #include <R_ext/Rdynload.h>

@@ -357,25 +357,32 @@ void orc_trsm_lower(const double* L, int64_t n, double* B, int64_t nrhs, int tra
     }
 }
 
-/* src/draw-fstar.cpp:10-31 (quirk Q2: s = 1 - sqrt(q)) */
-void orc_draw_fstar(orc_rng* r, uint32_t iter, const double* f, const double* theta,
-                    const double* theta_star, const double* L, const double* mu_star,
-                    int64_t n, int64_t m, int64_t N, double* out, double* s_out, double* mean_out)
+/* src/draw-fstar.cpp:17-20, the part that does not depend on the item: kstar = K(theta, theta_star) (n x N),
+ * tmp = solve(trimatl(L), kstar), s = 1 - sqrt(colsum(tmp^2)) (quirk Q2).  theta_star may be any slice of the grid
+ * (the columns are independent), which is how the all-core parity driver (tests/_oracle_parallel.py) spreads it. */
+void orc_fstar_grid(const double* theta, const double* theta_star, const double* L, int64_t n, int64_t N,
+                    double* kstar_out, double* tmp_out, double* s_out)
 {
-    double* kstar = (double*)malloc(sizeof(double) * (size_t)(n * N));
-    double* tmp   = (double*)malloc(sizeof(double) * (size_t)(n * N));
-    double* s     = (double*)malloc(sizeof(double) * (size_t)N);
-    double* alpha = (double*)malloc(sizeof(double) * (size_t)n);
-    orc_se_kernel(theta, n, theta_star, N, kstar);                 /* :17 */
-    memcpy(tmp, kstar, sizeof(double) * (size_t)(n * N));
+    double* tmp = tmp_out ? tmp_out : (double*)malloc(sizeof(double) * (size_t)(n * N));
+    orc_se_kernel(theta, n, theta_star, N, kstar_out);             /* :17 */
+    memcpy(tmp, kstar_out, sizeof(double) * (size_t)(n * N));
     orc_trsm_lower(L, n, tmp, N, 0);                               /* :19 */
     for (int64_t i = 0; i < N; ++i) {                              /* :20 */
         double q = 0.0;
         const double* t = tmp + i * n;
         for (int64_t k = 0; k < n; ++k) q += t[k] * t[k];
-        s[i] = 1.0 - sqrt(q);
+        s_out[i] = 1.0 - sqrt(q);
     }
-    if (s_out) memcpy(s_out, s, sizeof(double) * (size_t)N);
+    if (!tmp_out) free(tmp);
+}
+
+/* src/draw-fstar.cpp:23-29, the loop over items, given kstar (n x N) and s (N) from orc_fstar_grid.
+ * Items are keyed (iter, ORC_ST_FSTAR, item_base + j): a slice of the items gives the same draws as the whole loop. */
+void orc_fstar_items(orc_rng* r, uint32_t iter, const double* f, const double* kstar, const double* s,
+                     const double* L, const double* mu_star, int64_t n, int64_t m, int64_t N,
+                     double* out, double* mean_out)
+{
+    double* alpha = (double*)malloc(sizeof(double) * (size_t)n);
     for (int64_t j = 0; j < m; ++j) {                              /* :23-29 */
         memcpy(alpha, f + j * n, sizeof(double) * (size_t)n);
         orc_trsm_lower(L, n, alpha, 1, 0);                         /* :24 -> :7 */
@@ -391,7 +398,20 @@ void orc_draw_fstar(orc_rng* r, uint32_t iter, const double* f, const double* th
             out[i + j * N] = orc_rnorm(r, mean, s[i]);             /* :27 */
         }
     }
-    free(kstar); free(tmp); free(s); free(alpha);
+    free(alpha);
+}
+
+/* src/draw-fstar.cpp:10-31 (quirk Q2: s = 1 - sqrt(q)) */
+void orc_draw_fstar(orc_rng* r, uint32_t iter, const double* f, const double* theta,
+                    const double* theta_star, const double* L, const double* mu_star,
+                    int64_t n, int64_t m, int64_t N, double* out, double* s_out, double* mean_out)
+{
+    double* kstar = (double*)malloc(sizeof(double) * (size_t)(n * N));
+    double* s     = (double*)malloc(sizeof(double) * (size_t)N);
+    orc_fstar_grid(theta, theta_star, L, n, N, kstar, NULL, s);    /* :17-20 */
+    if (s_out) memcpy(s_out, s, sizeof(double) * (size_t)N);
+    orc_fstar_items(r, iter, f, kstar, s, L, mu_star, n, m, N, out, mean_out);   /* :23-29 */
+    free(kstar); free(s);
 }
 
 /* Same stage with the algebraically identical form mean = (L^-1 kstar)^T (L^-1 f) + mu_star,
@@ -432,6 +452,15 @@ int orc_draw_theta(orc_rng* r, uint32_t iter, const double* theta_star, const do
                    const double* theta_prior, const double* fstar, int64_t n, int64_t m,
                    int64_t N, int stabilise, double* theta_out)
 {
+    return orc_draw_theta_block(r, iter, theta_star, y, theta_prior, fstar, n, m, N, stabilise, 0, theta_out);
+}
+
+/* the same loop for a block of respondents: y holds rows i0 .. i0 + n - 1 (n x m, leading dimension n), the uniform of
+ * local respondent i is keyed by its global index i0 + i (item RNG), so blocks reproduce the whole loop's draws */
+int orc_draw_theta_block(orc_rng* r, uint32_t iter, const double* theta_star, const double* y,
+                         const double* theta_prior, const double* fstar, int64_t n, int64_t m,
+                         int64_t N, int stabilise, int64_t i0, double* theta_out)
+{
     double* P = (double*)malloc(sizeof(double) * (size_t)N);
     int degenerate = 0;
     for (int64_t i = 0; i < n; ++i) {
@@ -456,7 +485,7 @@ int orc_draw_theta(orc_rng* r, uint32_t iter, const double* theta_star, const do
         double max_p = P[0], min_p = P[0];                           /* :23-24 */
         for (int64_t k = 1; k < N; ++k) { if (P[k] > max_p) max_p = P[k]; if (P[k] < min_p) min_p = P[k]; }
         for (int64_t k = 0; k < N; ++k) P[k] = (P[k] - min_p) / (max_p - min_p); /* :25 */
-        orc_rng_substream(r, iter, ORC_ST_THETA, (uint32_t)i);
+        orc_rng_substream(r, iter, ORC_ST_THETA, (uint32_t)(i0 + i));
         double u = orc_runif(r, 0.0, 1.0);                           /* :27 */
         double res = NAN;   /* reference: theta_star[N] (out of bounds, UB); we return NaN */
         int found = 0;

@@ -105,12 +105,25 @@ void orc_draw_fstar(orc_rng* r, uint32_t iter, const double* f, const double* th
                     const double* theta_star, const double* L, const double* mu_star,
                     int64_t n, int64_t m, int64_t N, double* out, double* s_out, double* mean_out);
 
+/* The two halves of draw_fstar() separately (the all-core parity driver spreads grid columns and items over threads):
+ * :17-20 for any slice of the grid (kstar_out n x N required, tmp_out optional), and :23-29 for any slice of items.   */
+void orc_fstar_grid(const double* theta, const double* theta_star, const double* L, int64_t n, int64_t N,
+                    double* kstar_out, double* tmp_out, double* s_out);
+void orc_fstar_items(orc_rng* r, uint32_t iter, const double* f, const double* kstar, const double* s,
+                     const double* L, const double* mu_star, int64_t n, int64_t m, int64_t N,
+                     double* out, double* mean_out);
+
 /* draw_theta(): src/draw-theta.cpp:3-37.  stabilise!=0 subtracts the row maximum before exp
  * (identical up to rounding wherever the reference is defined).  Returns the
  * number of respondents whose CDF degenerated (reference would read theta_star[N], UB).      */
 int  orc_draw_theta(orc_rng* r, uint32_t iter, const double* theta_star, const double* y,
                     const double* theta_prior, const double* fstar, int64_t n, int64_t m,
                     int64_t N, int stabilise, double* theta_out);
+
+/* ... for the block of respondents i0 .. i0 + n - 1 (y n x m holds just those rows): same draws as the whole loop */
+int  orc_draw_theta_block(orc_rng* r, uint32_t iter, const double* theta_star, const double* y,
+                          const double* theta_prior, const double* fstar, int64_t n, int64_t m,
+                          int64_t N, int stabilise, int64_t i0, double* theta_out);
 
 /* draw_beta(): src/draw-beta.cpp:3-41.  X = [1, theta].                                      */
 void orc_draw_beta(orc_rng* r, uint32_t iter, const double* beta, const double* theta,

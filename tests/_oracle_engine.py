@@ -132,6 +132,9 @@ class OracleEngine:
     def skip_factor(self):
         self.it += 1
 
+    def adopt_factor(self, rows_with_L):
+        self.it += 1
+
     # -- the factorisation in pieces (gpirt_potrf_panel_* / gpirt_sampler_build_cov), NumPy, small panels ----------
     panel_width = 16
     torch_device = torch.device("cpu")

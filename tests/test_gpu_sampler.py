@@ -359,3 +359,52 @@ def test_copy_state_and_set_theta_rebuild_the_border_rows(handle, form):
     b.draw_fstar(); b.check()
     assert np.abs(b.get("fstar") - fa).max() <= 1e-9 * max(1.0, np.abs(fa).max())
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("n,kw", [(1024, dict(fstar_fused=False)), (1024, dict(fstar_fused=True)),
+                                  (320, dict(fstar_fused=True, kstar_rank=64))])
+def test_factor_set_from_outside_rebuilds_the_bordered_rows(handle, n, kw):
+    """A C-API host that moves only the n x n factor (gpirt_sampler_set("L") / a broadcast of n x n) and then calls
+    gpirt_sampler_skip_factor must NOT see the rows below L of the previous (theta, L) re-validated: draw_fstar has to
+    rebuild them by the explicit solve.  (Round-2 advisor finding: skip_factor forced rows_valid.)"""
+    from gpirt_amd import Sampler
+    from gpirt_amd.synthetic import make_responses
+    m = 6
+    y, th0 = make_responses(n, m, seed=31)
+    ref = Sampler(handle, y, th0, rng="item", seed=9, **kw)
+    ref.init(); ref.step(); ref.check()                 # theta_1, L_1 = chol(K(theta_1)), rows valid
+    tst = Sampler(handle, y, th0, rng="item", seed=9, **kw)
+    tst.init()                                          # its rows belong to (theta_0, L_0)
+    for name in ("theta", "f", "beta", "mu", "mu_star"):
+        tst.set(name, ref.get(name))
+    tst.set("L", ref.get("L"))                          # the n x n factor only
+    tst.skip_factor()                                   # closes iteration 1 without factoring
+    assert tst.iteration == ref.iteration == 1
+    ref.draw_fstar(); tst.draw_fstar()
+    ref.check(); tst.check()
+    fs_ref, fs = ref.get("fstar"), tst.get("fstar")
+    assert np.isfinite(fs).all()
+    assert np.abs(fs - fs_ref).max() <= 1e-9 * max(1.0, np.abs(fs_ref).max())
+    assert np.abs(tst.get("s") - ref.get("s")).max() <= 1e-9
+    ref.close(); tst.close()
+
+
+def test_null_options_need_an_r_stream(handle):
+    """include/gpirt_hip.h: the default options are the reference's contract (R-stream replay), so a NULL options
+    pointer without an R stream state is an argument error with a message that says so."""
+    import ctypes as C
+    from gpirt_amd import _lib
+    lib = _lib.load()
+    dp = C.POINTER(C.c_double)
+    y = np.asfortranarray(np.where(np.arange(32).reshape(8, 4) % 3 == 0, 1.0, -1.0))
+    th = np.zeros(8)
+    p = np.asfortranarray(np.full((2, 4), 0.5))
+    s = C.c_void_p()
+    rc = lib.gpirt_sampler_create(C.byref(s), handle.ptr, y.ctypes.data_as(dp), 8, 4, th.ctypes.data_as(dp),
+                                  p.ctypes.data_as(dp), p.ctypes.data_as(dp), p.ctypes.data_as(dp), None, None)
+    assert rc == _lib.E_ARG and "R stream" in _lib.last_error()
+    out = [np.zeros(sh, order="F") for sh in ((2, 8), (2, 4, 2), (8, 4, 2), (1001, 4))]
+    rc = lib.gpirt_mcmc(y.ctypes.data_as(dp), 8, 4, th.ctypes.data_as(dp), 1, 0, p.ctypes.data_as(dp),
+                        p.ctypes.data_as(dp), p.ctypes.data_as(dp), None, None, _lib.TICK_FN(0), None,
+                        *[o.ctypes.data_as(dp) for o in out])
+    assert rc == _lib.E_ARG and "R stream" in _lib.last_error()
