@@ -174,6 +174,13 @@ int gpirt_destroy(gpirt_handle_t h)
     if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->ev_mid) hipEventDestroy(h->ev_mid);
     if (h->ev_a) hipEventDestroy(h->ev_a);
+    if (h->ev_half) hipEventDestroy(h->ev_half);
+    if (h->rows_stream) hipStreamDestroy(h->rows_stream);
+    if (h->near_stream) hipStreamDestroy(h->near_stream);
+    if (h->chainb_stream) hipStreamDestroy(h->chainb_stream);
+    if (h->d_ready) hipFree(h->d_ready);
+    if (h->d_chain_ws) hipFree(h->d_chain_ws);
+    for (auto& e : h->ev_pool) if (e) hipEventDestroy(e);
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
     return 0;

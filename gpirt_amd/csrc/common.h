@@ -69,10 +69,18 @@ struct gpirt_handle_s {
     gpirt::Prof  prof;
     // look-ahead Cholesky: high-priority side stream for the panel chain + fork/join events
     hipStream_t  side = nullptr;
-    hipEvent_t   ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr, ev_a = nullptr;
+    hipEvent_t   ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr, ev_a = nullptr, ev_half = nullptr;
     // persistent panel kernel (panel.hip): one progress counter per 64-row block, epoch-tagged
     unsigned long long* d_prog = nullptr;
     double*      d_winv = nullptr;        // panel.hip: inverses of the diagonal blocks' 16 x 16 blocks, handed along the pivot chain
+    int64_t      winv_blocks = 0;         //   ... one 4 x 256 slot per 64-column block of the matrix
+    hipStream_t  rows_stream = nullptr;   // potrf.hip (windowed schedule): the rows far below the chain launches + their updates
+    hipStream_t  near_stream = nullptr;   //   ... and the rows of the NEXT outer panel (what the chain needs next)
+    hipStream_t  chainb_stream = nullptr; //   ... second sub-panels' chain launches (pre-launched beside the first sub-panel's)
+    unsigned long long* d_ready = nullptr;//   ... [2] ready flags of the pre-launched chain launches (first / second sub-panel)
+    double*      d_chain_ws = nullptr;    //   ... split-K parts of the small updates on the chain (4 x 1024 x 1024 doubles)
+    int          win_state = 0;           //   ... 0 = not probed, 1 = streams on separate hardware queues (usable), 2 = not usable
+    hipEvent_t   ev_pool[16] = {};        //   ... and the cross-stream events
     size_t       prog_cap = 0;
     unsigned long long prog_seq = 0;
     long long*   panel_trace = nullptr;   // debug stamps (micro-benchmarks only)

@@ -597,6 +597,86 @@ int launch_gemm_update_potf2(hipStream_t stream, int64_t M, int64_t N, int64_t K
     return 0;
 }
 
+// Rectangular piece of a factorisation update (windowed schedule, potrf.hip): C (M x N) = beta C + alpha A B^T with the
+// same PAD = 8 instantiations as the syrk launches (one kernel name per tile size in traces and PMC profiles), never split
+// over K: per element the same sum in the same order as the syrk launch that used to cover these rows.
+bool gemm_rect_uses_128(int64_t M, int64_t N)
+{
+    static const int bmin = getenv("GPIRT_BG128_MIN") ? atoi(getenv("GPIRT_BG128_MIN")) : 448;
+    return ((M + 127) / 128) * ((N + 127) / 128) >= bmin;
+}
+
+int launch_gemm_nosplit(hipStream_t stream, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
+                        int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc)
+{
+    if (M <= 0 || N <= 0) return 0;
+    if (ta || !tb) { set_error("launch_gemm_nosplit: NT form only"); return GPIRT_E_ARG; }
+    GemmParams p;
+    p.A = A; p.B = B; p.C = C;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.M = (int)M; p.N = (int)N; p.K = (int)K; p.Mr = 0;
+    p.alpha = alpha; p.beta = beta; p.tri = TRI_NONE;
+    p.fz_A = nullptr; p.fz_lda = 0; p.fz_nb = 0; p.fz_k0 = 0; p.fz_info = nullptr;
+    p.sA = p.sB = p.sC = 0; p.ksplit = 0;
+    p.fastA = (((uintptr_t)A & 15) == 0) && (lda % 2 == 0);
+    p.fastB = (((uintptr_t)B & 15) == 0) && (ldb % 2 == 0);
+    if (gemm_rect_uses_128(M, N)) {
+        p.mblocks = (p.M + 127) / 128; p.nblocks = (p.N + 127) / 128;
+        hipLaunchKernelGGL((gemm_f64_kernel<false, true, 128, 8>), dim3((unsigned)((int64_t)p.mblocks * p.nblocks)), dim3(256), 0, stream, p);
+    } else {
+        p.mblocks = (p.M + 63) / 64; p.nblocks = (p.N + 63) / 64;
+        hipLaunchKernelGGL((gemm_f64_kernel<false, true, 64, 8>), dim3((unsigned)((int64_t)p.mblocks * p.nblocks)), dim3(256), 0, stream, p);
+    }
+    GP_HIP(hipGetLastError());
+    return 0;
+}
+
+// Small updates ON THE PIVOT CHAIN of the windowed factorisation (the K = 512 update of a 512 x 512 diagonal triangle, the
+// K = 1024 update of the next 1024 x 1024 diagonal trapezoid): 36 / 136 tiles with 32 / 64 dependent K-steps each run at the
+// latency of a lone work-group per CU (52 / 82 us measured).  Here the K range is cut into `nsplit` parts computed side by
+// side into `work` (nsplit slabs of M x N, ldc = M) and added to C in a FIXED order: the lower trapezoid
+// C[r, c] (r >= c) = beta C + sum_q part_q.  Deterministic; rounding differs from the unsplit launch in the last bits,
+// so every schedule of the factorisation (and its pieces) sends these same regions through here.
+__global__ __launch_bounds__(256) void sum_parts_lower_kernel(const double* __restrict__ part, int64_t M, int64_t N, int64_t stride,
+                                                              int nparts, double beta, double* __restrict__ out, int64_t ldo)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * N) return;
+    const int64_t r = i % M, c = i / M;
+    if (r < c) return;
+    double acc = 0.0;
+    for (int q = 0; q < nparts; ++q) acc += part[i + q * stride];
+    double* o = out + r + c * ldo;
+    *o = (beta != 0.0) ? beta * (*o) + acc : acc;
+}
+
+int launch_syrk_splitk(hipStream_t stream, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
+                       const double* B, int64_t ldb, double beta, double* C, int64_t ldc, double* work, int nsplit)
+{
+    if (M <= 0 || N <= 0) return 0;
+    if (M < N || nsplit < 1) { set_error("launch_syrk_splitk: needs M >= N"); return GPIRT_E_ARG; }
+    constexpr int T = 64;
+    GemmParams p;
+    p.A = A; p.B = B; p.C = work;
+    p.lda = lda; p.ldb = ldb; p.ldc = M;
+    p.M = (int)M; p.N = (int)N; p.K = (int)K; p.Mr = 0;
+    p.alpha = alpha; p.beta = 0.0; p.tri = TRI_SYRK_LOWER;
+    p.fz_A = nullptr; p.fz_lda = 0; p.fz_nb = 0; p.fz_k0 = 0; p.fz_info = nullptr;
+    p.sA = p.sB = 0; p.sC = M * N;
+    p.ksplit = (int)((((K + nsplit - 1) / nsplit) + BK - 1) / BK * BK);
+    const int parts = (int)((K + p.ksplit - 1) / p.ksplit);
+    p.fastA = (((uintptr_t)A & 15) == 0) && (lda % 2 == 0);
+    p.fastB = (((uintptr_t)B & 15) == 0) && (ldb % 2 == 0);
+    p.mblocks = (p.M + T - 1) / T;
+    p.nblocks = (p.N + T - 1) / T;
+    const int64_t grid = (int64_t)p.nblocks * p.mblocks - (int64_t)p.nblocks * (p.nblocks - 1) / 2;
+    hipLaunchKernelGGL((gemm_f64_kernel<false, true, 64, 8>), dim3((unsigned)grid, (unsigned)parts), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(sum_parts_lower_kernel, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, stream, work, M, N, M * N, parts,
+                       beta, C, ldc);
+    GP_HIP(hipGetLastError());
+    return 0;
+}
+
 bool gemm_trailing_uses_128(int64_t M, int64_t N, bool background)
 {
     static const int tmin = getenv("GPIRT_TRAIL128_MIN") ? atoi(getenv("GPIRT_TRAIL128_MIN")) : 448;

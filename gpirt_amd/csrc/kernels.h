@@ -22,6 +22,12 @@ int launch_gemm_batched(hipStream_t stream, bool ta, bool tb, int tri, int64_t M
                         const double* A, int64_t lda, int64_t strideA, const double* B, int64_t ldb, int64_t strideB,
                         double beta, double* C, int64_t ldc, int64_t strideC, int batch);
 
+bool gemm_rect_uses_128(int64_t M, int64_t N);
+int launch_gemm_nosplit(hipStream_t stream, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
+                        int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc);
+// lower trapezoid C (M x N, M >= N) = beta C + alpha A B^T with the K range cut into nsplit parts (work: nsplit * M * N doubles)
+int launch_syrk_splitk(hipStream_t stream, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
+                       const double* B, int64_t ldb, double beta, double* C, int64_t ldc, double* work, int nsplit);
 int gemm_split_count(gpirt_handle_t h, hipStream_t stream, int tri, int64_t M, int64_t N, int64_t K);
 // split-K product for small M x N with long K: parts land in Cpart (+ q * strideC, each M x N with ldc == M),
 // then Cout (ldout) = beta_out * Cout + their sum
@@ -49,7 +55,15 @@ int potrf_panel_copy(hipStream_t stream, double* A, int64_t n, int64_t lda, int6
                      int64_t extra_rows = 0);
 
 // panel.hip: columns [K0, c1) of the Cholesky factor, all rows below, one persistent kernel
-int launch_panel_ll(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t K0, int64_t c1);
+int launch_panel_ll(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t K0, int64_t c1,
+                    int64_t row_end = 0, unsigned long long* epoch_out = nullptr, const unsigned long long* ready = nullptr);
+// ready != nullptr: a PRE launch -- resident at once, starts its sweep when *ready reaches the launch's own epoch
+// (launch_flag_store(stream, ready, epoch) behind the kernel that produces its input)
+int launch_flag_store(hipStream_t stream, unsigned long long* flag, unsigned long long value);
+int panel_queue_probe(hipStream_t spin_stream, hipStream_t set_stream, unsigned long long* flag, int* d_result, int* ok);
+// the rows [r0, r1) a restricted launch_panel_ll left out, against its counters (epoch): beside it or after it
+int launch_panel_rows(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t K0, int64_t c1,
+                      int64_t r0, int64_t r1, unsigned long long epoch, bool lean = true);
 
 // trsm.hip
 int launch_trsm_lower(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t n, int64_t ldl,

@@ -223,6 +223,252 @@ int trailing(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t
 }
 
 
+// Panel [K0, c1)'s update of the NEXT panel's block column [lo, hi) -- the update the pivot chain waits for.  Its first
+// sub-panel's columns [lo, lo + nbp) receive the panel as TWO products of depth nbp (the panel's first sub-panel, then
+// the rest) instead of one of depth c1 - K0: the first half does not need the panel's second sub-panel, so the look-ahead
+// schedule applies it while that sub-panel is still being factored (first_half_done) and only K = 512 of the update is
+// left on the chain.  The rule is the same wherever this block column is updated (with or without look-ahead, in the
+// distributed pieces), so L does not depend on the schedule.  Columns [lo + nbp, hi) take the panel in one product.
+//   part: 1 = the first sub-panel's columns only (what the chain waits for), 2 = the others, 3 = both
+int crit_update(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t K0, int64_t c1, int64_t lo,
+                int64_t hi, int64_t nbp, bool first_half_done, int part)
+{
+    const int64_t a_hi = (lo + nbp < hi) ? lo + nbp : hi;          // the next panel's first sub-panel
+    const int64_t kmid = K0 + nbp;                                 // end of this panel's first sub-panel
+    if (part & 1) {
+        if (kmid < c1) {
+            if (!first_half_done) GP_TRY(trailing(h, stream, A, n, lda, K0, kmid, lo, a_hi));
+            GP_TRY(trailing(h, stream, A, n, lda, kmid, c1, lo, a_hi));
+        } else {
+            GP_TRY(trailing(h, stream, A, n, lda, K0, c1, lo, a_hi));
+        }
+    }
+    if ((part & 2) && a_hi < hi) GP_TRY(trailing(h, stream, A, n, lda, K0, c1, a_hi, hi));
+    return 0;
+}
+
+int64_t potrf_subpanel_width()
+{
+    const int64_t v = (env_int("GPIRT_NBP", NBP) / NBI) * NBI;
+    return v > 0 ? v : NBP;
+}
+
+
+}  // namespace
+
+
+// ---- the windowed schedule (round 3, GPIRT_SCHED=2) ------------------------------------------------------------------
+// What the pivot chain needs next is never more than the rows of the outer panel being factored and of the one behind
+// it; everything further down only has to be ready one outer panel later.  So a sub-panel is no longer ONE kernel over
+// all rows, gated by an update of all rows (the schedule below: ~100-170 us of full-chip update + a 165-280 us kernel,
+// 16 times in a row).  Per outer panel p = columns [c1, c2), sub-panels A = [c1, cA) and B = [cA, c2), five streams:
+//   chain A (high prio)  chainA: panel_ll_kernel on the rows [c1, c2) only (16 work-groups); midW: the K = 512 update of
+//                        B's diagonal triangle (split over K: a lone tile per CU runs its K loop at latency); flag B.
+//   chain B (high prio)  chainB (8 work-groups).  Both chain launches are PRE launches: enqueued one step ahead, resident
+//                        on their compute units while they wait for their input flag -- a panel work-group needs a WHOLE
+//                        CU and, launched when its input is ready, waits for the updates beside it to drain (measured:
+//                        165 us kernels stretched to 375-515 us).
+//   near (high prio)     the rows [c2, c3) of the NEXT outer panel: panel_rows_kernel beside chainA / chainB (lean 32-row
+//                        work-groups consuming the chain launches' counters), the K = 512 update between them; then updW
+//                        -- panel p's K = 1024 update of the next panel's 1024 x 1024 diagonal trapezoid (split over K) --
+//                        and flag A; then updN: panel p's update of the rows [c3, c4) of block column p + 1.
+//   rows                 the same for the rest of the rows [c3, nr), then updR (rows below c4 of block column p + 1).
+//   main                 the deferred trailing updates (block column p + 2 <- panels 0 .. p, as under GPIRT_DEFER=3).
+// Every element of the matrix still receives the same products in the same order -- K = 512 inside an outer panel,
+// K = 1024 per earlier panel in ascending order, the left-looking sums of the panel kernels -- except the two split-K
+// regions, whose parts are added in a fixed order.  Deadlock freedom: a launch that may spin on counters (near / rows) is
+// enqueued after the chain launch it consumes and never fills the chip (launch_panel_rows); a PRE launch waits for a flag
+// whose producer sits on ANOTHER hardware queue (probed once per handle, win_setup; otherwise the schedule is not used)
+// and depends only on work enqueued before it or on streams that never wait for the chain launches.
+namespace {
+
+struct WinStreams { hipStream_t chainA, chainB, near, rows, main; };
+
+int win_setup(gpirt_handle_t h)
+{
+    if (h->win_state != 0) return 0;
+    int lo_pri = 0, hi_pri = 0;
+    GP_HIP(hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
+    if (!h->side) {
+        GP_HIP(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, hi_pri));
+        GP_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        GP_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        GP_HIP(hipEventCreateWithFlags(&h->ev_mid, hipEventDisableTiming));
+        GP_HIP(hipEventCreateWithFlags(&h->ev_a, hipEventDisableTiming));
+    }
+    GP_HIP(hipStreamCreateWithPriority(&h->chainb_stream, hipStreamNonBlocking, hi_pri));
+    GP_HIP(hipStreamCreateWithPriority(&h->near_stream, hipStreamNonBlocking, hi_pri));
+    GP_HIP(hipStreamCreateWithFlags(&h->rows_stream, hipStreamNonBlocking));
+    for (auto& e : h->ev_pool) GP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    GP_HIP(hipMalloc(&h->d_ready, 4 * sizeof(unsigned long long)));
+    GP_HIP(hipMalloc(&h->d_chain_ws, (size_t)4 * 1024 * 1024 * sizeof(double)));
+    GP_HIP(hipMemsetAsync(h->d_ready, 0, 4 * sizeof(unsigned long long), h->side));
+    GP_HIP(hipStreamSynchronize(h->side));
+    // the PRE launches spin on chain A / chain B for flags raised from chain A / near, and what raises them waits for
+    // events of rows / main: a spinner must not sit in front of any of those in a shared hardware queue
+    int ok = 1, r = 0;
+    int* d_res = reinterpret_cast<int*>(h->d_ready + 2);
+    hipStream_t spin[2] = { h->side, h->chainb_stream };
+    hipStream_t others[4] = { h->near_stream, h->rows_stream, h->stream, nullptr };
+    for (int a = 0; a < 2 && ok; ++a) {
+        others[3] = spin[1 - a];
+        for (int b = 0; b < 4 && ok; ++b) {
+            GP_TRY(panel_queue_probe(spin[a], others[b], h->d_ready, d_res, &r));
+            ok = ok && r;
+        }
+    }
+    h->win_state = ok ? 1 : 2;
+    return 0;
+}
+
+// C[rows r0..r1, cols lo..hi] -= A[rows, K0..c1] A[lo..hi, K0..c1]^T : the lower trapezoid when the row range starts at lo
+// (syrk mode), a full rectangle when it lies below the column range.  inpanel: the K = 512 update inside an outer panel
+// (profiling class 2), otherwise a K = 1024 trailing update (class 0 / 1 by tile).  splitk: the small trapezoids on the
+// pivot chain (launch_syrk_splitk).
+int win_update(gpirt_handle_t h, hipStream_t st, double* A, int64_t lda, int64_t K0, int64_t c1, int64_t r0, int64_t r1,
+               int64_t lo, int64_t hi, bool inpanel, bool splitk = false)
+{
+    const int64_t M = r1 - r0, N = hi - lo, K = c1 - K0;
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    ProfPair pp;
+    GP_TRY(prof_begin(h, st, pp));
+    const double* P = A + r0 + K0 * lda;
+    const double* Q = A + lo + K0 * lda;
+    if (r0 == lo) {
+        static const int nsplit = env_int("GPIRT_CHAIN_SPLITK", 4);
+        if (splitk && nsplit > 1 && M <= 1024 && N <= 1024 && K >= 256) {
+            GP_TRY(launch_syrk_splitk(st, M, N, K, -1.0, P, lda, Q, lda, 1.0, A + r0 + lo * lda, lda, h->d_chain_ws, nsplit > 4 ? 4 : nsplit));
+            return prof_end(h, st, pp, inpanel ? 2 : 1, M, N, K);
+        }
+        GP_TRY(launch_gemm(h, st, false, true, inpanel ? TRI_SYRK_LOWER : TRI_SYRK_LOWER_BACKGROUND, M, N, K, -1.0, P, lda, Q, lda,
+                           1.0, A + r0 + lo * lda, lda));
+        return prof_end(h, st, pp, inpanel ? 2 : (gemm_trailing_uses_128(M, N, true) ? 0 : 1), M, N, K);
+    }
+    if (r0 < hi) { set_error("windowed update: row range cuts the column range"); return GPIRT_E_ARG; }
+    GP_TRY(launch_gemm_nosplit(st, false, true, M, N, K, -1.0, P, lda, Q, lda, 1.0, A + r0 + lo * lda, lda));
+    if (!pp.e0) return 0;
+    GP_HIP(hipEventRecord(pp.e1, st));
+    pp.flops = 2.0 * (double)M * (double)N * (double)K;
+    pp.bytes = 8.0 * (2.0 * (double)M * (double)N + (double)(M + N) * (double)K);
+    pp.cls = inpanel ? 2 : (gemm_rect_uses_128(M, N) ? 0 : 1);
+    h->prof.pending.push_back(pp);
+    return 0;
+}
+
+int potrf_windowed(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t nr, int64_t nbo, int64_t nbp)
+{
+    WinStreams S{ h->side, h->chainb_stream, h->near_stream, h->rows_stream, stream };
+    hipEvent_t* E = h->ev_pool;
+    enum { E_CA = 0, E_CB = 2, E_NB = 4, E_RB = 6, E_DEF = 8, E_MW = 10, E_UW = 11 };   // [+ parity of p]
+    unsigned long long* readyA = h->d_ready;
+    unsigned long long* readyB = h->d_ready + 1;
+    static const bool pre = !(getenv("GPIRT_WIN_PRE") && atoi(getenv("GPIRT_WIN_PRE")) == 0);
+    GP_HIP(hipEventRecord(h->ev_fork, stream));
+    GP_HIP(hipStreamWaitEvent(S.chainA, h->ev_fork, 0));
+    GP_HIP(hipStreamWaitEvent(S.chainB, h->ev_fork, 0));
+    GP_HIP(hipStreamWaitEvent(S.near, h->ev_fork, 0));
+    GP_HIP(hipStreamWaitEvent(S.rows, h->ev_fork, 0));
+    const int64_t P = (n + nbo - 1) / nbo;
+    std::vector<int64_t> done_col((size_t)P, 0);      // columns < done_col[q] carry panel q's update (deferred updates)
+    unsigned long long eA = 0, eB = 0, eA_next = 0;
+    // chain launch of the first sub-panel: its input is the matrix itself
+    GP_TRY(launch_panel_ll(h, S.chainA, A, nr, lda, 0, nbp < n ? nbp : n, nbo < nr ? (nbo < n ? nbo : n) : 0, &eA_next, nullptr));
+    for (int64_t p = 0; p < P; ++p) {
+        const int b = (int)(p & 1), bp = b ^ 1;
+        const int64_t c1 = p * nbo, c2 = (c1 + nbo < n) ? c1 + nbo : n;
+        const int64_t cA = (c1 + nbp < c2) ? c1 + nbp : c2;
+        const int64_t c3 = (c2 < n) ? ((c2 + nbo < n) ? c2 + nbo : n) : c2;     // end of the next outer panel's rows
+        const int64_t c4 = (c3 < n) ? ((c3 + nbo < n) ? c3 + nbo : n) : c3;
+        const bool has_b = cA < c2;
+        const bool last = c2 >= n;
+        eA = eA_next;                                   // chainA(p) is already enqueued (above, or by the previous step)
+        // ---- chain A: [chainA(p) enqueued earlier] -> E_CA -> midW -> flag B ;  chain B: chainB(p), PRE
+        GP_HIP(hipEventRecord(E[E_CA + b], S.chainA));
+        if (has_b) {
+            if (pre) {
+                GP_TRY(launch_panel_ll(h, S.chainB, A, nr, lda, cA, c2, c2 < nr ? c2 : 0, &eB, readyB));
+                GP_TRY(win_update(h, S.chainA, A, lda, c1, cA, cA, c2, cA, c2, true, true));
+                GP_TRY(launch_flag_store(S.chainA, readyB, eB));
+            } else {                                     // (GPIRT_WIN_PRE=0: ordinary launches ordered by events)
+                GP_TRY(win_update(h, S.chainA, A, lda, c1, cA, cA, c2, cA, c2, true, true));
+                GP_HIP(hipEventRecord(E[E_MW], S.chainA));
+                GP_HIP(hipStreamWaitEvent(S.chainB, E[E_MW], 0));
+                GP_TRY(launch_panel_ll(h, S.chainB, A, nr, lda, cA, c2, c2 < nr ? c2 : 0, &eB, nullptr));
+            }
+        } else {
+            GP_HIP(hipStreamWaitEvent(S.chainB, E[E_CA + b], 0));     // E_CB always implies E_CA
+        }
+        GP_HIP(hipEventRecord(E[E_CB + b], S.chainB));
+        // the NEXT outer panel's first chain launch goes out now (PRE): resident while chainB(p) runs
+        const int64_t nx1 = c2, nx2 = c3, nxA = (nx1 + nbp < nx2) ? nx1 + nbp : nx2;
+        if (!last && pre) GP_TRY(launch_panel_ll(h, S.chainA, A, nr, lda, nx1, nxA, nx2 < nr ? nx2 : 0, &eA_next, readyA));
+        // ---- near: the next outer panel's rows [c2, c3), in step with the chain launches
+        if (c3 > c2) {
+            GP_TRY(launch_panel_rows(h, S.near, A, nr, lda, c1, cA, c2, c3, eA));
+            if (has_b) {
+                GP_HIP(hipStreamWaitEvent(S.near, E[E_CA + b], 0));
+                GP_TRY(win_update(h, S.near, A, lda, c1, cA, c2, c3, cA, c2, true));
+                GP_TRY(launch_panel_rows(h, S.near, A, nr, lda, cA, c2, c2, c3, eB));
+            }
+        }
+        GP_HIP(hipEventRecord(E[E_NB + b], S.near));
+        // ---- rows: everything below
+        if (nr > c3) {
+            GP_TRY(launch_panel_rows(h, S.rows, A, nr, lda, c1, cA, c3, nr, eA));
+            if (has_b) {
+                GP_HIP(hipStreamWaitEvent(S.rows, E[E_CA + b], 0));
+                GP_TRY(win_update(h, S.rows, A, lda, c1, cA, c3, nr, cA, c2, true));
+                GP_TRY(launch_panel_rows(h, S.rows, A, nr, lda, cA, c2, c3, nr, eB));
+            }
+        }
+        GP_HIP(hipEventRecord(E[E_RB + b], S.rows));
+        if (last) {                                      // last outer panel: nothing left to update
+            GP_HIP(hipStreamWaitEvent(stream, E[E_CB + b], 0));
+            GP_HIP(hipStreamWaitEvent(stream, E[E_NB + b], 0));
+            GP_HIP(hipStreamWaitEvent(stream, E[E_RB + b], 0));
+            break;
+        }
+        // ---- panel p's update of block column p + 1 = [c2, c3), nearest rows first.  The block column already carries
+        // the panels q < p (deferred updates of the previous step: E_DEF of the other parity).
+        const bool have_def = p >= 1;
+        // near: the trapezoid on the diagonal (needs the rows [c2, c3) of panel p: this stream) -> flag A
+        if (have_def) GP_HIP(hipStreamWaitEvent(S.near, E[E_DEF + bp], 0));
+        GP_TRY(win_update(h, S.near, A, lda, c1, c2, c2, c3, c2, c3, false, true));
+        if (pre) {
+            GP_TRY(launch_flag_store(S.near, readyA, eA_next));
+        } else {
+            GP_HIP(hipEventRecord(E[E_UW], S.near));
+            GP_HIP(hipStreamWaitEvent(S.chainA, E[E_UW], 0));
+            GP_TRY(launch_panel_ll(h, S.chainA, A, nr, lda, nx1, nxA, nx2 < nr ? nx2 : 0, &eA_next, nullptr));
+        }
+        // near: the rows [c3, c4) -- needs them of panel p (rows stream)
+        if (c4 > c3) {
+            GP_HIP(hipStreamWaitEvent(S.near, E[E_RB + b], 0));
+            GP_TRY(win_update(h, S.near, A, lda, c1, c2, c3, c4, c2, c3, false));
+        }
+        // rows: the rest -- needs the rows [c2, c3) of panel p (near)
+        if (nr > c4) {
+            GP_HIP(hipStreamWaitEvent(S.rows, E[E_NB + b], 0));
+            if (have_def) GP_HIP(hipStreamWaitEvent(S.rows, E[E_DEF + bp], 0));
+            GP_TRY(win_update(h, S.rows, A, lda, c1, c2, c4, nr, c2, c3, false));
+        }
+        // ---- main: block column p + 2 = [c3, c4) receives the panels 0 .. p in ascending order; the panels q < p need
+        // nothing of this step and go first (work for the chip while the chain runs), panel p waits for its rows
+        done_col[(size_t)p] = c3;
+        if (c4 > c3) {
+            for (int64_t q = 0; q <= p; ++q) {
+                if (done_col[(size_t)q] >= c4) continue;
+                if (q == p) GP_HIP(hipStreamWaitEvent(stream, E[E_RB + b], 0));
+                const int64_t lo = done_col[(size_t)q];
+                GP_TRY(trailing(h, stream, A, nr, lda, q * nbo, (q + 1) * nbo, lo, c4, nullptr, true));
+                done_col[(size_t)q] = c4;
+            }
+        }
+        GP_HIP(hipEventRecord(E[E_DEF + b], stream));
+    }
+    return 0;
+}
+
 }  // namespace
 
 // ---- the factorisation in pieces, for a host that distributes it (gpirt_amd/distributed.py) ----------
@@ -250,7 +496,10 @@ int potrf_panel_update(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
 {
     const int64_t W = potrf_panel_width(), K0 = p * W, lo = c * W;
     if (p < 0 || c <= p || lo >= n) { set_error("panel update (%lld -> %lld) out of range", (long long)p, (long long)c); return GPIRT_E_ARG; }
-    return trailing(h, stream, A, n + extra_rows, lda, K0, K0 + W, lo, (lo + W < n) ? lo + W : n);
+    const int64_t hi = (lo + W < n) ? lo + W : n;
+    if (c == p + 1 && panel_persistent())       // the next panel's block column: the same products as launch_potrf_lower
+        return crit_update(h, stream, A, n + extra_rows, lda, K0, K0 + W, lo, hi, potrf_subpanel_width(), false, 3);
+    return trailing(h, stream, A, n + extra_rows, lda, K0, K0 + W, lo, hi);
 }
 
 // Look-ahead schedule: the trailing update of panel p is split into the columns of panel p+1
@@ -274,6 +523,23 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
     const int64_t nbo = (nbo_env / NBI) * NBI > 0 ? (nbo_env / NBI) * NBI : NBO;
     if (reset_info) GP_HIP(hipMemsetAsync(h->d_info, 0, sizeof(int), stream));
     const bool la = (lookahead == 1) && (n > 2 * nbo);
+    {
+        // GPIRT_SCHED: 2 = the windowed schedule (chain / near / rows / main streams), 1 = one sub-panel kernel over all rows
+        const char* sv = getenv("GPIRT_SCHED");
+        const int sched = (sv && *sv) ? atoi(sv) : 1;
+        const int64_t nbp_w = (env_int("GPIRT_NBP", NBP) / NBI) * NBI > 0 ? (env_int("GPIRT_NBP", NBP) / NBI) * NBI : NBP;
+        const bool cols_on = !(getenv("GPIRT_PANEL_COLS") && atoi(getenv("GPIRT_PANEL_COLS")) == 0);
+        if (sched == 2 && la && panel_persistent() && cols_on && (nbo % NBI) == 0) GP_TRY(win_setup(h));
+        if (sched == 2 && la && panel_persistent() && cols_on && (nbo % NBI) == 0 && h->win_state == 1) {
+            GP_TRY(potrf_windowed(h, stream, A, n, lda, nr, nbo, nbp_w));
+            if (zero_upper) {
+                hipLaunchKernelGGL(zero_upper_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256),
+                                   0, stream, A, n, lda);
+            }
+            GP_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     if (la && !h->side) {
         int lo_pri = 0, hi_pri = 0;
         GP_HIP(hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
@@ -303,6 +569,11 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
     static const int defer_env = env_int("GPIRT_DEFER", 0);  // 3: one launch per panel and block column, 2: off, 1: fused; 0: by size
     const int defer = defer_env ? defer_env : (n <= 14336 ? 3 : 2);
     std::vector<int64_t> done_col;                   // (mode 3) columns < done_col[q] carry panel q's update
+    // GPIRT_HALF_AHEAD=2 switches the early half of the chain-critical update off (the products stay the same: the two
+    // halves are then applied back to back when the chain needs them)
+    static const bool half_ahead = !(getenv("GPIRT_HALF_AHEAD") && atoi(getenv("GPIRT_HALF_AHEAD")) == 2);
+    bool half_done = false;                          // the next crit_update's first half is already in
+    if (la && !h->ev_half) GP_HIP(hipEventCreateWithFlags(&h->ev_half, hipEventDisableTiming));
     GP_TRY(factor_panel(h, stream, A, nr, lda, 0, nbo < n ? nbo : n));
     for (int64_t K0 = 0; K0 < n; K0 += nbo) {
         const int64_t c1 = (K0 + nbo < n) ? K0 + nbo : n;
@@ -312,7 +583,13 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
         // with persistent sub-panels and look-ahead, only the first sub-panel's columns gate the side stream
         const int64_t cA = (c1 + nbp_la < c2) ? c1 + nbp_la : c2;
         const bool split = la && c2 < n && panel_persistent() && cA < c2;
-        GP_TRY(trailing(h, stream, A, nr, lda, K0, c1, c1, split ? cA : c2, split ? nullptr : &diag_done));
+        if (panel_persistent()) {
+            // (the first sub-panel's columns first: part 1; the others follow behind the fork when `split`)
+            GP_TRY(crit_update(h, stream, A, nr, lda, K0, c1, c1, c2, nbp_la, half_done, split ? 1 : 3));
+            half_done = false;
+        } else {
+            GP_TRY(trailing(h, stream, A, nr, lda, K0, c1, c1, split ? cA : c2, split ? nullptr : &diag_done));
+        }
         if (la && c2 < n) {
             GP_HIP(hipEventRecord(h->ev_fork, stream));
             GP_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
@@ -320,7 +597,9 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
                 // the side stream starts on the first sub-panel as soon as ITS columns are up to date; the
                 // other columns of the outer panel are brought up to date behind it on the main stream
                 GP_TRY(factor_panel(h, h->side, A, nr, lda, c1, cA));
-                GP_TRY(trailing(h, stream, A, nr, lda, K0, c1, cA, c2));
+                if (half_ahead) GP_HIP(hipEventRecord(h->ev_half, h->side));
+                if (panel_persistent()) GP_TRY(crit_update(h, stream, A, nr, lda, K0, c1, c1, c2, nbp_la, false, 2));
+                else GP_TRY(trailing(h, stream, A, nr, lda, K0, c1, cA, c2));
                 GP_HIP(hipEventRecord(h->ev_mid, stream));
                 GP_HIP(hipStreamWaitEvent(h->side, h->ev_mid, 0));
                 GP_TRY(panel_update(h, h->side, nr - cA, c2 - cA, cA - c1, A + cA + c1 * lda, lda, A + cA + cA * lda, lda));
@@ -354,6 +633,15 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
                     }
             } else {
                 GP_TRY(trailing(h, stream, A, nr, lda, K0, c1, c2, n));    // the rest, concurrently
+            }
+            if (split && half_ahead && panel_persistent() && cA - c1 == nbp_la && defer != 1) {
+                // the first sub-panel of the panel being factored on the side stream is final: its half of the NEXT
+                // step's chain-critical update goes out now, behind this step's other updates of that block column
+                // (ascending panel order), beside the second sub-panel's kernel
+                const int64_t a_hi = (c2 + nbp_la < n) ? c2 + nbp_la : n;
+                GP_HIP(hipStreamWaitEvent(stream, h->ev_half, 0));
+                GP_TRY(trailing(h, stream, A, nr, lda, c1, cA, c2, a_hi, nullptr, true));
+                half_done = true;
             }
             GP_HIP(hipEventRecord(h->ev_join, h->side));
             GP_HIP(hipStreamWaitEvent(stream, h->ev_join, 0));

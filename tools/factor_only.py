@@ -1,3 +1,5 @@
+"""A few factorisations of K(theta, theta) + jitter at n (default 8192): the target of rocprofv3 traces (tools/trace_factor.sh).
+GPIRT_SCHED etc. are read by the library."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
