@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgpirt_hip.so")
+# GPIRT_HIP_LIBRARY: test hook -- another build of the same library (tests/test_gpu_fences.py loads the fenced variant)
+LIB_PATH = os.environ.get("GPIRT_HIP_LIBRARY") or os.path.join(HERE, "libgpirt_hip.so")
 
 NGRID = 1001
 RNG_RSTREAM, RNG_ITEM = 0, 1

@@ -19,5 +19,11 @@ def build(force: bool = False, jobs: int = 8) -> str:
     return LIB
 
 
+def build_fences(jobs: int = 8) -> str:
+    """The fenced variant of the panel kernel's hand-off (test-only second library, csrc/Makefile `fences`)."""
+    subprocess.check_call(["make", "-C", CSRC, f"-j{jobs}", "-s", "fences"])
+    return os.path.join(HERE, "libgpirt_hip_fences.so")
+
+
 if __name__ == "__main__":
     print(build())

@@ -10,6 +10,14 @@
 // private results included) and no acquire (buffer_inv: it empties the XCD's L2 for all 16 work-groups sharing it,
 // twice per step each) -- measured in round 2: 216 -> ... us per 512-column sub-panel.
 //
+// "One work-group per CU" in the guide's table is the regime the form was MEASURED in.  panel_ll_kernel meets it for
+// its own work-groups (114 KB of LDS each); foreign work-groups that fit beside one (no LDS to speak of, <= 152 registers) do
+// not change the argument, because it never relied on the CU's L1: every load of a handed-off byte is an sc1 load (served
+// past the L1) and every such byte was stored sc1 (written through, dropped from the producer's L2).  panel_rows_kernel
+// (two or three work-groups per CU, beside update work-groups) is a CONSUMER only, of the same sc1 bytes, and is outside
+// the measured regime: it is opt-in (GPIRT_SCHED=2 / GPIRT_ROWS=1) and checked bit for bit against the one-launch factor.
+// The fenced form (-DGPIRT_PANEL_FENCES, `make fences`) is built and compared bit for bit by tests/test_gpu_fences.py.
+//
 // Rules that keep such kernels safe on this hardware:
 //   * a work-group only ever waits for work-groups with a SMALLER block index (dispatched earlier), and the
 //     awaited result is always produced before its producer waits for anything itself;

@@ -90,6 +90,10 @@ __device__ __forceinline__ double ldg_sc1(const double* sbase, uint32_t voff)
                              __HIP_MEMORY_SCOPE_AGENT);
 #endif
 }
+// OWN ROWS ONLY: a plain store stays in this XCD's L2 until the kernel ends, so the bytes may be re-read by the storing
+// work-group alone (its X[R, k] operands of later steps) -- never by another work-group of this launch or of a launch
+// running beside it; whatever a neighbour reads goes through stg_off.  (tests/test_panel_isa.py counts the plain and the
+// sc1 accesses of every kernel in this file against a committed census, so a new plain access does not slip in unseen.)
 __device__ __forceinline__ void stg_plain(double* sbase, uint32_t voff, double x)
 {
     *reinterpret_cast<double*>(reinterpret_cast<char*>(sbase) + voff) = x;
@@ -172,7 +176,7 @@ __device__ __forceinline__ void load_strip(d4 (&X)[4], const double* A, int64_t 
                 const int c = 16 * J + 4 * g + r;
                 const bool ok = live && c < ncols;
                 const double x = FRESH ? ldg_sc1(A + row0 + rc + (col0 + (c < ncols ? c : 0)) * lda, 0u)
-                                       : A[row0 + rc + (col0 + (c < ncols ? c : 0)) * lda];
+                                       : ldg_off(A + row0 + rc + (col0 + (c < ncols ? c : 0)) * lda, 0u);
                 X[J][r] = ok ? x : 0.0;
             }
     }
@@ -248,8 +252,11 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
     extern __shared__ __attribute__((aligned(16))) double smem[];
     // Two 64 x 64 buffers (34 KB each): the "other" GEMM operand alternates between them, and whichever
     // one the last chunk did not use then takes L_jj for the solve and X for the diagonal update; a third holds D
-    // (below).  114 KB in all: the work-group holds all 512 registers of its SIMDs' lane slices anyway, so no other
-    // work-group can share the CU and there is nobody to leave LDS for.
+    // (below).  114 KB in all, so two of these work-groups never share a CU (160 KB).  The kernel runs at 360 registers per
+    // lane (<true>; 422 <false>), not the full 512: a small foreign work-group (<= 46 KB of LDS, <= 152 registers -- a
+    // split-K sum, a copy-back, a flag store) CAN sit beside it.  That does not touch the hand-off protocol: no handed-off
+    // byte is ever read through the CU's L1 or expected in this XCD's L2 (every such store and load is sc1, flagsync.h), so
+    // what a co-resident work-group may have left in L1 cannot be observed; exclusivity only matters for speed.
     double* sT0 = smem;
     double* sT1 = smem + PB * S64_LS;
     double* sXT = smem + 2 * PB * S64_LS;             // potf2's multiplier copy
@@ -284,6 +291,9 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
         }
         __syncthreads();
         if (s_seen == 0) return;
+#ifdef GPIRT_PANEL_FENCES
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
         __syncthreads();
     }
 

@@ -164,9 +164,28 @@ int factor_panel(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int
         // sub-panels of NBP columns with an MFMA update of the remaining columns in between
         static const int nbp_env = env_int("GPIRT_NBP", NBP);
         const int64_t nbp = (nbp_env / NBI) * NBI > 0 ? (nbp_env / NBI) * NBI : NBP;
+        // GPIRT_ROWS=1: the sub-panel in two launches -- the persistent kernel on the diagonal owners and the `lean_win` rows
+        // below them (whole CUs), panel_rows_kernel (32-row work-groups that SHARE CUs with the updates) on the rest,
+        // beside it on a helper stream; same counters, same arithmetic, L bit-identical (panel.hip)
+        static const int lean_rows = env_int("GPIRT_ROWS", 0);
+        static const int lean_win = env_int("GPIRT_ROWS_WINDOW", 512);
         for (int64_t k0 = K0; k0 < c1; k0 += nbp) {
             const int64_t k1 = (k0 + nbp < c1) ? k0 + nbp : c1;
-            GP_TRY(launch_panel_ll(h, stream, A, n, lda, k0, k1));
+            const int64_t wend = k1 + ((int64_t)lean_win / NBI) * NBI;
+            if (lean_rows == 1 && (k1 - k0) % NBI == 0 && wend + 2048 <= n && (wend % NBI) == 0) {
+                if (!h->rows_stream) GP_HIP(hipStreamCreateWithFlags(&h->rows_stream, hipStreamNonBlocking));
+                for (int e = 12; e < 14; ++e)
+                    if (!h->ev_pool[e]) GP_HIP(hipEventCreateWithFlags(&h->ev_pool[e], hipEventDisableTiming));
+                unsigned long long epoch = 0;
+                GP_HIP(hipEventRecord(h->ev_pool[12], stream));
+                GP_HIP(hipStreamWaitEvent(h->rows_stream, h->ev_pool[12], 0));
+                GP_TRY(launch_panel_ll(h, stream, A, n, lda, k0, k1, wend, &epoch));
+                GP_TRY(launch_panel_rows(h, h->rows_stream, A, n, lda, k0, k1, wend, n, epoch));
+                GP_HIP(hipEventRecord(h->ev_pool[13], h->rows_stream));
+                GP_HIP(hipStreamWaitEvent(stream, h->ev_pool[13], 0));
+            } else {
+                GP_TRY(launch_panel_ll(h, stream, A, n, lda, k0, k1));
+            }
             if (k1 < c1)      // A[k1:n, k1:c1] -= A[k1:n, k0:k1] A[k1:c1, k0:k1]^T
                 GP_TRY(panel_update(h, stream, n - k1, c1 - k1, k1 - k0, A + k1 + k0 * lda, lda, A + k1 + k1 * lda, lda));
         }
