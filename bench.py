@@ -209,6 +209,12 @@ def main():
         stage_ms = cur if not stage_ms else {k: min(stage_ms[k], cur[k]) for k in cur}
     ss.engine.check()
     stage_ms = {k: round(v, 3) for k, v in stage_ms.items()}
+    # every rank's stage times in rank 0's line: a first multi-GPU run is then diagnosable from one log (a slow rank, a
+    # collective that waits, the Cholesky mode in use)
+    stage_ms_per_rank = None
+    if world > 1:
+        stage_ms_per_rank = [None] * world
+        dist.all_gather_object(stage_ms_per_rank, stage_ms)        # a few hundred bytes, outside every timed region
 
     # the same iteration with draw_fstar in the other forms (one GPU only), same K and W: reported beside `value`
     alt = None
@@ -273,6 +279,10 @@ def main():
                                  if args.theta == "gather" else
                                  f"all-reduce of the {1001}x{n} partial log-posterior per iteration")) if world > 1 else "single GPU",
                 "stage_ms": stage_ms,
+                "stage_ms_per_rank": stage_ms_per_rank,
+                "chol": args.chol if world > 1 else "single GPU",
+                "theta": args.theta if world > 1 else "single GPU",
+                "backend": args.backend if world > 1 else None,
                 "draw_fstar_form": {"double_solve": "src/draw-fstar.cpp:17-25 as written",
                                     "fused": "mean = (L^-1 k*)^T (L^-1 f)",
                                     "lowrank": "fused + K(theta, theta*) = K(theta, c) V^T, 64 Chebyshev nodes: 2 x 64 right-hand "

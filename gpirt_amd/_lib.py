@@ -65,6 +65,11 @@ SIGNATURES = {
     "gpirt_potrf_panel_update": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64]),
     "gpirt_potrf_panel_copy": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i32]),
     "gpirt_potrf_finish": (_i32, [_vp]),
+    "gpirt_potrf_subpanel_width": (_i64, []),
+    "gpirt_potrf_panel_factor_part": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32]),
+    "gpirt_potrf_panel_update_part": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _i32]),
+    "gpirt_potrf_panel_copy_part": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _vp, _i32]),
+    "gpirt_debug_streams_busy": (_i32, [_vp, C.POINTER(_i32)]),
     "gpirt_trmm_lz": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64]),
     "gpirt_trsm_lower": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _i32]),
     "gpirt_gemm": (_i32, [_vp, _i32, _i32, _i64, _i64, _i64, _dbl, _vp, _i64, _vp, _i64, _dbl, _vp, _i64]),
@@ -105,6 +110,9 @@ SIGNATURES = {
     "gpirt_sampler_panel_update": (_i32, [_vp, _i64, _i64]),
     "gpirt_sampler_panel_copy": (_i32, [_vp, _i64, _vp, _i32]),
     "gpirt_sampler_panel_rows": (_i32, [_vp, C.POINTER(_i64)]),
+    "gpirt_sampler_panel_factor_part": (_i32, [_vp, _i64, _i32]),
+    "gpirt_sampler_panel_update_part": (_i32, [_vp, _i64, _i64, _i32]),
+    "gpirt_sampler_panel_copy_part": (_i32, [_vp, _i64, _i32, _vp, _i32]),
     "gpirt_sampler_ldl": (_i32, [_vp, C.POINTER(_i64)]),
     "gpirt_sampler_copy_state": (_i32, [_vp, _vp]),
     "gpirt_sampler_accumulate_irf": (_i32, [_vp]),

@@ -76,11 +76,15 @@ int report_panel_guard(gpirt_handle_t h, const int* w, hipStream_t stream)
 }
 
 int potrf_panel_copy(hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t p, double* buf, bool to_buf,
-                     int64_t extra_rows)
+                     int64_t extra_rows, int half)
 {
-    const int64_t W = potrf_panel_width(), K0 = p * W;
-    if (p < 0 || K0 >= n) { set_error("panel %lld out of range", (long long)p); return GPIRT_E_ARG; }
-    const int64_t w = (K0 + W < n) ? W : n - K0, rows = n + extra_rows - K0;
+    const int64_t W = potrf_panel_width(), H = potrf_subpanel_width(), P0 = p * W;
+    if (p < 0 || P0 >= n || half < 0 || half > 2) { set_error("panel %lld / half %d out of range", (long long)p, half); return GPIRT_E_ARG; }
+    const int64_t P1 = (P0 + W < n) ? P0 + W : n;
+    const int64_t mid = (P0 + H < P1) ? P0 + H : P1;
+    const int64_t K0 = (half == 1) ? mid : P0, K1 = (half == 0) ? mid : P1;     // the columns that travel
+    const int64_t w = K1 - K0, rows = n + extra_rows - K0;
+    if (w <= 0) return 0;
     double* a = A + K0 + K0 * lda;
     if (to_buf) GP_HIP(hipMemcpy2DAsync(buf, (size_t)rows * 8, a, (size_t)lda * 8, (size_t)rows * 8, (size_t)w, hipMemcpyDeviceToDevice, stream));
     else        GP_HIP(hipMemcpy2DAsync(a, (size_t)lda * 8, buf, (size_t)rows * 8, (size_t)rows * 8, (size_t)w, hipMemcpyDeviceToDevice, stream));
@@ -310,6 +314,42 @@ int gpirt_potrf_panel_copy(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda
 {
     GP_ARG(h && d_A && d_buf && n > 0 && lda >= n && p >= 0);
     return potrf_panel_copy(h->stream, d_A, n, lda, p, d_buf, to_buf != 0, 0);
+}
+
+// the same three pieces by halves of an outer panel (its first sub-panel / the rest): the pipeline of a distributing host
+int64_t gpirt_potrf_subpanel_width(void) { return potrf_subpanel_width(); }
+
+int gpirt_potrf_panel_factor_part(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda, int64_t p, int half)
+{
+    GP_ARG(h && d_A && n > 0 && lda >= n);
+    return potrf_panel_factor(h, h->stream, d_A, n, lda, p, 0, half);
+}
+
+int gpirt_potrf_panel_update_part(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda, int64_t p, int64_t c, int part)
+{
+    GP_ARG(h && d_A && n > 0 && lda >= n);
+    return potrf_panel_update(h, h->stream, d_A, n, lda, p, c, 0, part);
+}
+
+int gpirt_potrf_panel_copy_part(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda, int64_t p, int half, double* d_buf, int to_buf)
+{
+    GP_ARG(h && d_A && d_buf && n > 0 && lda >= n && p >= 0);
+    return potrf_panel_copy(h->stream, d_A, n, lda, p, d_buf, to_buf != 0, 0, half);
+}
+
+// Debug aid for hosts that put collectives between the pieces: every piece must have joined the handle's stream before it
+// returns (the library forks look-ahead work onto streams of its own).  *busy = bit mask of the handle's internal streams
+// that still have work in flight (0 = all idle): side 1, rows 2, near 4, chain-B 8.  Does not synchronise.
+int gpirt_debug_streams_busy(gpirt_handle_t h, int* busy)
+{
+    GP_ARG(h && busy);
+    int m = 0;
+    hipStream_t st[4] = { h->side, h->rows_stream, h->near_stream, h->chainb_stream };
+    for (int i = 0; i < 4; ++i)
+        if (st[i] && hipStreamQuery(st[i]) == hipErrorNotReady) m |= 1 << i;
+    (void)hipGetLastError();
+    *busy = m;
+    return 0;
 }
 
 int gpirt_potrf_finish(gpirt_handle_t h)

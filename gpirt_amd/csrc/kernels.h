@@ -48,11 +48,16 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
 
 // the same factorisation in pieces (distributed hosts): outer panel p = columns [p W, (p + 1) W)
 int64_t potrf_panel_width();
-int potrf_panel_factor(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t p, int64_t extra_rows = 0);
+int64_t potrf_subpanel_width();
+// half: 0 = the panel's first sub-panel, 1 = the rest of it, 2 = the whole panel (persistent panel kernel for 0 / 1)
+int potrf_panel_factor(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t p, int64_t extra_rows = 0,
+                       int half = 2);
+// part: 2 = the whole update of block column c by panel p; 0 = what needs only the panel's first sub-panel; 1 = the rest
 int potrf_panel_update(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t p, int64_t c,
-                       int64_t extra_rows = 0);
+                       int64_t extra_rows = 0, int part = 2);
+// half as for potrf_panel_factor: the columns of that part of the panel, rows from the part's first row down
 int potrf_panel_copy(hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t p, double* buf, bool to_buf,
-                     int64_t extra_rows = 0);
+                     int64_t extra_rows = 0, int half = 2);
 
 // panel.hip: columns [K0, c1) of the Cholesky factor, all rows below, one persistent kernel
 int launch_panel_ll(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t K0, int64_t c1,

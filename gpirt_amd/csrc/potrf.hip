@@ -154,8 +154,10 @@ bool panel_persistent()
 }
 
 // inner loop of one outer panel: columns [K0, c1), every row below; 64-column steps
+// part: 0 = the whole panel; 1 = its first sub-panel only; 2 = the rest (the update of the remaining columns by the first
+// sub-panel, then the other sub-panels) -- the halves a distributing host sends one at a time (persistent kernel only)
 int factor_panel(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t K0, int64_t c1,
-                 bool first_diag_done = false)
+                 bool first_diag_done = false, int part = 0)
 {
     static const bool fuse = !(getenv("GPIRT_FUSE_POTF2") && atoi(getenv("GPIRT_FUSE_POTF2")) == 2);
     if (panel_persistent()) {
@@ -172,7 +174,7 @@ int factor_panel(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int
         for (int64_t k0 = K0; k0 < c1; k0 += nbp) {
             const int64_t k1 = (k0 + nbp < c1) ? k0 + nbp : c1;
             const int64_t wend = k1 + ((int64_t)lean_win / NBI) * NBI;
-            if (lean_rows == 1 && (k1 - k0) % NBI == 0 && wend + 2048 <= n && (wend % NBI) == 0) {
+            if (lean_rows == 1 && !(part == 2 && k0 == K0) && (k1 - k0) % NBI == 0 && wend + 2048 <= n && (wend % NBI) == 0) {
                 if (!h->rows_stream) GP_HIP(hipStreamCreateWithFlags(&h->rows_stream, hipStreamNonBlocking));
                 for (int e = 12; e < 14; ++e)
                     if (!h->ev_pool[e]) GP_HIP(hipEventCreateWithFlags(&h->ev_pool[e], hipEventDisableTiming));
@@ -183,14 +185,16 @@ int factor_panel(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int
                 GP_TRY(launch_panel_rows(h, h->rows_stream, A, n, lda, k0, k1, wend, n, epoch));
                 GP_HIP(hipEventRecord(h->ev_pool[13], h->rows_stream));
                 GP_HIP(hipStreamWaitEvent(stream, h->ev_pool[13], 0));
-            } else {
+            } else if (!(part == 2 && k0 == K0)) {
                 GP_TRY(launch_panel_ll(h, stream, A, n, lda, k0, k1));
             }
+            if (part == 1) return 0;
             if (k1 < c1)      // A[k1:n, k1:c1] -= A[k1:n, k0:k1] A[k1:c1, k0:k1]^T
                 GP_TRY(panel_update(h, stream, n - k1, c1 - k1, k1 - k0, A + k1 + k0 * lda, lda, A + k1 + k1 * lda, lda));
         }
         return 0;
     }
+    if (part != 0) { set_error("the panel in halves needs the persistent panel kernel"); return GPIRT_E_ARG; }
     for (int64_t k0 = K0; k0 < c1; k0 += NBI) {
         const int nb = (int)((c1 - k0) < NBI ? (c1 - k0) : NBI);
         // only the first diagonal block of an outer panel needs its own potf2 launch: every later one is
@@ -248,28 +252,22 @@ int trailing(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t
 // schedule applies it while that sub-panel is still being factored (first_half_done) and only K = 512 of the update is
 // left on the chain.  The rule is the same wherever this block column is updated (with or without look-ahead, in the
 // distributed pieces), so L does not depend on the schedule.  Columns [lo + nbp, hi) take the panel in one product.
-//   part: 1 = the first sub-panel's columns only (what the chain waits for), 2 = the others, 3 = both
+//   part (bit mask): 1 = the panel's first half on the first sub-panel's columns, 2 = its second half on them (what the
+//   chain waits for), 4 = the whole panel on the other columns.  A panel with a single sub-panel has no halves: bit 2
+//   then carries the whole product and bit 1 nothing.
 int crit_update(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t K0, int64_t c1, int64_t lo,
-                int64_t hi, int64_t nbp, bool first_half_done, int part)
+                int64_t hi, int64_t nbp, int part)
 {
     const int64_t a_hi = (lo + nbp < hi) ? lo + nbp : hi;          // the next panel's first sub-panel
     const int64_t kmid = K0 + nbp;                                 // end of this panel's first sub-panel
-    if (part & 1) {
-        if (kmid < c1) {
-            if (!first_half_done) GP_TRY(trailing(h, stream, A, n, lda, K0, kmid, lo, a_hi));
-            GP_TRY(trailing(h, stream, A, n, lda, kmid, c1, lo, a_hi));
-        } else {
-            GP_TRY(trailing(h, stream, A, n, lda, K0, c1, lo, a_hi));
-        }
+    if (kmid < c1) {
+        if (part & 1) GP_TRY(trailing(h, stream, A, n, lda, K0, kmid, lo, a_hi));
+        if (part & 2) GP_TRY(trailing(h, stream, A, n, lda, kmid, c1, lo, a_hi));
+    } else if (part & 2) {
+        GP_TRY(trailing(h, stream, A, n, lda, K0, c1, lo, a_hi));
     }
-    if ((part & 2) && a_hi < hi) GP_TRY(trailing(h, stream, A, n, lda, K0, c1, a_hi, hi));
+    if ((part & 4) && a_hi < hi) GP_TRY(trailing(h, stream, A, n, lda, K0, c1, a_hi, hi));
     return 0;
-}
-
-int64_t potrf_subpanel_width()
-{
-    const int64_t v = (env_int("GPIRT_NBP", NBP) / NBI) * NBI;
-    return v > 0 ? v : NBP;
 }
 
 
@@ -496,28 +494,40 @@ int potrf_windowed(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, i
 // rank applies it to the block columns it owns.  The pieces are exactly the launches of launch_potrf_lower -- same
 // sub-panel split, same K = 1024 products applied to every block in ascending panel order -- so the assembled L is
 // bit-identical to the single-GPU factor.
+int64_t potrf_subpanel_width()
+{
+    const int64_t v = (env_int("GPIRT_NBP", NBP) / NBI) * NBI;
+    return v > 0 ? v : NBP;
+}
+
 int64_t potrf_panel_width()
 {
     static const int nbo_env = env_int("GPIRT_NBO", NBO);
     return (nbo_env / NBI) * NBI > 0 ? (nbo_env / NBI) * NBI : NBO;
 }
 
-int potrf_panel_factor(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t p, int64_t extra_rows)
+// half: 0 = the panel's first sub-panel, 1 = the rest of it, 2 = the whole panel
+int potrf_panel_factor(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t p, int64_t extra_rows,
+                       int half)
 {
     const int64_t W = potrf_panel_width(), K0 = p * W;
-    if (p < 0 || K0 >= n) { set_error("panel %lld out of range", (long long)p); return GPIRT_E_ARG; }
-    return factor_panel(h, stream, A, n + extra_rows, lda, K0, (K0 + W < n) ? K0 + W : n);
+    if (p < 0 || K0 >= n || half < 0 || half > 2) { set_error("panel %lld / half %d out of range", (long long)p, half); return GPIRT_E_ARG; }
+    return factor_panel(h, stream, A, n + extra_rows, lda, K0, (K0 + W < n) ? K0 + W : n, false, half == 2 ? 0 : half + 1);
 }
 
 // A[cW:n, cW:(c+1)W] -= A[cW:n, pW:(p+1)W] A[cW:(c+1)W, pW:(p+1)W]^T   (lower trapezoid of block column c > p)
+// part: 2 = everything; 0 = what needs only panel p's FIRST sub-panel (its half of the update of the next panel's first
+// columns; nothing for other block columns); 1 = the rest.  0 then 1 launches exactly what 2 does, in the same order.
 int potrf_panel_update(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t p, int64_t c,
-                       int64_t extra_rows)
+                       int64_t extra_rows, int part)
 {
     const int64_t W = potrf_panel_width(), K0 = p * W, lo = c * W;
     if (p < 0 || c <= p || lo >= n) { set_error("panel update (%lld -> %lld) out of range", (long long)p, (long long)c); return GPIRT_E_ARG; }
     const int64_t hi = (lo + W < n) ? lo + W : n;
+    if (part < 0 || part > 2) { set_error("panel update part %d", part); return GPIRT_E_ARG; }
     if (c == p + 1 && panel_persistent())       // the next panel's block column: the same products as launch_potrf_lower
-        return crit_update(h, stream, A, n + extra_rows, lda, K0, K0 + W, lo, hi, potrf_subpanel_width(), false, 3);
+        return crit_update(h, stream, A, n + extra_rows, lda, K0, K0 + W, lo, hi, potrf_subpanel_width(), part == 2 ? 7 : (part == 0 ? 1 : 6));
+    if (part == 0) return 0;
     return trailing(h, stream, A, n + extra_rows, lda, K0, K0 + W, lo, hi);
 }
 
@@ -604,7 +614,7 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
         const bool split = la && c2 < n && panel_persistent() && cA < c2;
         if (panel_persistent()) {
             // (the first sub-panel's columns first: part 1; the others follow behind the fork when `split`)
-            GP_TRY(crit_update(h, stream, A, nr, lda, K0, c1, c1, c2, nbp_la, half_done, split ? 1 : 3));
+            GP_TRY(crit_update(h, stream, A, nr, lda, K0, c1, c1, c2, nbp_la, (half_done ? 2 : 3) | (split ? 0 : 4)));
             half_done = false;
         } else {
             GP_TRY(trailing(h, stream, A, nr, lda, K0, c1, c1, split ? cA : c2, split ? nullptr : &diag_done));
@@ -617,7 +627,7 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
                 // other columns of the outer panel are brought up to date behind it on the main stream
                 GP_TRY(factor_panel(h, h->side, A, nr, lda, c1, cA));
                 if (half_ahead) GP_HIP(hipEventRecord(h->ev_half, h->side));
-                if (panel_persistent()) GP_TRY(crit_update(h, stream, A, nr, lda, K0, c1, c1, c2, nbp_la, false, 2));
+                if (panel_persistent()) GP_TRY(crit_update(h, stream, A, nr, lda, K0, c1, c1, c2, nbp_la, 4));
                 else GP_TRY(trailing(h, stream, A, nr, lda, K0, c1, cA, c2));
                 GP_HIP(hipEventRecord(h->ev_mid, stream));
                 GP_HIP(hipStreamWaitEvent(h->side, h->ev_mid, 0));

@@ -881,6 +881,25 @@ int gpirt_sampler_panel_rows(gpirt_sampler_t s, int64_t* rows)
     return 0;
 }
 
+// ... and by halves of an outer panel (first sub-panel / the rest), for a host that pipelines the broadcasts
+int gpirt_sampler_panel_factor_part(gpirt_sampler_t s, int64_t p, int half)
+{
+    GP_ARG(s && s->initialised);
+    return potrf_panel_factor(s->h, s->h->stream, s->L, s->n, s->ldl, p, s->ext, half);
+}
+
+int gpirt_sampler_panel_update_part(gpirt_sampler_t s, int64_t p, int64_t c, int part)
+{
+    GP_ARG(s && s->initialised);
+    return potrf_panel_update(s->h, s->h->stream, s->L, s->n, s->ldl, p, c, s->ext, part);
+}
+
+int gpirt_sampler_panel_copy_part(gpirt_sampler_t s, int64_t p, int half, double* d_buf, int to_buf)
+{
+    GP_ARG(s && s->initialised && d_buf);
+    return potrf_panel_copy(s->h->stream, s->L, s->n, s->ldl, p, d_buf, to_buf != 0, s->ext, half);
+}
+
 // dst's chain state := src's (theta, f, beta, mu, mu_star, fstar, the n x n factor, the iteration counter): lets a second
 // sampler with other options replay a stage on the same state (bench.py's in-run check of the draw_fstar forms)
 int gpirt_sampler_copy_state(gpirt_sampler_t dst, gpirt_sampler_t src)

@@ -12,11 +12,15 @@ owns columns [m*r/G, m*(r+1)/G).  What is not item-separable:
     Either way the RNG is keyed by the global respondent index.
   * K + chol (src/gpirtMCMC.cpp:76-78): `chol="replicated"` factors on every rank (no traffic);
     `chol="bcast"` factors on rank 0 and broadcasts L (one RCCL broadcast per iteration);
-    `chol="distributed"`: 1-D block-cyclic ownership of the 1024-column outer panels -- the owner
-    factors a panel, the finished panel is broadcast while every rank applies the PREVIOUS panel to the block columns
-    it owns (the next panel's columns first, so its owner can start factoring), and every rank ends with the full L:
-    the panel broadcasts ARE the broadcast of L.  Same launches as the single-GPU factorisation => bit-identical L.
-The per-item RNG sub-streams are keyed by the GLOBAL item index, so the draws do not depend on G.
+    `chol="distributed"`: 1-D block-cyclic ownership of the 1024-column outer panels, pipelined by
+    halves of a panel -- the owner factors the first sub-panel and broadcasts it while it factors the second; the next
+    owner applies the first half's share of the update of its own first columns meanwhile, and every rank applies each
+    finished panel to the block columns it owns.  Every rank ends with the full L: the panel broadcasts ARE the
+    broadcast of L.  Same launches, same order as the single-GPU factorisation => bit-identical L.
+The per-item RNG sub-streams are keyed by the GLOBAL item index, so the draws do not depend on G up to rounding: the
+GEMM tiling / split-K partition of nu = L z and of the f* products depends on the local column count, so f and f* agree
+to ~1e-12 between partitions, and theta -- a grid pick -- is identical unless one of those last bits flips a comparison
+(probability ~1e-11 per draw).
 
 `engine_factory(y_local, theta_init, pm, ps, step, item0, m_total)` must return an object with the
 stage methods of gpirt_amd.Sampler; tests substitute a CPU engine to exercise this host logic
@@ -54,6 +58,8 @@ class ShardedSampler:
         if chol not in ("replicated", "bcast", "distributed"):
             raise ValueError("chol must be 'replicated', 'bcast' or 'distributed'")
         self._panel_bufs = None
+        import os as _os
+        self._debug = _os.environ.get("GPIRT_DIST_DEBUG") == "1"
         if theta not in ("gather", "allreduce"):
             raise ValueError("theta must be 'gather' or 'allreduce'")
         self.theta_mode = theta if self.world > 1 else "local"
@@ -94,49 +100,83 @@ class ShardedSampler:
         self.dist.all_reduce(self._view("theta_stage"))   # zero outside each rank's block
 
     def _factor_distributed(self):
-        """Right-looking over outer panels with one panel of look-ahead.  Panel p is owned by rank p % world.
-        Every block column receives the panels' updates in ascending order on its owner's (in-order) stream."""
+        """Right-looking over outer panels, pipelined by HALVES of a panel.  Panel p is owned by rank
+        p % world and factored as a first sub-panel A(p) (512 columns) and the rest B(p).  A(p) is broadcast while its
+        owner factors B(p); the next owner applies A(p)'s half of the update of ITS first columns while B(p) is still
+        being factored and travelling (the single-GPU factorisation splits that update the same way, potrf.hip
+        crit_update), so behind B(p)'s arrival only K = 512 of update and the next first sub-panel are left on the chain.
+        Every block column receives the panels' products in the same order as on one GPU: L is bit-identical.
+        Collectives are issued in one fixed order on every rank: A(0), B(0), A(1), B(1), ..."""
         import torch
         e, W, n = self.engine, self.engine.panel_width, self.n
+        H = e.subpanel_width
         NP = (n + W - 1) // W
         rows = e.panel_rows                         # n, plus the rows of a bordered factorisation
         owner = lambda p: p % self.world
+        mine = lambda p: owner(p) == self.rank
         if self._panel_bufs is None:
-            # two broadcast buffers (panel p + 1 travels while panel p is still being applied)
-            self._panel_bufs = [torch.empty(rows * min(W, n), dtype=torch.float64, device=e.torch_device) for _ in range(2)]
-        buf = lambda p: self._panel_bufs[p % 2][: (rows - p * W) * min(W, n - p * W)]
-        e.build_cov()
-        work = None
+            # two broadcast buffers: one half travels while the previous one is still being unpacked / applied
+            self._panel_bufs = [torch.empty(rows * min(H, n), dtype=torch.float64, device=e.torch_device) for _ in range(2)]
+        seq = [0]
 
-        def send(p):            # the finished panel p leaves its owner; collective: every rank calls it
-            if owner(p) == self.rank:
-                e.panel_copy(p, buf(p), True)
-            return self.dist.broadcast(buf(p), src=owner(p), async_op=True)
+        def cols(p, half):
+            P0, P1 = p * W, min((p + 1) * W, n)
+            mid = min(P0 + H, P1)
+            return (P0, mid) if half == 0 else (mid, P1)
 
-        def receive(p, w):
+        def send(p, half):      # collective: every rank calls it, in the same order
+            k0, k1 = cols(p, half)
+            if k1 <= k0:
+                return None
+            buf = self._panel_bufs[seq[0] % 2][: (rows - k0) * (k1 - k0)]
+            seq[0] += 1
+            if mine(p):
+                e.panel_copy_part(p, half, buf, True)
+            self._check_joined()
+            return buf, self.dist.broadcast(buf, src=owner(p), async_op=True)
+
+        def receive(p, half, h):
+            if h is None:
+                return
+            buf, w = h
             w.wait()
-            if owner(p) != self.rank:
-                e.panel_copy(p, buf(p), False)
+            if not mine(p):
+                e.panel_copy_part(p, half, buf, False)
 
-        if owner(0) == self.rank:
-            e.panel_factor(0)
-        receive(0, send(0))
-        for p in range(NP - 1):
+        e.build_cov()
+        if mine(0):
+            e.panel_factor_part(0, 0)
+        hA = send(0, 0)
+        if mine(0):
+            e.panel_factor_part(0, 1)               # beside A(0)'s broadcast
+        receive(0, 0, hA)
+        for p in range(NP):
             nxt = p + 1
-            if owner(nxt) == self.rank:
-                e.panel_update(p, nxt)              # the next panel's columns first ...
-                e.panel_factor(nxt)                 # ... so its owner can factor it
-            if nxt < NP - 1:
-                work = send(nxt)                    # travels while panel p is applied to the remaining columns
-            for c in range(nxt + 1, NP):
-                if owner(c) == self.rank:
-                    e.panel_update(p, c)
-            if nxt < NP - 1:
-                receive(nxt, work)
-        # the last panel has nothing to update: it only has to reach everybody
-        if NP > 1:
-            receive(NP - 1, send(NP - 1))
+            hB = send(p, 1)                          # B(p): behind its factorisation on the owner's stream
+            if nxt < NP and mine(nxt):
+                e.panel_update_part(p, nxt, 0)       # needs A(p) only: runs while B(p) is factored and travels
+            receive(p, 1, hB)
+            if nxt >= NP:
+                break
+            if mine(nxt):
+                e.panel_update_part(p, nxt, 1)       # what is left on the chain: K = 512 on the first columns + the others
+                e.panel_factor_part(nxt, 0)
+            hA = send(nxt, 0)
+            if mine(nxt):
+                e.panel_factor_part(nxt, 1)          # beside A(p + 1)'s broadcast
+            for c in range(nxt + 1, NP):             # panel p on the rest of this rank's block columns
+                if mine(c):
+                    e.panel_update_part(p, c, 2)
+            receive(nxt, 0, hA)
         e.adopt_factor(True)                        # the panel copies carry the rows below the factor too (panel_rows)
+
+    def _check_joined(self):
+        """GPIRT_DIST_DEBUG=1: every piece must have joined the engine's stream before a collective is enqueued behind it
+        (the library forks look-ahead work onto streams of its own; RCCL orders itself behind torch's current stream only)."""
+        if self._debug and hasattr(self.engine, "streams_busy"):
+            busy = self.engine.streams_busy()
+            if busy:
+                raise RuntimeError(f"a factorisation piece returned with internal streams still busy (mask {busy})")
 
     def _factor(self):
         if self.chol == "distributed" and self.world > 1:
@@ -174,10 +214,28 @@ class ShardedSampler:
         self._factor(); t("factor")
 
     def gather(self, name: str):
-        """All ranks receive the full (column-concatenated) array `name` of item-sharded state."""
+        """All ranks receive the full (column-concatenated) array `name` of item-sharded state.  Tensor collectives on
+        the host copies (no pickling: `f` is 64 MiB per rank at the metric size): shards are padded to the largest
+        item count so that one flat all-gather serves unequal partitions too."""
         local = np.ascontiguousarray(self.engine.get(name).T)     # (m_local, rows)
         if self.world == 1:
             return np.asfortranarray(local.T)
-        parts = [None] * self.world
-        self.dist.all_gather_object(parts, local)
-        return np.asfortranarray(np.concatenate(parts, axis=0).T)
+        import torch
+        rows = local.shape[1]
+        counts = [item_range(self.m_total, r, self.world) for r in range(self.world)]
+        mmax = max(hi - lo for lo, hi in counts)
+        dev = getattr(self.engine, "torch_device", torch.device("cpu"))
+        if self.dist.get_backend() == "gloo":
+            dev = torch.device("cpu")
+        mine = torch.zeros((mmax, rows), dtype=torch.float64, device=dev)
+        mine[: local.shape[0]] = torch.from_numpy(local).to(dev)
+        full = torch.empty((self.world * mmax, rows), dtype=torch.float64, device=dev)
+        if hasattr(self.dist, "all_gather_into_tensor"):
+            self.dist.all_gather_into_tensor(full, mine)
+        else:
+            parts = [torch.empty_like(mine) for _ in range(self.world)]
+            self.dist.all_gather(parts, mine)
+            full = torch.cat(parts, dim=0)
+        full = full.cpu().numpy()
+        out = np.concatenate([full[r * mmax: r * mmax + (hi - lo)] for r, (lo, hi) in enumerate(counts)], axis=0)
+        return np.asfortranarray(out.T)

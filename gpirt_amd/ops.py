@@ -135,6 +135,20 @@ class Handle:
     def potrf_panel_copy(self, A: torch.Tensor, p: int, buf: torch.Tensor, to_buf: bool):
         check(self.lib.gpirt_potrf_panel_copy(self._h, _p(A), A.shape[0], _ld(A), int(p), _p(buf), int(bool(to_buf))))
 
+    # ... by halves of an outer panel (half: 0 first sub-panel, 1 the rest, 2 whole; part: 0 needs only the first sub-panel)
+    @property
+    def subpanel_width(self) -> int:
+        return int(self.lib.gpirt_potrf_subpanel_width())
+
+    def potrf_panel_factor_part(self, A: torch.Tensor, p: int, half: int):
+        check(self.lib.gpirt_potrf_panel_factor_part(self._h, _p(A), A.shape[0], _ld(A), int(p), int(half)))
+
+    def potrf_panel_update_part(self, A: torch.Tensor, p: int, c: int, part: int):
+        check(self.lib.gpirt_potrf_panel_update_part(self._h, _p(A), A.shape[0], _ld(A), int(p), int(c), int(part)))
+
+    def potrf_panel_copy_part(self, A: torch.Tensor, p: int, half: int, buf: torch.Tensor, to_buf: bool):
+        check(self.lib.gpirt_potrf_panel_copy_part(self._h, _p(A), A.shape[0], _ld(A), int(p), int(half), _p(buf), int(bool(to_buf))))
+
     def potrf_finish(self):
         info = self.lib.gpirt_potrf_finish(self._h)
         if info > 0:

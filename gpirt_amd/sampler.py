@@ -192,6 +192,27 @@ class Sampler:
         """rows [pW, panel_rows) of outer panel p <-> the dense torch buffer `buf` (what the host broadcasts)"""
         check(self.lib.gpirt_sampler_panel_copy(self._s, int(p), C.c_void_p(buf.data_ptr()), int(bool(to_buf))))
 
+    # ... by halves of an outer panel (half: 0 first sub-panel, 1 the rest, 2 whole; part: 0 needs only the first
+    # sub-panel, 1 the rest, 2 all): what the pipelined distributed factorisation drives (gpirt_amd/distributed.py)
+    @property
+    def subpanel_width(self) -> int:
+        return int(self.lib.gpirt_potrf_subpanel_width())
+
+    def panel_factor_part(self, p: int, half: int):
+        check(self.lib.gpirt_sampler_panel_factor_part(self._s, int(p), int(half)))
+
+    def panel_update_part(self, p: int, c: int, part: int):
+        check(self.lib.gpirt_sampler_panel_update_part(self._s, int(p), int(c), int(part)))
+
+    def panel_copy_part(self, p: int, half: int, buf, to_buf: bool):
+        check(self.lib.gpirt_sampler_panel_copy_part(self._s, int(p), int(half), C.c_void_p(buf.data_ptr()), int(bool(to_buf))))
+
+    def streams_busy(self) -> int:
+        """bit mask of the handle's internal streams with work in flight (0: every piece has joined the handle stream)"""
+        b = C.c_int()
+        check(self.lib.gpirt_debug_streams_busy(self.handle.ptr, C.byref(b)))
+        return b.value
+
     def copy_state_from(self, other: "Sampler"):
         check(self.lib.gpirt_sampler_copy_state(self._s, other._s))
 

@@ -102,6 +102,21 @@ int gpirt_potrf_panel_factor(gpirt_handle_t h, double* d_A, int64_t n, int64_t l
 int gpirt_potrf_panel_update(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda, int64_t p, int64_t c);
 int gpirt_potrf_panel_copy(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda, int64_t p, double* d_buf, int to_buf);
 int gpirt_potrf_finish(gpirt_handle_t h);
+/* The same pieces by HALVES of an outer panel, for a host that pipelines its broadcasts: an outer panel is factored as a
+ * first sub-panel of gpirt_potrf_subpanel_width() columns and the rest, and the next panel's first columns take the panel's
+ * update as two products (first sub-panel, then the rest -- the same rule launch_potrf_lower follows on one GPU), so
+ *   half: 0 = the panel's first sub-panel, 1 = the rest of it, 2 = the whole panel        (factor / copy)
+ *   part: 0 = what needs only panel p's first sub-panel, 1 = everything else, 2 = all     (update)
+ * let the next owner start on a panel's first half while its second half is still being factored or travelling.
+ * Factoring / updating by halves launches exactly what the whole-panel calls launch, in the same order: L is the same
+ * bit for bit.  copy_part moves the part's columns, rows from the part's first row down (dense, ld = that row count). */
+int64_t gpirt_potrf_subpanel_width(void);
+int gpirt_potrf_panel_factor_part(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda, int64_t p, int half);
+int gpirt_potrf_panel_update_part(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda, int64_t p, int64_t c, int part);
+int gpirt_potrf_panel_copy_part(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda, int64_t p, int half, double* d_buf, int to_buf);
+/* Debug aid for hosts that enqueue collectives between the pieces: *busy = bit mask of the handle's INTERNAL streams that
+ * still have work in flight (0 = every piece has joined the handle's stream, as each must before it returns). */
+int gpirt_debug_streams_busy(gpirt_handle_t h, int* busy);
 
 /* rmvnorm()'s product `cholS * res` (src/mvnormal.h:10) for all item columns at once:
  * d_out (n x m) = L * Z with L lower triangular; the strict upper triangle of d_L must hold zeros
@@ -248,6 +263,10 @@ int gpirt_sampler_panel_factor(gpirt_sampler_t s, int64_t p);
 int gpirt_sampler_panel_update(gpirt_sampler_t s, int64_t p, int64_t c);
 int gpirt_sampler_panel_copy(gpirt_sampler_t s, int64_t p, double* d_buf, int to_buf);
 int gpirt_sampler_panel_rows(gpirt_sampler_t s, int64_t* rows);
+/* ... and by halves of an outer panel (gpirt_potrf_panel_*_part above) */
+int gpirt_sampler_panel_factor_part(gpirt_sampler_t s, int64_t p, int half);
+int gpirt_sampler_panel_update_part(gpirt_sampler_t s, int64_t p, int64_t c, int part);
+int gpirt_sampler_panel_copy_part(gpirt_sampler_t s, int64_t p, int half, double* d_buf, int to_buf);
 /* Close the iteration WITHOUT factoring: "L" arrived from elsewhere (a broadcast into the "L" devptr, the distributed
  * pieces, gpirt_sampler_set).  rows_with_L != 0: the rows below the n x n factor (gpirt_sampler_ldl) arrived with it,
  * i.e. the whole ldl x n buffer was received; 0: only the n x n factor is current and the rows are rebuilt by the

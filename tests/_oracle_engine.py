@@ -168,6 +168,54 @@ class OracleEngine:
         lo, hi = self._cols(c)
         L[lo:, lo:hi] -= L[lo:, K0:c1] @ L[lo:hi, K0:c1].T
 
+    # ... by halves of an outer panel (gpirt_potrf_panel_*_part): first sub-panel of `subpanel_width` columns / the rest
+    subpanel_width = 8
+
+    def _half(self, p, half):
+        K0, c1 = self._cols(p)
+        mid = min(K0 + self.subpanel_width, c1)
+        return (K0, mid) if half == 0 else ((mid, c1) if half == 1 else (K0, c1))
+
+    def panel_factor_part(self, p, half):
+        L = self.L
+        K0, _ = self._cols(p)
+        j0, j1 = self._half(p, half)
+        for j in range(j0, j1):
+            L[j:, j] -= L[j:, K0:j] @ L[j, K0:j]
+            d = np.sqrt(L[j, j])
+            L[j, j] = d
+            L[j + 1:, j] /= d
+            L[:j, j] = 0.0
+
+    def panel_update_part(self, p, c, part):
+        L = self.L
+        K0, c1 = self._cols(p)
+        mid = min(K0 + self.subpanel_width, c1)
+        lo, hi = self._cols(c)
+        a_hi = min(lo + self.subpanel_width, hi)
+        if c != p + 1:
+            if part != 0:
+                L[lo:, lo:hi] -= L[lo:, K0:c1] @ L[lo:hi, K0:c1].T
+            return
+        if part in (0, 2) and mid < c1:
+            L[lo:, lo:a_hi] -= L[lo:, K0:mid] @ L[lo:a_hi, K0:mid].T
+        if part in (1, 2):
+            k0 = mid if mid < c1 else K0
+            L[lo:, lo:a_hi] -= L[lo:, k0:c1] @ L[lo:a_hi, k0:c1].T
+            if a_hi < hi:
+                L[lo:, a_hi:hi] -= L[lo:, K0:c1] @ L[a_hi:hi, K0:c1].T
+
+    def panel_copy_part(self, p, half, buf, to_buf):
+        k0, k1 = self._half(p, half)
+        if k1 <= k0:
+            return
+        view = buf.numpy()[: (self.n - k0) * (k1 - k0)].reshape(self.n - k0, k1 - k0, order="F")
+        if to_buf:
+            view[:, :] = self.L[k0:, k0:k1]
+        else:
+            self.L[k0:, k0:k1] = view
+            self.L[:k0, k0:k1] = 0.0
+
     def panel_copy(self, p, buf, to_buf):
         K0, c1 = self._cols(p)
         view = buf.numpy()[: (self.n - K0) * (c1 - K0)].reshape(self.n - K0, c1 - K0, order="F")

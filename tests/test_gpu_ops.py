@@ -192,6 +192,52 @@ def test_potrf_in_pieces_is_bit_identical(handle, n, G):
         assert torch.equal(torch.tril(ranks[r]), torch.tril(ref)), f"rank {r} differs from the single-GPU factor"
 
 
+@pytest.mark.parametrize("n,G", [(5000, 3), (8192, 8), (2600, 2)])
+def test_potrf_in_half_panels_is_bit_identical(handle, n, G):
+    """The pipelined form of the same host (round 3): an outer panel travels as its first sub-panel and the rest, and the
+    next owner applies the first half's share of the update of its first columns before the second half exists
+    (gpirt_potrf_panel_*_part, in the order gpirt_amd/distributed.py issues them).  Same launches, same order: every
+    rank must again hold gpirt_potrf_lower's factor BIT FOR BIT."""
+    import torch
+    from gpirt_amd.ops import to_device
+    from gpirt_amd.synthetic import make_responses
+    _, th0 = make_responses(n, 2, seed=n)
+    th = to_device(th0)
+    ref = handle.factor(th)
+    W, H = handle.panel_width, handle.subpanel_width
+    NP = (n + W - 1) // W
+    ranks = [handle.se_kernel(th, th, jitter=0.001) for _ in range(G)]
+    buf = torch.empty(n * min(H, n), dtype=torch.float64, device="cuda")
+    own = lambda p: p % G
+
+    def travel(p, half):
+        handle.potrf_panel_copy_part(ranks[own(p)], p, half, buf, True)
+        for r in range(G):
+            if r != own(p):
+                handle.potrf_panel_copy_part(ranks[r], p, half, buf, False)
+
+    handle.potrf_begin()
+    handle.potrf_panel_factor_part(ranks[own(0)], 0, 0)
+    travel(0, 0)
+    handle.potrf_panel_factor_part(ranks[own(0)], 0, 1)
+    for p in range(NP):
+        nxt = p + 1
+        if nxt < NP:
+            handle.potrf_panel_update_part(ranks[own(nxt)], p, nxt, 0)      # before B(p) has arrived anywhere
+        travel(p, 1)
+        if nxt >= NP:
+            break
+        handle.potrf_panel_update_part(ranks[own(nxt)], p, nxt, 1)
+        handle.potrf_panel_factor_part(ranks[own(nxt)], nxt, 0)
+        travel(nxt, 0)
+        handle.potrf_panel_factor_part(ranks[own(nxt)], nxt, 1)
+        for c in range(nxt + 1, NP):
+            handle.potrf_panel_update_part(ranks[own(c)], p, c, 2)
+    handle.potrf_finish()
+    for r in range(G):
+        assert torch.equal(torch.tril(ranks[r]), torch.tril(ref)), f"rank {r} differs from the single-GPU factor"
+
+
 def test_potrf_operator_on_user_matrix(handle, oracle):
     from gpirt_amd.ops import to_device, to_host
     n = 200
