@@ -179,6 +179,7 @@ int gpirt_destroy(gpirt_handle_t h)
     if (h->ev_mid) hipEventDestroy(h->ev_mid);
     if (h->ev_a) hipEventDestroy(h->ev_a);
     if (h->ev_half) hipEventDestroy(h->ev_half);
+    if (h->ev_prelast) hipEventDestroy(h->ev_prelast);
     if (h->rows_stream) hipStreamDestroy(h->rows_stream);
     if (h->near_stream) hipStreamDestroy(h->near_stream);
     if (h->chainb_stream) hipStreamDestroy(h->chainb_stream);

@@ -70,6 +70,8 @@ struct gpirt_handle_s {
     // look-ahead Cholesky: high-priority side stream for the panel chain + fork/join events
     hipStream_t  side = nullptr;
     hipEvent_t   ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr, ev_a = nullptr, ev_half = nullptr;
+    hipEvent_t   ev_prelast = nullptr;    // fires when every outer panel but the last is final (columns [0, prelast_cols))
+    int64_t      prelast_cols = 0;        //   ... of the factorisation enqueued last (0: no such point, e.g. a single panel)
     // persistent panel kernel (panel.hip): one progress counter per 64-row block, epoch-tagged
     unsigned long long* d_prog = nullptr;
     double*      d_winv = nullptr;        // panel.hip: inverses of the diagonal blocks' 16 x 16 blocks, handed along the pivot chain

@@ -74,9 +74,12 @@ int launch_panel_rows(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n
 int launch_trsm_lower(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t n, int64_t ldl,
                       double* B, int64_t nrhs, int64_t ldb, bool trans, bool reuse_inverses = false);
 
-// the block inverses launch_trsm_lower applies (all 512 x 512 diagonal blocks of the factor at once)
+// the block inverses launch_trsm_lower applies, exposed so that they can be built by ranges of 512-block pairs [p0, p1) as
+// the factor's outer panels finish; *_mark tells the handle that its inverses now belong to (L, n, ldl)
 int trsm_inverses_reserve(gpirt_handle_t h, hipStream_t stream, int64_t n, int64_t nrhs, bool thin);
-int trsm_inverses_build(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t n, int64_t ldl, bool thin);
+int trsm_inverses_build(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t n, int64_t ldl, bool thin,
+                        int64_t p0, int64_t p1);
+void trsm_inverses_mark(gpirt_handle_t h, const double* L, int64_t n, int64_t ldl, bool thin);
 
 // rng.hip
 int launch_item_uniforms(hipStream_t stream, uint64_t seed, uint32_t iter, uint32_t stage,

@@ -551,6 +551,7 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
     static const int lookahead = env_int("GPIRT_LOOKAHEAD", 1);     // 2 = off
     const int64_t nbo = (nbo_env / NBI) * NBI > 0 ? (nbo_env / NBI) * NBI : NBO;
     if (reset_info) GP_HIP(hipMemsetAsync(h->d_info, 0, sizeof(int), stream));
+    h->prelast_cols = 0;
     const bool la = (lookahead == 1) && (n > 2 * nbo);
     {
         // GPIRT_SCHED: 2 = the windowed schedule (chain / near / rows / main streams), 1 = one sub-panel kernel over all rows
@@ -647,6 +648,13 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
             } else {
                 GP_TRY(factor_panel(h, h->side, A, nr, lda, c1, c2, diag_done)); // next panel, side stream
             }
+            if (c2 + nbo >= n) {
+                // [0, c2) is final and only the last outer panel is left -- a phase with most of the chip idle: whoever has
+                // work that needs only the finished part of L (the sampler's block inverses) may start behind this event
+                if (!h->ev_prelast) GP_HIP(hipEventCreateWithFlags(&h->ev_prelast, hipEventDisableTiming));
+                GP_HIP(hipEventRecord(h->ev_prelast, h->side));
+                h->prelast_cols = c2;
+            }
             if (defer == 1 && split) {
                 const int64_t horizon = (c2 + nbo < n) ? c2 + nbo : n;
                 GP_TRY(trailing(h, stream, A, nr, lda, 0, c1, c2, horizon, nullptr, true));
@@ -654,12 +662,41 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
                 done_col.push_back(c2);                                   // this panel: [c1, c2) done above
                 static const int ahead = env_int("GPIRT_DEFER_AHEAD", 1);  // block columns brought up to date per step
                 const int64_t horizon = (c2 + ahead * nbo < n) ? c2 + ahead * nbo : n;
+                // GPIRT_DEFER_SPLIT=1: each of these launches is cut in two by rows -- the upper slab (with the trapezoid on
+                // the diagonal) stays on this stream, the lower one goes to a second stream.  Different rows of a block
+                // column are independent, so the two slabs form two chains of launches whose partial last rounds (a
+                // launch of 868 64-tiles on 768 slots takes two rounds) fill each other.  Same products per element.
+                static const int defer_split = env_int("GPIRT_DEFER_SPLIT", 0);
+                bool forked = false;
                 for (size_t q = 0; q < done_col.size(); ++q)
                     if (done_col[q] < horizon) {
-                        GP_TRY(trailing(h, stream, A, nr, lda, (int64_t)q * nbo, (int64_t)(q + 1) * nbo, done_col[q], horizon,
-                                        nullptr, true));
+                        const int64_t lo = done_col[q], rows = nr - lo;
+                        if (defer_split == 1 && rows >= 3072) {
+                            const int64_t mid = lo + ((rows / 2 + NBI - 1) / NBI) * NBI;
+                            if (!forked) {
+                                if (!h->rows_stream) GP_HIP(hipStreamCreateWithFlags(&h->rows_stream, hipStreamNonBlocking));
+                                for (int e = 12; e < 14; ++e)
+                                    if (!h->ev_pool[e]) GP_HIP(hipEventCreateWithFlags(&h->ev_pool[e], hipEventDisableTiming));
+                                GP_HIP(hipEventRecord(h->ev_pool[12], stream));
+                                GP_HIP(hipStreamWaitEvent(h->rows_stream, h->ev_pool[12], 0));
+                                forked = true;
+                            }
+                            GP_TRY(win_update(h, stream, A, lda, (int64_t)q * nbo, (int64_t)(q + 1) * nbo, lo, mid, lo, horizon, false));
+                            GP_TRY(win_update(h, h->rows_stream, A, lda, (int64_t)q * nbo, (int64_t)(q + 1) * nbo, mid, nr, lo, horizon, false));
+                        } else {
+                            if (forked) {      // a launch over all rows behind split ones: the lower slabs first
+                                GP_HIP(hipEventRecord(h->ev_pool[13], h->rows_stream));
+                                GP_HIP(hipStreamWaitEvent(stream, h->ev_pool[13], 0));
+                                forked = false;
+                            }
+                            GP_TRY(trailing(h, stream, A, nr, lda, (int64_t)q * nbo, (int64_t)(q + 1) * nbo, lo, horizon, nullptr, true));
+                        }
                         done_col[q] = horizon;
                     }
+                if (forked) {
+                    GP_HIP(hipEventRecord(h->ev_pool[13], h->rows_stream));
+                    GP_HIP(hipStreamWaitEvent(stream, h->ev_pool[13], 0));
+                }
             } else {
                 GP_TRY(trailing(h, stream, A, nr, lda, K0, c1, c2, n));    // the rest, concurrently
             }

@@ -63,6 +63,11 @@ struct gpirt_sampler_s {
     gpirt_handle_t haux = nullptr;
     hipEvent_t ev_trmm = nullptr, ev_prep = nullptr;
     bool prep_valid = false, prep_pending = false;
+    int64_t inv_built_pairs = 0;      // 512-block pairs of L whose inverses haux already holds (built behind the factorisation)
+    // the N(0,1) draws of the NEXT draw_f depend on (seed, iteration, item, index) only: filled on the sampler's own stream
+    // while the last outer panel is factored; z_filled_iter = the iteration they belong to (0: none), ev_zfill fires when done
+    uint32_t z_filled_iter = 0;
+    hipEvent_t ev_zfill = nullptr;
     // respondent-block form of draw_theta for item-sharded runs (gpirt_sampler_set_theta_block): this rank's
     // block of respondents with ALL items
     int64_t blk_i0 = 0, blk_n = 0, blk_m = 0;
@@ -171,7 +176,12 @@ int do_draw_f(gpirt_sampler_s* s)
         // as well; with all 1024 columns it waits for the product (whose 256 work-groups would starve it).
         const bool early = prep && m <= 128;
         if (early) GP_HIP(hipEventRecord(s->ev_trmm, st));
-        GP_TRY(launch_item_uniforms(st, s->opt.seed, iter, GPIRT_ST_F_Z, (uint32_t)s->opt.item0, m, n, s->Z, true));
+        if (s->z_filled_iter == iter && s->ev_zfill) {
+            GP_HIP(hipStreamWaitEvent(st, s->ev_zfill, 0));       // filled behind the previous factorisation (do_factor)
+        } else {
+            GP_TRY(launch_item_uniforms(st, s->opt.seed, iter, GPIRT_ST_F_Z, (uint32_t)s->opt.item0, m, n, s->Z, true));
+        }
+        s->z_filled_iter = 0;
         GP_TRY(launch_gemm(h, st, false, false, TRI_A_LOWER, n, m, n, 1.0, s->L, s->ldl, s->Z, n, 0.0, s->NU, n));
         if (prep && !early) GP_HIP(hipEventRecord(s->ev_trmm, st));
         EssArgs a{};
@@ -215,6 +225,11 @@ int fstar_prep(gpirt_sampler_s* s, gpirt_handle_t hh)
     double* Cu = s->rhs + (size_t)n * r;
     const double* Bt = s->L + n;
     GP_TRY(launch_transpose(st, Bt, r, n, s->ldl, Cu, n));
+    if (hh == s->haux && s->inv_built_pairs > 0 && hh->trsm_winv_L != s->L) {
+        // most of the block inverses were built while the last outer panel was being factored (do_factor): the rest now
+        GP_TRY(trsm_inverses_build(hh, st, s->L, n, s->ldl, true, s->inv_built_pairs, (n / 256) / 2));
+        trsm_inverses_mark(hh, s->L, n, s->ldl, true);
+    }
     // the block inverses of L are reused when this handle already holds them (built by an earlier solve against the
     // same factor) -- invalidate_factor_products() clears that whenever L changes
     GP_TRY(launch_trsm_lower(hh, st, s->L, n, s->ldl, Cu, r, n, true, true));
@@ -357,6 +372,7 @@ int do_draw_beta(gpirt_sampler_s* s)
 void invalidate_factor_products(gpirt_sampler_s* s)
 {
     s->prep_valid = false;
+    s->inv_built_pairs = 0;
     if (s->h->trsm_winv_L == s->L) s->h->trsm_winv_L = nullptr;
     if (s->haux && s->haux->trsm_winv_L == s->L) s->haux->trsm_winv_L = nullptr;
 }
@@ -400,7 +416,33 @@ int do_factor(gpirt_sampler_s* s)
     invalidate_factor_products(s);
     GP_TRY(build_cov(s));                                                                                  // :76-77
     s->rows_valid = true;
-    return launch_potrf_lower(s->h, st, s->L, s->n, s->ldl, false, !s->sticky_info, s->ext);              // :78
+    GP_TRY(launch_potrf_lower(s->h, st, s->L, s->n, s->ldl, false, !s->sticky_info, s->ext));             // :78
+    // The low-rank draw_fstar's transposed solve (fstar_prep) goes through the inverses of L's 1024 x 1024 diagonal blocks:
+    // ~5 GFLOP to build at n = 8192, and they only need the DIAGONAL blocks, final panel by panel.  Those of every outer
+    // panel but the last are built on the sampler's own stream while the last outer panel is factored (16 + 8 whole-CU
+    // work-groups and small updates: most of the chip is idle then); only the last block and the solve are left behind.
+    const char* ei = getenv("GPIRT_EARLY_INV");        // (read per call: tests switch it inside one process)
+    const bool early_inv = !(ei && atoi(ei) == 2);
+    if (early_inv && s->haux && s->kr > 0 && s->ext > 0 && !s->ext_grid && !stream_mode(s) && s->h->prelast_cols >= 2048) {
+        const int64_t p1 = (s->h->prelast_cols / 512) & ~(int64_t)1;
+        hipStream_t ax = s->haux->stream;
+        GP_HIP(hipStreamWaitEvent(ax, s->h->ev_prelast, 0));
+        GP_TRY(trsm_inverses_reserve(s->haux, ax, s->n, s->kr, true));
+        GP_TRY(trsm_inverses_build(s->haux, ax, s->L, s->n, s->ldl, true, 0, p1));
+        s->inv_built_pairs = p1;
+    }
+    if (early_inv && s->initialised && s->haux && s->ev_zfill && !stream_mode(s) && s->h->prelast_cols >= 2048) {
+        // (not from gpirt_sampler_init: it fills Z itself for the initial f right behind its factorisation)
+        // ... and the next draw_f's N(0,1) draws (the factorisation closes iteration s->iter + 1; the next draw_f is
+        // iteration s->iter + 2).  Z was last read by this iteration's nu = L z, long finished on the main stream.
+        hipStream_t ax = s->haux->stream;
+        const uint32_t next_iter = (uint32_t)(s->iter + 2);
+        GP_HIP(hipStreamWaitEvent(ax, s->h->ev_prelast, 0));
+        GP_TRY(launch_item_uniforms(ax, s->opt.seed, next_iter, GPIRT_ST_F_Z, (uint32_t)s->opt.item0, s->m, s->n, s->Z, true));
+        GP_HIP(hipEventRecord(s->ev_zfill, ax));
+        s->z_filled_iter = next_iter;
+    }
+    return 0;
 }
 
 // draw_theta's CDF came out 0/0 for some respondents: the reference reads theta_star[N] out of bounds there
@@ -564,7 +606,8 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
         if ((getenv("GPIRT_AUX_PRIO") && atoi(getenv("GPIRT_AUX_PRIO")) == 2 ? gpirt_create_own_stream(&s->haux, h->device)
                                                                             : create_side_handle(&s->haux, h->device)) != 0 ||
             hipEventCreateWithFlags(&s->ev_trmm, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&s->ev_prep, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&s->ev_prep, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s->ev_zfill, hipEventDisableTiming) != hipSuccess) {
             gpirt_sampler_destroy(s);
             return GPIRT_E_HIP;
         }
@@ -583,6 +626,7 @@ int gpirt_sampler_destroy(gpirt_sampler_t s)
     if (s->haux) { hipStreamSynchronize(s->haux->stream); gpirt_destroy(s->haux); }
     if (s->ev_trmm) hipEventDestroy(s->ev_trmm);
     if (s->ev_prep) hipEventDestroy(s->ev_prep);
+    if (s->ev_zfill) hipEventDestroy(s->ev_zfill);
     for (void* p : s->allocs) hipFree(p);
     if (s->hU) hipHostFree(s->hU);
     if (s->h_pos) hipHostFree(s->h_pos);

@@ -371,29 +371,35 @@ int trsm_inverses_reserve(gpirt_handle_t h, hipStream_t stream, int64_t n, int64
     return 0;
 }
 
-// Inverses of ALL of L's 512 x 512 diagonal blocks (the odd 256-row block behind the last pair included), into
-// h->d_trsm_winv / d_trsm_wquad:
+// Inverses of L's diagonal blocks for the 512-block pairs [p0, p1) (p = index of a 512 x 512 diagonal block; the odd
+// 256-row block behind the last pair rides with the last range), into h->d_trsm_winv / d_trsm_wquad:
 //  1. the full 256 x 256 diagonal blocks: ONE batched launch of the fused leaf on identity right-hand sides
 //     (4 work-groups per block), written straight into the diagonal quarters of the 512 x 512 slots;
 //  2. the lower-left quarter of each slot,  -W2 (L21 W1),  as two batched 256^3 MFMA products;
 //  3. thin solves (few right-hand sides are launch-bound, not flop-bound): pairs of 512-blocks merged into 1024 x 1024
 //     inverses (two more batched products), which halves the leaves and drops a recursion level.
-// (Building them panel by panel behind the factorisation was measured in round 2 and dropped -- the backward solve
-// starts with the LAST diagonal block -- so there is no partial-range form.)
-int trsm_inverses_build(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t n, int64_t ldl, bool thin)
+// A range only reads the diagonal blocks it inverts, so the blocks of every outer panel but the last are built while the
+// LAST outer panel is still being factored -- a phase that leaves most of the chip idle -- on the sampler's own stream
+// (sampler.hip, do_factor; round 3), and only the last range + the solve follow the factorisation.  p0 must be even when
+// `thin`.  tests/test_gpu_ops.py::test_trsm_inverses_piecewise compares a piecewise build with the one-range build.
+int trsm_inverses_build(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t n, int64_t ldl, bool thin,
+                        int64_t p0, int64_t p1)
 {
     const int64_t nfull = n / NL4, npair = nfull / 2;
-    if (nfull == 0) return 0;
+    if (p1 > npair) p1 = npair;
+    if (p0 >= p1 && !(p1 == npair && (nfull & 1))) return 0;
     double* W = h->d_trsm_winv;
-    // every full 256-block (the odd one behind the last pair included)
-    hipLaunchKernelGGL((trsm_leaf256_kernel<false, true>), dim3(NL4 / CB, (unsigned)nfull), dim3(256), 0, stream,
-                           L, ldl, NL4, W, (int64_t)NI, (int64_t)NL4,
+    // 256-blocks 2 p0 .. 2 p1 - 1 (+ the odd one when this range closes the matrix)
+    const int64_t b0 = 2 * p0, b1 = (p1 == npair) ? nfull : 2 * p1;
+    if (b1 > b0)
+        hipLaunchKernelGGL((trsm_leaf256_kernel<false, true>), dim3(NL4 / CB, (unsigned)(b1 - b0)), dim3(256), 0, stream,
+                           L + b0 * (int64_t)NL4 * (ldl + 1), ldl, NL4, W + p0 * (int64_t)NI * NI, (int64_t)NI, (int64_t)NL4,
                            (long long*)nullptr, (int64_t)NL4 * (ldl + 1), (int64_t)NI * NI, (int64_t)NL4 * (NI + 1));
-    const int np = (int)npair;
+    const int np = (int)(p1 - p0);
     if (np > 0) {
-        const double* Lp = L;
-        double* Wp = W;
-        double* Tp = h->d_trsm_tmp;
+        const double* Lp = L + p0 * (int64_t)NI * (ldl + 1);
+        double* Wp = W + p0 * (int64_t)NI * NI;
+        double* Tp = h->d_trsm_tmp + p0 * (int64_t)NL4 * NL4;
         // T_b = L21 W1
         GP_TRY(launch_gemm_batched(stream, false, false, TRI_NONE, NL4, NL4, NL4, 1.0,
                                    Lp + NL4, ldl, (int64_t)NI * (ldl + 1), Wp, NI, (int64_t)NI * NI,
@@ -404,7 +410,7 @@ int trsm_inverses_build(gpirt_handle_t h, hipStream_t stream, const double* L, i
                                    (int64_t)NL4 * NL4, 0.0, Wp + NL4, NI, (int64_t)NI * NI, np));
     }
     if (thin && npair >= 2) {
-        const int64_t q0 = 0, q1 = npair / 2;
+        const int64_t q0 = p0 / 2, q1 = (p1 / 2 < npair / 2) ? p1 / 2 : npair / 2;
         const int nq = (int)(q1 - q0);
         if (nq > 0) {
             double* Wq = h->d_trsm_wquad + q0 * (int64_t)NQ * NQ;
@@ -423,6 +429,13 @@ int trsm_inverses_build(gpirt_handle_t h, hipStream_t stream, const double* L, i
     }
     GP_HIP(hipGetLastError());
     return 0;
+}
+
+void trsm_inverses_mark(gpirt_handle_t h, const double* L, int64_t n, int64_t ldl, bool thin)
+{
+    const int64_t npair = (n / NL4) / 2;
+    h->trsm_winv_L = L; h->trsm_winv_n = n; h->trsm_winv_ld = ldl;
+    h->trsm_quads = (thin && npair >= 2) ? npair / 2 : 0;
 }
 
 // reuse_inverses: the block inverses built by the previous call on this handle are still those of L (same L,
@@ -444,7 +457,7 @@ int launch_trsm_lower(gpirt_handle_t h, hipStream_t stream, const double* L, int
         winv = h->d_trsm_winv;
     } else if (use_inv && nfull >= 2 && nrhs >= 64) {
         GP_TRY(trsm_inverses_reserve(h, stream, n, nrhs, thin));
-        GP_TRY(trsm_inverses_build(h, stream, L, n, ldl, thin));
+        GP_TRY(trsm_inverses_build(h, stream, L, n, ldl, thin, 0, npair));
         winv = h->d_trsm_winv;
         h->trsm_winv_L = L; h->trsm_winv_n = n; h->trsm_winv_ld = ldl;
         h->trsm_quads = (thin && npair >= 2) ? npair / 2 : 0;
