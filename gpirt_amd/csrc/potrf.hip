@@ -321,9 +321,10 @@ int win_setup(gpirt_handle_t h)
     GP_HIP(hipMalloc(&h->d_chain_ws, (size_t)4 * 1024 * 1024 * sizeof(double)));
     GP_HIP(hipMemsetAsync(h->d_ready, 0, 4 * sizeof(unsigned long long), h->side));
     GP_HIP(hipStreamSynchronize(h->side));
-    // the PRE launches spin on chain A / chain B for flags raised from chain A / near, and what raises them waits for
-    // events of rows / main: a spinner must not sit in front of any of those in a shared hardware queue
+    // the PRE launches (GPIRT_WIN_PRE=1) spin on chain A / chain B for flags raised from chain A / near, and what raises
+    // them waits for events of rows / main: a spinner must not sit in front of any of those in a shared hardware queue
     int ok = 1, r = 0;
+    if (!(getenv("GPIRT_WIN_PRE") && atoi(getenv("GPIRT_WIN_PRE")) == 1)) { h->win_state = 1; return 0; }
     int* d_res = reinterpret_cast<int*>(h->d_ready + 2);
     hipStream_t spin[2] = { h->side, h->chainb_stream };
     hipStream_t others[4] = { h->near_stream, h->rows_stream, h->stream, nullptr };
@@ -379,7 +380,11 @@ int potrf_windowed(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, i
     enum { E_CA = 0, E_CB = 2, E_NB = 4, E_RB = 6, E_DEF = 8, E_MW = 10, E_UW = 11 };   // [+ parity of p]
     unsigned long long* readyA = h->d_ready;
     unsigned long long* readyB = h->d_ready + 1;
-    static const bool pre = !(getenv("GPIRT_WIN_PRE") && atoi(getenv("GPIRT_WIN_PRE")) == 0);
+    // PRE launches are OFF unless GPIRT_WIN_PRE=1: they measured slower still (6.0 against 5.6 ms) and, once in a full test
+    // session (many streams created and destroyed by then), a pre-launched chain kernel's bounded wait for its flag
+    // expired -- the hang guard reported it instead of hanging -- although the queue probe had passed for this handle.
+    // Without them every spinning launch only waits for work enqueued BEFORE it: no dependence on the queue mapping.
+    static const bool pre = (getenv("GPIRT_WIN_PRE") && atoi(getenv("GPIRT_WIN_PRE")) == 1);
     GP_HIP(hipEventRecord(h->ev_fork, stream));
     GP_HIP(hipStreamWaitEvent(S.chainA, h->ev_fork, 0));
     GP_HIP(hipStreamWaitEvent(S.chainB, h->ev_fork, 0));

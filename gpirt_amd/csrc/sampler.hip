@@ -68,6 +68,12 @@ struct gpirt_sampler_s {
     // while the last outer panel is factored; z_filled_iter = the iteration they belong to (0: none), ev_zfill fires when done
     uint32_t z_filled_iter = 0;
     hipEvent_t ev_zfill = nullptr;
+    // draw_beta (+ mu, mu_star) needs theta and f but nothing of the factorisation that follows it: it is held back
+    // (beta_deferred) until the factorisation has been enqueued and then runs on the sampler's own stream in the same idle
+    // phase; beta_pending: the main stream has not yet waited for it (ev_beta).  Anything that reads or writes beta, mu,
+    // mu_star, theta or f first flushes / joins it (beta_sync).
+    bool beta_deferred = false, beta_pending = false;
+    hipEvent_t ev_beta = nullptr;
     // respondent-block form of draw_theta for item-sharded runs (gpirt_sampler_set_theta_block): this rank's
     // block of respondents with ALL items
     int64_t blk_i0 = 0, blk_n = 0, blk_m = 0;
@@ -162,6 +168,7 @@ __global__ void trmv_lower_kernel(const double* __restrict__ L, int64_t n, int64
 
 int fstar_prep(gpirt_sampler_s* s, gpirt_handle_t hh);
 int rebuild_rows(gpirt_sampler_s* s);
+int beta_sync(gpirt_sampler_s* s);
 
 int do_draw_f(gpirt_sampler_s* s)
 {
@@ -169,6 +176,7 @@ int do_draw_f(gpirt_sampler_s* s)
     hipStream_t st = h->stream;
     const int64_t n = s->n, m = s->m;
     const uint32_t iter = (uint32_t)(s->iter + 1);
+    GP_TRY(beta_sync(s));                     // mu of the previous iteration's draw_beta
     if (!stream_mode(s)) {
         const bool prep = s->haux && s->ext > 0 && !s->ext_grid && s->rows_valid && !s->prep_valid;
         // With few item columns on this rank (m <= 128: eight GPUs at the metric size) the product below does not
@@ -245,6 +253,7 @@ int do_draw_fstar(gpirt_sampler_s* s, uint32_t iter)
     double* tmp = s->rhs;                    // n x N : L^-1 kstar
     double* W = s->rhs + (size_t)n * N;      // n x m : L^-1 f, then L^-T L^-1 f
     const bool fused = s->opt.fstar_fused != 0;
+    GP_TRY(beta_sync(s));                     // mu_star
     GP_TRY(rebuild_rows(s));
     if (s->kr > 0) {
         // K*^T = U V^T exactly (see gpirt_sampler_create), so with B = L^-1 U and C = L^-T B = S^-1 U:
@@ -354,9 +363,8 @@ int do_theta_block(gpirt_sampler_s* s)
     return launch_theta_sample(st, a);
 }
 
-int do_draw_beta(gpirt_sampler_s* s)
+int launch_beta_on(gpirt_sampler_s* s, hipStream_t st)
 {
-    hipStream_t st = s->h->stream;
     BetaArgs a{};
     a.beta = s->beta; a.theta = s->theta; a.y = s->y; a.f = s->f; a.pm = s->pm; a.ps = s->ps;
     a.step = s->step; a.n = s->n; a.m = s->m; a.N = s->N; a.mu = s->mu; a.mu_star = s->mu_star;
@@ -366,6 +374,29 @@ int do_draw_beta(gpirt_sampler_s* s)
     GP_TRY(launch_draw_beta(st, a));
     if (stream_mode(s)) GP_TRY(launch_advance_pos(st, s->pos, s->beta_total));
     return 0;
+}
+
+// a deferred draw_beta runs NOW on the main stream; one already running on the sampler's stream is joined
+int beta_sync(gpirt_sampler_s* s)
+{
+    if (s->beta_deferred) {
+        s->beta_deferred = false;
+        GP_TRY(launch_beta_on(s, s->h->stream));
+    }
+    if (s->beta_pending) {
+        GP_HIP(hipStreamWaitEvent(s->h->stream, s->ev_beta, 0));
+        s->beta_pending = false;
+    }
+    return 0;
+}
+
+int do_draw_beta(gpirt_sampler_s* s)
+{
+    const char* ei = getenv("GPIRT_EARLY_INV");
+    const bool defer = !(ei && atoi(ei) == 2) && !stream_mode(s) && s->haux && s->ev_beta && s->initialised;
+    GP_TRY(beta_sync(s));
+    if (defer) { s->beta_deferred = true; return 0; }     // do_factor launches it behind the factorisation's last outer panel
+    return launch_beta_on(s, s->h->stream);
 }
 
 // everything derived from the factor (C, G, cached block inverses on either handle) is stale once L changes
@@ -378,10 +409,11 @@ void invalidate_factor_products(gpirt_sampler_s* s)
 }
 
 // the main stream waits for whatever the sampler's own stream still has in flight
-int aux_join(gpirt_sampler_s* s)
+int aux_join(gpirt_sampler_s* s, bool beta_too = true)
 {
     hipStream_t st = s->h->stream;
     if (s->prep_pending) { GP_HIP(hipStreamWaitEvent(st, s->ev_prep, 0)); s->prep_pending = false; }
+    if (beta_too) GP_TRY(beta_sync(s));
     return 0;
 }
 
@@ -412,7 +444,8 @@ int rebuild_rows(gpirt_sampler_s* s)
 int do_factor(gpirt_sampler_s* s)
 {
     hipStream_t st = s->h->stream;
-    GP_TRY(aux_join(s));                  // nothing of the old factor may still be read when it is overwritten
+    GP_TRY(aux_join(s, false));           // nothing of the old factor may still be read when it is overwritten (a held-back
+                                          // draw_beta does not read it: it is launched below, behind the factorisation)
     invalidate_factor_products(s);
     GP_TRY(build_cov(s));                                                                                  // :76-77
     s->rows_valid = true;
@@ -441,6 +474,20 @@ int do_factor(gpirt_sampler_s* s)
         GP_TRY(launch_item_uniforms(ax, s->opt.seed, next_iter, GPIRT_ST_F_Z, (uint32_t)s->opt.item0, s->m, s->n, s->Z, true));
         GP_HIP(hipEventRecord(s->ev_zfill, ax));
         s->z_filled_iter = next_iter;
+    }
+    if (s->beta_deferred) {
+        // draw_beta of THIS iteration (do_draw_beta held it back): beside the last outer panel on the sampler's stream
+        // when there is such a phase, otherwise right here on the main stream
+        s->beta_deferred = false;
+        if (s->haux && s->h->prelast_cols >= 2048) {
+            hipStream_t ax = s->haux->stream;
+            GP_HIP(hipStreamWaitEvent(ax, s->h->ev_prelast, 0));       // (causally behind theta and f on the main stream)
+            GP_TRY(launch_beta_on(s, ax));
+            GP_HIP(hipEventRecord(s->ev_beta, ax));
+            s->beta_pending = true;
+        } else {
+            GP_TRY(launch_beta_on(s, st));
+        }
     }
     return 0;
 }
@@ -607,7 +654,8 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
                                                                             : create_side_handle(&s->haux, h->device)) != 0 ||
             hipEventCreateWithFlags(&s->ev_trmm, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s->ev_prep, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&s->ev_zfill, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&s->ev_zfill, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s->ev_beta, hipEventDisableTiming) != hipSuccess) {
             gpirt_sampler_destroy(s);
             return GPIRT_E_HIP;
         }
@@ -627,6 +675,7 @@ int gpirt_sampler_destroy(gpirt_sampler_t s)
     if (s->ev_trmm) hipEventDestroy(s->ev_trmm);
     if (s->ev_prep) hipEventDestroy(s->ev_prep);
     if (s->ev_zfill) hipEventDestroy(s->ev_zfill);
+    if (s->ev_beta) hipEventDestroy(s->ev_beta);
     for (void* p : s->allocs) hipFree(p);
     if (s->hU) hipHostFree(s->hU);
     if (s->h_pos) hipHostFree(s->h_pos);
@@ -792,6 +841,7 @@ int gpirt_sampler_build_cov(gpirt_sampler_t s)
 int gpirt_sampler_adopt_factor(gpirt_sampler_t s, int rows_with_L)
 {
     GP_ARG(s && s->initialised);
+    GP_TRY(beta_sync(s));                // a held-back draw_beta belongs to the iteration that closes here
     invalidate_factor_products(s);
     s->rows_valid = rows_with_L != 0;
     s->iter += 1;
@@ -851,6 +901,7 @@ int gpirt_sampler_check(gpirt_sampler_t s)
     GP_ARG(s != nullptr);
     gpirt_handle_t h = s->h;
     hipStream_t st = h->stream;
+    GP_TRY(aux_join(s));                  // the flags of work still running on the sampler's own stream
     GP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
     GP_HIP(hipMemcpyAsync(s->h_flags, s->flags, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     GP_HIP(hipStreamSynchronize(st));
@@ -1083,6 +1134,7 @@ int gpirt_mcmc(const double* h_y, int64_t n, int64_t m, const double* h_theta0, 
     };
     auto snapshot = [&]() -> int {                          // enqueue on the compute stream
         hipStream_t st = h->stream;
+        if (beta_sync(s) != 0) return fail_hip("draw_beta join");
         if (hipMemcpyAsync(snap_f, s->f, sizeof(double) * (size_t)(n * m), hipMemcpyDeviceToDevice, st) != hipSuccess ||
             hipMemcpyAsync(snap_small, s->theta, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st) != hipSuccess ||
             hipMemcpyAsync(snap_small + n, s->beta, sizeof(double) * (size_t)(2 * m), hipMemcpyDeviceToDevice, st) != hipSuccess ||

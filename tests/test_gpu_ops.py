@@ -137,8 +137,9 @@ def test_potrf_previous_panel_kernel_agrees():
 
 @pytest.mark.parametrize("n", [2560, 3100, 4160, 8192])
 def test_potrf_windowed_schedule_agrees(handle, n):
-    """GPIRT_SCHED=2 (potrf.hip: the sub-panel split into a chain launch on the outer panel's own rows, pre-launched and
-    flag-started, + panel_rows_kernel -- lean 32-row work-groups -- on the rows below, five streams) against the default
+    """GPIRT_SCHED=2 (potrf.hip: the sub-panel split into a chain launch on the outer panel's own rows +
+    panel_rows_kernel -- lean 32-row work-groups -- on the rows below, five streams; the pre-launched, flag-started form
+    of the chain launches stays behind GPIRT_WIN_PRE=1 and is not part of this test) against the default
     one-kernel-per-sub-panel schedule.  Every product is the same except the two small split-K updates on the chain and
     the undivided K = 1024 update of the next panel's first columns: L agrees to rounding (1e-12), factors the same
     matrix to the same residual, and the schedule never trips the hang guard.  (Opt-in: it measured slower)"""
