@@ -180,6 +180,7 @@ int gpirt_destroy(gpirt_handle_t h)
     if (h->ev_a) hipEventDestroy(h->ev_a);
     if (h->ev_half) hipEventDestroy(h->ev_half);
     if (h->ev_prelast) hipEventDestroy(h->ev_prelast);
+    if (h->aux) { hipStreamSynchronize(h->aux->stream); gpirt_destroy(h->aux); h->aux = nullptr; }
     if (h->rows_stream) hipStreamDestroy(h->rows_stream);
     if (h->near_stream) hipStreamDestroy(h->near_stream);
     if (h->chainb_stream) hipStreamDestroy(h->chainb_stream);

@@ -70,6 +70,13 @@ struct gpirt_handle_s {
     // look-ahead Cholesky: high-priority side stream for the panel chain + fork/join events
     hipStream_t  side = nullptr;
     hipEvent_t   ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr, ev_a = nullptr, ev_half = nullptr;
+    // The samplers' side work (the factor-only part of draw_fstar, block inverses, the next draw_f's normals, draw_beta) runs
+    // on ONE high-priority handle per main handle, shared by every sampler created on it (samplers of a handle are driven
+    // one after the other anyway).  Round 3: a handle per SAMPLER meant a new high-priority stream per sampler, and with
+    // three samplers alive on one handle every stage of the third ran 1.3-1.9x slower (tools/two_samplers_probe.py).
+    gpirt_handle_t aux = nullptr;
+    const double* inv_partial_L = nullptr;   // (on the aux handle) the factor whose block inverses are PARTLY built ...
+    int64_t      inv_partial_pairs = 0;      //   ... 512-block pairs [0, inv_partial_pairs)
     hipEvent_t   ev_prelast = nullptr;    // fires when every outer panel but the last is final (columns [0, prelast_cols))
     int64_t      prelast_cols = 0;        //   ... of the factorisation enqueued last (0: no such point, e.g. a single panel)
     // persistent panel kernel (panel.hip): one progress counter per 64-row block, epoch-tagged

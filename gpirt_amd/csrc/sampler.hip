@@ -57,13 +57,12 @@ struct gpirt_sampler_s {
     bool ext_grid = false, rows_valid = false;
     // Work that needs only L (not this iteration's f) runs on a stream of the sampler's own, beside draw_f's elliptical
     // slice kernel: the part of the low-rank draw_fstar that depends on the factor alone (C = L^-T B, G = B^T B).
-    // haux is a private handle on that stream (its own trsm / split-K workspaces: several
+    // haux is the main handle's side handle (h->aux, shared by the samplers of that handle, not owned) on that stream (its own trsm / split-K workspaces: several
     // samplers may share `h`).  prep_valid: C and G belong to the current L; *_pending: the main stream has not yet
     // waited for the event.
     gpirt_handle_t haux = nullptr;
     hipEvent_t ev_trmm = nullptr, ev_prep = nullptr;
     bool prep_valid = false, prep_pending = false;
-    int64_t inv_built_pairs = 0;      // 512-block pairs of L whose inverses haux already holds (built behind the factorisation)
     // the N(0,1) draws of the NEXT draw_f depend on (seed, iteration, item, index) only: filled on the sampler's own stream
     // while the last outer panel is factored; z_filled_iter = the iteration they belong to (0: none), ev_zfill fires when done
     uint32_t z_filled_iter = 0;
@@ -233,10 +232,13 @@ int fstar_prep(gpirt_sampler_s* s, gpirt_handle_t hh)
     double* Cu = s->rhs + (size_t)n * r;
     const double* Bt = s->L + n;
     GP_TRY(launch_transpose(st, Bt, r, n, s->ldl, Cu, n));
-    if (hh == s->haux && s->inv_built_pairs > 0 && hh->trsm_winv_L != s->L) {
-        // most of the block inverses were built while the last outer panel was being factored (do_factor): the rest now
-        GP_TRY(trsm_inverses_build(hh, st, s->L, n, s->ldl, true, s->inv_built_pairs, (n / 256) / 2));
+    if (hh == s->haux && hh->inv_partial_L == s->L && hh->inv_partial_pairs > 0 && hh->trsm_winv_L != s->L) {
+        // most of the block inverses were built while the last outer panel was being factored (do_factor): the rest now.
+        // (inv_partial_L lives on the shared side handle: another sampler's early build in between resets it, and this
+        // one then rebuilds everything below, in launch_trsm_lower.)
+        GP_TRY(trsm_inverses_build(hh, st, s->L, n, s->ldl, true, hh->inv_partial_pairs, (n / 256) / 2));
         trsm_inverses_mark(hh, s->L, n, s->ldl, true);
+        hh->inv_partial_L = nullptr; hh->inv_partial_pairs = 0;
     }
     // the block inverses of L are reused when this handle already holds them (built by an earlier solve against the
     // same factor) -- invalidate_factor_products() clears that whenever L changes
@@ -403,7 +405,7 @@ int do_draw_beta(gpirt_sampler_s* s)
 void invalidate_factor_products(gpirt_sampler_s* s)
 {
     s->prep_valid = false;
-    s->inv_built_pairs = 0;
+    if (s->haux && s->haux->inv_partial_L == s->L) { s->haux->inv_partial_L = nullptr; s->haux->inv_partial_pairs = 0; }
     if (s->h->trsm_winv_L == s->L) s->h->trsm_winv_L = nullptr;
     if (s->haux && s->haux->trsm_winv_L == s->L) s->haux->trsm_winv_L = nullptr;
 }
@@ -461,8 +463,9 @@ int do_factor(gpirt_sampler_s* s)
         hipStream_t ax = s->haux->stream;
         GP_HIP(hipStreamWaitEvent(ax, s->h->ev_prelast, 0));
         GP_TRY(trsm_inverses_reserve(s->haux, ax, s->n, s->kr, true));
+        s->haux->trsm_winv_L = nullptr;                      // whatever the side handle held is being overwritten
         GP_TRY(trsm_inverses_build(s->haux, ax, s->L, s->n, s->ldl, true, 0, p1));
-        s->inv_built_pairs = p1;
+        s->haux->inv_partial_L = s->L; s->haux->inv_partial_pairs = p1;
     }
     if (early_inv && s->initialised && s->haux && s->ev_zfill && !stream_mode(s) && s->h->prelast_cols >= 2048) {
         // (not from gpirt_sampler_init: it fills Z itself for the initial f right behind its factorisation)
@@ -650,8 +653,13 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
         set_error("sampler upload failed"); gpirt_sampler_destroy(s); return GPIRT_E_HIP;
     }
     if (!stream_mode(s) && !(getenv("GPIRT_AUX") && atoi(getenv("GPIRT_AUX")) == 2)) {
-        if ((getenv("GPIRT_AUX_PRIO") && atoi(getenv("GPIRT_AUX_PRIO")) == 2 ? gpirt_create_own_stream(&s->haux, h->device)
-                                                                            : create_side_handle(&s->haux, h->device)) != 0 ||
+        if (!h->aux && (getenv("GPIRT_AUX_PRIO") && atoi(getenv("GPIRT_AUX_PRIO")) == 2 ? gpirt_create_own_stream(&h->aux, h->device)
+                                                                                         : create_side_handle(&h->aux, h->device)) != 0) {
+            gpirt_sampler_destroy(s);
+            return GPIRT_E_HIP;
+        }
+        s->haux = h->aux;
+        if (
             hipEventCreateWithFlags(&s->ev_trmm, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s->ev_prep, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s->ev_zfill, hipEventDisableTiming) != hipSuccess ||
@@ -671,7 +679,12 @@ int gpirt_sampler_destroy(gpirt_sampler_t s)
 {
     if (!s) return 0;
     if (s->h) hipStreamSynchronize(s->h->stream);
-    if (s->haux) { hipStreamSynchronize(s->haux->stream); gpirt_destroy(s->haux); }
+    if (s->haux) {
+        hipStreamSynchronize(s->haux->stream);       // (the side handle belongs to the main handle: not destroyed here)
+        if (s->haux->trsm_winv_L == s->L) s->haux->trsm_winv_L = nullptr;
+        if (s->haux->inv_partial_L == s->L) { s->haux->inv_partial_L = nullptr; s->haux->inv_partial_pairs = 0; }
+    }
+    if (s->h && s->h->trsm_winv_L == s->L) s->h->trsm_winv_L = nullptr;
     if (s->ev_trmm) hipEventDestroy(s->ev_trmm);
     if (s->ev_prep) hipEventDestroy(s->ev_prep);
     if (s->ev_zfill) hipEventDestroy(s->ev_zfill);
