@@ -667,11 +667,13 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
                 done_col.push_back(c2);                                   // this panel: [c1, c2) done above
                 static const int ahead = env_int("GPIRT_DEFER_AHEAD", 1);  // block columns brought up to date per step
                 const int64_t horizon = (c2 + ahead * nbo < n) ? c2 + ahead * nbo : n;
-                // GPIRT_DEFER_SPLIT=1: each of these launches is cut in two by rows -- the upper slab (with the trapezoid on
-                // the diagonal) stays on this stream, the lower one goes to a second stream.  Different rows of a block
+                // Each of these launches is cut in two by rows (GPIRT_DEFER_SPLIT=2: not) -- the upper slab (with the trapezoid
+                // on the diagonal) stays on this stream, the lower one goes to a second stream.  Different rows of a block
                 // column are independent, so the two slabs form two chains of launches whose partial last rounds (a
-                // launch of 868 64-tiles on 768 slots takes two rounds) fill each other.  Same products per element.
-                static const int defer_split = env_int("GPIRT_DEFER_SPLIT", 0);
+                // launch of 868 64-tiles on 768 slots takes two rounds) fill each other.  Same products per element: L
+                // bit-identical (tools/factor_hash.py).  Small and consistent: 7.38 -> 7.35 ms per iteration at the metric
+                // size in four alternating A/B runs, 13.08 -> 12.84 ms for the factorisation at n = 12288.
+                static const int defer_split = env_int("GPIRT_DEFER_SPLIT", 1);
                 bool forked = false;
                 for (size_t q = 0; q < done_col.size(); ++q)
                     if (done_col[q] < horizon) {
