@@ -69,3 +69,46 @@ def test_two_ranks_reproduce_single_process(tmp_path, chol, theta, m):
     assert np.abs(got["f"] - ref.gather("f")).max() < tol
     assert np.abs(got["beta"] - ref.gather("beta")).max() < tol
     assert np.abs(got["fstar"] - ref.gather("fstar")).max() < tol
+
+
+def _run3(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["GPIRT_DIST_DEBUG"] = "1"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from _oracle_engine import OracleEngine
+    from gpirt_amd.distributed import ShardedSampler
+    from gpirt_amd.synthetic import make_responses
+    y, th0 = make_responses(75, 10, seed=14)           # five 16-column outer panels, the last ragged (11 columns = sub-panels of 8 + 3)
+    ss = ShardedSampler(OracleEngine, y, th0, dist=dist, chol="distributed")
+    ss.init()
+    ss.step()
+    f, fstar = ss.gather("f"), ss.gather("fstar")
+    if rank == 0:
+        np.savez(os.path.join(outdir, "sharded3.npz"), f=f, fstar=fstar, theta=ss.engine.theta, L=ss.engine.L)
+    dist.destroy_process_group()
+
+
+def test_three_ranks_pipelined_distributed_factorisation(tmp_path):
+    """The factorisation pipelined by halves of a panel (gpirt_amd/distributed.py) with three ranks, five outer panels
+    (so ranks own 2 / 2 / 1 of them), a ragged last panel, unequal item shards (10 items over 3 ranks = 3 / 3 / 4: the
+    padded tensor-collective gather and the all-reduce form of the f* gather), with the joined-streams debug check on,
+    against the single-process run."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _oracle_engine import OracleEngine
+    from gpirt_amd.distributed import ShardedSampler
+    from gpirt_amd.synthetic import make_responses
+    port = 29300 + (os.getpid() % 2000)
+    mp.spawn(_run3, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    got = np.load(tmp_path / "sharded3.npz")
+    y, th0 = make_responses(75, 10, seed=14)
+    ref = ShardedSampler(OracleEngine, y, th0, dist=None)
+    ref.init()
+    ref.step()
+    assert np.array_equal(got["theta"], ref.engine.theta)
+    assert np.abs(got["L"] - ref.engine.L).max() < 1e-12
+    assert np.abs(np.triu(got["L"], 1)).max() == 0
+    assert np.abs(got["f"] - ref.gather("f")).max() < 1e-9
+    assert np.abs(got["fstar"] - ref.gather("fstar")).max() < 1e-9
