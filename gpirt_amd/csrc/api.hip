@@ -186,6 +186,7 @@ int gpirt_destroy(gpirt_handle_t h)
     if (h->chainb_stream) hipStreamDestroy(h->chainb_stream);
     if (h->d_ready) hipFree(h->d_ready);
     if (h->d_chain_ws) hipFree(h->d_chain_ws);
+    if (h->d_defer_ws) hipFree(h->d_defer_ws);
     for (auto& e : h->ev_pool) if (e) hipEventDestroy(e);
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;

@@ -87,6 +87,8 @@ struct gpirt_handle_s {
     hipStream_t  near_stream = nullptr;   //   ... and the rows of the NEXT outer panel (what the chain needs next)
     hipStream_t  chainb_stream = nullptr; //   ... second sub-panels' chain launches (pre-launched beside the first sub-panel's)
     unsigned long long* d_ready = nullptr;//   ... [2] ready flags of the pre-launched chain launches (first / second sub-panel)
+    double*      d_defer_ws = nullptr;    // potrf.hip: slabs of the panel-parallel deferred updates (launch_syrk_panels)
+    size_t       defer_ws_bytes = 0;
     double*      d_chain_ws = nullptr;    //   ... split-K parts of the small updates on the chain (4 x 1024 x 1024 doubles)
     int          win_state = 0;           //   ... 0 = not probed, 1 = streams on separate hardware queues (usable), 2 = not usable
     hipEvent_t   ev_pool[16] = {};        //   ... and the cross-stream events

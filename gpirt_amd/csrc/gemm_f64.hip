@@ -677,6 +677,52 @@ int launch_syrk_splitk(hipStream_t stream, int64_t M, int64_t N, int64_t K, doub
     return 0;
 }
 
+// Several trailing updates of ONE block column by consecutive panels, as one launch: the panels' columns are contiguous in
+// memory, so  C -= sum_q P_q P_q^T  is a single product over K = parts * kpart cut at the panel boundaries (blockIdx.y picks
+// the panel).  Each part lands in its own slab of `work` as alpha * P_q P_q^T, and the sum kernel then applies them to C ONE
+// AFTER THE OTHER in panel order -- c = part_q + c, exactly what the epilogue of a separate launch per panel computes
+// (v = alpha * acc; v += beta * c with beta = 1) -- so the result is bit-identical to the sequential launches, while
+// the products themselves run side by side (potrf.hip, deferred updates: 2-7 dependent launches of 150-900 tiles each,
+// every one a partial round of the chip, become one grid).
+__global__ __launch_bounds__(256) void apply_parts_seq_lower_kernel(const double* __restrict__ part, int64_t M, int64_t N, int64_t stride,
+                                                                    int nparts, double* __restrict__ out, int64_t ldo)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * N) return;
+    const int64_t r = i % M, c = i / M;
+    if (r < c) return;
+    double* o = out + r + c * ldo;
+    double v = *o;
+    for (int q = 0; q < nparts; ++q) v = part[i + q * stride] + v;
+    *o = v;
+}
+
+int launch_syrk_panels(hipStream_t stream, int64_t M, int64_t N, int64_t kpart, int nparts, double alpha, const double* A,
+                       int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, double* work)
+{
+    if (M <= 0 || N <= 0 || nparts <= 0) return 0;
+    if (M < N || (kpart % BK) != 0) { set_error("launch_syrk_panels: needs M >= N and a part depth that is a multiple of 16"); return GPIRT_E_ARG; }
+    constexpr int T = 64;
+    GemmParams p;
+    p.A = A; p.B = B; p.C = work;
+    p.lda = lda; p.ldb = ldb; p.ldc = M;
+    p.M = (int)M; p.N = (int)N; p.K = (int)(kpart * nparts); p.Mr = 0;
+    p.alpha = alpha; p.beta = 0.0; p.tri = TRI_SYRK_LOWER;
+    p.fz_A = nullptr; p.fz_lda = 0; p.fz_nb = 0; p.fz_k0 = 0; p.fz_info = nullptr;
+    p.sA = p.sB = 0; p.sC = M * N;
+    p.ksplit = (int)kpart;
+    p.fastA = (((uintptr_t)A & 15) == 0) && (lda % 2 == 0);
+    p.fastB = (((uintptr_t)B & 15) == 0) && (ldb % 2 == 0);
+    p.mblocks = (p.M + T - 1) / T;
+    p.nblocks = (p.N + T - 1) / T;
+    const int64_t grid = (int64_t)p.nblocks * p.mblocks - (int64_t)p.nblocks * (p.nblocks - 1) / 2;
+    hipLaunchKernelGGL((gemm_f64_kernel<false, true, 64, 8>), dim3((unsigned)grid, (unsigned)nparts), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(apply_parts_seq_lower_kernel, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, stream, work, M, N, M * N,
+                       nparts, C, ldc);
+    GP_HIP(hipGetLastError());
+    return 0;
+}
+
 bool gemm_trailing_uses_128(int64_t M, int64_t N, bool background)
 {
     static const int tmin = getenv("GPIRT_TRAIL128_MIN") ? atoi(getenv("GPIRT_TRAIL128_MIN")) : 448;

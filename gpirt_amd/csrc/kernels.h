@@ -28,6 +28,10 @@ int launch_gemm_nosplit(hipStream_t stream, bool ta, bool tb, int64_t M, int64_t
 // lower trapezoid C (M x N, M >= N) = beta C + alpha A B^T with the K range cut into nsplit parts (work: nsplit * M * N doubles)
 int launch_syrk_splitk(hipStream_t stream, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
                        const double* B, int64_t ldb, double beta, double* C, int64_t ldc, double* work, int nsplit);
+// nparts consecutive trailing updates of one block column (panel q = columns [q * kpart, (q + 1) * kpart) of A / B) as one
+// launch + an in-order application: bit-identical to nparts separate launches (work: nparts * M * N doubles)
+int launch_syrk_panels(hipStream_t stream, int64_t M, int64_t N, int64_t kpart, int nparts, double alpha, const double* A,
+                       int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, double* work);
 int gemm_split_count(gpirt_handle_t h, hipStream_t stream, int tri, int64_t M, int64_t N, int64_t K);
 // split-K product for small M x N with long K: parts land in Cpart (+ q * strideC, each M x N with ldc == M),
 // then Cout (ldout) = beta_out * Cout + their sum

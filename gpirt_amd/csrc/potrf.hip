@@ -674,6 +674,32 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
                 // bit-identical (tools/factor_hash.py).  Small and consistent: 7.38 -> 7.35 ms per iteration at the metric
                 // size in four alternating A/B runs, 13.08 -> 12.84 ms for the factorisation at n = 12288.
                 static const int defer_split = env_int("GPIRT_DEFER_SPLIT", 1);
+                // GPIRT_DEFER_PAR (default 1; 2 = off): the step's updates of this block column by the panels 0 .. q are
+                // ONE grid -- their products side by side, applied to C one after the other in panel order
+                // (launch_syrk_panels: bit-identical to the separate launches below).  Every panel so far has brought the
+                // block column up to the same column (done_col), which is what makes them one product over contiguous K.
+                static const int defer_par = env_int("GPIRT_DEFER_PAR", 1);
+                bool same_lo = done_col.size() >= 2;
+                for (size_t q = 1; q < done_col.size(); ++q) same_lo = same_lo && done_col[q] == done_col[0];
+                if (defer_par == 1 && same_lo && done_col[0] < horizon && (nbo % 16) == 0) {
+                    const int64_t lo = done_col[0], M = nr - lo, N = horizon - lo;
+                    const int np = (int)done_col.size();
+                    const size_t need = (size_t)np * (size_t)M * (size_t)N * sizeof(double);
+                    if (h->defer_ws_bytes < need) {
+                        GP_HIP(hipStreamSynchronize(stream));
+                        GP_HIP(hipStreamSynchronize(h->side));
+                        if (h->d_defer_ws) GP_HIP(hipFree(h->d_defer_ws));
+                        h->d_defer_ws = nullptr; h->defer_ws_bytes = 0;
+                        const size_t want = need + need / 4;
+                        GP_HIP(hipMalloc(&h->d_defer_ws, want));
+                        h->defer_ws_bytes = want;
+                    }
+                    ProfPair pp;
+                    GP_TRY(prof_begin(h, stream, pp));
+                    GP_TRY(launch_syrk_panels(stream, M, N, nbo, np, -1.0, A + lo, lda, A + lo, lda, A + lo + lo * lda, lda, h->d_defer_ws));
+                    GP_TRY(prof_end(h, stream, pp, 1, M, N, (int64_t)np * nbo));      // (one pair: the np products + their application)
+                    for (size_t q = 0; q < done_col.size(); ++q) done_col[q] = horizon;
+                }
                 bool forked = false;
                 for (size_t q = 0; q < done_col.size(); ++q)
                     if (done_col[q] < horizon) {
