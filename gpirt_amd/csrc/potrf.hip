@@ -674,11 +674,14 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
                 // bit-identical (tools/factor_hash.py).  Small and consistent: 7.38 -> 7.35 ms per iteration at the metric
                 // size in four alternating A/B runs, 13.08 -> 12.84 ms for the factorisation at n = 12288.
                 static const int defer_split = env_int("GPIRT_DEFER_SPLIT", 1);
-                // GPIRT_DEFER_PAR (default 1; 2 = off): the step's updates of this block column by the panels 0 .. q are
-                // ONE grid -- their products side by side, applied to C one after the other in panel order
+                // GPIRT_DEFER_PAR=1 (off by default): the step's updates of this block column by the panels 0 .. q as ONE
+                // grid -- their products side by side, applied to C one after the other in panel order
                 // (launch_syrk_panels: bit-identical to the separate launches below).  Every panel so far has brought the
                 // block column up to the same column (done_col), which is what makes them one product over contiguous K.
-                static const int defer_par = env_int("GPIRT_DEFER_PAR", 1);
+                // Measured: +2 % on the factorisation at n = 12288, nothing at the metric size (the main stream has slack
+                // there), and the parts' round trip through the workspace takes the launches' memory traffic from 1.9x to
+                // 2.35x their algorithmic bytes -- so it stays a switch.
+                static const int defer_par = env_int("GPIRT_DEFER_PAR", 2);
                 bool same_lo = done_col.size() >= 2;
                 for (size_t q = 1; q < done_col.size(); ++q) same_lo = same_lo && done_col[q] == done_col[0];
                 if (defer_par == 1 && same_lo && done_col[0] < horizon && (nbo % 16) == 0) {
