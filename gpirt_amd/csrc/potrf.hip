@@ -667,13 +667,16 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
                 done_col.push_back(c2);                                   // this panel: [c1, c2) done above
                 static const int ahead = env_int("GPIRT_DEFER_AHEAD", 1);  // block columns brought up to date per step
                 const int64_t horizon = (c2 + ahead * nbo < n) ? c2 + ahead * nbo : n;
-                // Each of these launches is cut in two by rows (GPIRT_DEFER_SPLIT=2: not) -- the upper slab (with the trapezoid
-                // on the diagonal) stays on this stream, the lower one goes to a second stream.  Different rows of a block
+                // GPIRT_DEFER_SPLIT=1 (off by default): each of these launches is cut in two by rows -- the upper slab (with the
+                // trapezoid on the diagonal) stays on this stream, the lower one goes to a second stream.  Different rows of a block
                 // column are independent, so the two slabs form two chains of launches whose partial last rounds (a
                 // launch of 868 64-tiles on 768 slots takes two rounds) fill each other.  Same products per element: L
                 // bit-identical (tools/factor_hash.py).  Small and consistent: 7.38 -> 7.35 ms per iteration at the metric
-                // size in four alternating A/B runs, 13.08 -> 12.84 ms for the factorisation at n = 12288.
-                static const int defer_split = env_int("GPIRT_DEFER_SPLIT", 1);
+                // size in four alternating A/B runs, 13.08 -> 12.84 ms for the factorisation at n = 12288 -- within noise of
+                // nothing, while two launches that run side by side each measure (HIP events, rocprofv3) as long as both
+                // together, which makes every per-launch rate in bench.py's roofline read a quarter lower (0.45 -> 0.36)
+                // for the same work.  Not worth a misleading profile: a switch.
+                static const int defer_split = env_int("GPIRT_DEFER_SPLIT", 2);
                 // GPIRT_DEFER_PAR=1 (off by default): the step's updates of this block column by the panels 0 .. q as ONE
                 // grid -- their products side by side, applied to C one after the other in panel order
                 // (launch_syrk_panels: bit-identical to the separate launches below).  Every panel so far has brought the
