@@ -67,7 +67,10 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--single-device", action="store_true",
-                    help="rehearsal: every rank uses cuda:0 (needs --backend gloo; RCCL refuses duplicate devices)")
+                    help="rehearsal: every rank uses cuda:0 (needs --backend gloo; RCCL refuses duplicate devices). The persistent "
+                         "sub-panel kernel needs its work-groups co-resident (DESIGN.md section 4): two processes on one card "
+                         "still get that, four do not (the hang guard fires and the run fails loudly), so with more than two "
+                         "ranks the rehearsal factors with the launch-per-step panel (GPIRT_PANEL=2)")
     args = ap.parse_args()
 
     import numpy as np
@@ -81,6 +84,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     if args.single_device:
         local_rank = 0
+        if world > 2:
+            os.environ.setdefault("GPIRT_PANEL", "2")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
