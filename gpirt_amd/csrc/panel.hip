@@ -26,6 +26,7 @@
 #include "solve64.h"
 #include "potf2.h"
 #include "flagsync.h"
+#include "chunk_asm.h"
 
 namespace gpirt {
 
@@ -264,6 +265,8 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
     // each step reads its strip, updates it and writes it back (own rows only: no barrier), potf2 factors it in place,
     // and the register allocator no longer spills D around the chunk loop (its reload sat on the pivot chain)
     double* sDD = smem + 2 * PB * S64_LS + PB * POTF2_XS;
+    // (PROG) staging area of the chunks' own-row operand: one slice of 8 x 136 doubles per wave (below)
+    double* sXI = smem + 3 * PB * S64_LS + PB * POTF2_XS;
     __shared__ unsigned long long s_seen;
 
     const int t = tid_here();
@@ -335,63 +338,82 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
             load_strip<PRE>(T, A, lda, n, row0, col0, jcols);
             // ---- T -= sum_k X[R,k] X[j,k]^T, chunks of 64, the other operand double-buffered through LDS
             if (j > 0) {
-                double breg[16];
-                d4 XI[4];
                 if (!wait_prog(o_prog, p.base + 1, have, &s_seen, p.info, false, cb0 + Rr, cb0 + j)) return;
-                load_block_regs(breg, A, lda, n, orow0, p.K0);
-                load_strip(XI, A, lda, n, row0, p.K0, PB);
                 const bool full_blocks = (row0 + PB <= n) && (orow0 + PB <= n);
-                const uint32_t voffB = (uint32_t)(((t & 63) + (int64_t)(t >> 6) * lda) * 8);
-                const uint32_t voffX = (uint32_t)((16 * wave + i + (int64_t)(4 * g) * lda) * 8);
-                for (int k = 0; k < j; ++k) {
-                    double* sT = (k & 1) ? sT1 : sT0;
-                    store_block_lds(breg, sT);
-                    d4 XC[4];
+#ifdef PANEL_CHUNK_PROF
+                long long cp[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#define CP_MARK_NOWAIT(slot) do { if (p.trace && threadIdx.x == 0) { const long long now_ = wall_clock64(); cp[slot] += now_ - cp_last; cp_last = now_; } } while (0)
+                long long cp_last = wall_clock64();
+#else
+#define CP_MARK_NOWAIT(slot) do { } while (0)
+#endif
+                if (PROG && full_blocks) {
+                    // Chunk operands in LDS, filled by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction, lane l
+                    // lands at base + 16 l bytes; no VGPR destination, no ds_write pass, half the vector-memory instructions
+                    // of 8-byte loads), issued from INSIDE the hand-scheduled MFMA blocks of the chunk before (chunk_asm.h):
+                    //   * X[j, k] (the other work-group's block, sc1): lanes 0..31 of a piece carry column 2 p, lanes 32..63
+                    //     column 2 p + 1, two rows each -- the PAIR IMAGE  column c at (c >> 1) * 136 + (c & 1) * 64 doubles
+                    //     (136 = 128 + 8: four columns apart = 16 (mod 32) 8-byte banks, as with S64_LS); wave w fills the
+                    //     pairs w, w + 4, ..., alternately into sT0 / sT1;
+                    //   * X[R, k] (own rows, plain): wave w's 16 rows x 8 columns per piece into ITS slice of sXI -- written
+                    //     and read by that wave alone, so the fill of chunk k + 1 needs no barrier against the reads of k.
+                    // A chunk: wait for its fills (vmcnt), own-row operand LDS -> registers (negated: T -= X B^T as 64
+                    // MFMAs on -X), barrier (every wave's pieces of the B block are in; every wave is done with the other
+                    // buffer), then the two MFMA halves carrying the fills of chunk k + 1.
+                    const int pi = 4 * (i & 3) + (i >> 2);
+                    const uint64_t st = (uint64_t)lda * 64u;                                 // 8 columns, bytes
+                    const int wv = __builtin_amdgcn_readfirstlane(wave);
+                    const uint32_t lbB0 = (uint32_t)(uintptr_t)sT0 + (uint32_t)wv * (CHUNK_PITCH * 8u);
+                    const uint32_t lbB1 = (uint32_t)(uintptr_t)sT1 + (uint32_t)wv * (CHUNK_PITCH * 8u);
+                    const uint32_t lbX = (uint32_t)(uintptr_t)sXI + (uint32_t)wv * (8u * CHUNK_PITCH * 8u);
+                    const double* vaB = A + orow0 + 2 * (lane & 31) + (p.K0 + 2 * wave + (lane >> 5)) * lda;
+                    const double* vaX = A + row0 + 16 * wave + 2 * (lane & 7) + (p.K0 + (lane >> 3)) * lda;
+                    const double* myX = sXI + wave * (8 * CHUNK_PITCH) + (g >> 1) * CHUNK_PITCH + (4 * (g & 1)) * 16 + i;
+                    chunk_dmaB(vaB, st, lbB0);
+                    chunk_dmaX(vaX, st, lbX);
+                    for (int k = 0; k < j; ++k) {
+                        const bool more = (k + 1 < j);
+                        CP_MARK_NOWAIT(4);
+                        if (more && !wait_prog(o_prog, p.base + (unsigned long long)(k + 2), have, &s_seen, p.info, false, cb0 + Rr, cb0 + j)) return;
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        CP_MARK_NOWAIT(0);
+                        double xa[8], xb[8];
 #pragma unroll
-                    for (int J = 0; J < 4; ++J) XC[J] = XI[J];
-                    const bool more = (k + 1 < j);
-                    if (more && !wait_prog(o_prog, p.base + (unsigned long long)(k + 2), have, &s_seen, p.info, false, cb0 + Rr, cb0 + j)) return;
-                    __syncthreads();
-                    if (PROG && full_blocks) {
-                        // chunk k's 64 MFMAs with the 32 loads of chunk k + 1 issued between them, two behind each group of
-                        // four (one basic block: the loads of the last chunk are repeated rather than branched around) --
-                        // a chunk is MFMA-bound (64 x 64 cycles = 1.8 us), the loads' address arithmetic and issue (1 us)
-                        // used to sit in front of it
-                        const int64_t kc = p.K0 + (int64_t)(more ? k + 1 : k) * PB;
-                        const double* gB = A + orow0 + kc * lda;
-                        const double* gX = A + row0 + kc * lda;
-                        const int pi = 4 * (i & 3) + (i >> 2);
-                        // (I, s) outside, J inside: consecutive MFMAs go to four DIFFERENT accumulators, so none waits for
-                        // its predecessor's result; per accumulator the order of the terms is unchanged
-                        // the LDS operands are read one group ahead, so the MFMA pipe never waits for the LDS either
-                        double an[4];
-#pragma unroll
-                        for (int J = 0; J < 4; ++J) an[J] = -sT[(4 * g) * S64_LS + 16 * J + pi];
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) {
-                            const int I = q >> 2, s2 = q & 3;
-                            double a[4];
-#pragma unroll
-                            for (int J = 0; J < 4; ++J) a[J] = an[J];
-                            if (q + 1 < 16) {
-                                const int In = (q + 1) >> 2, sn = (q + 1) & 3;
-#pragma unroll
-                                for (int J = 0; J < 4; ++J) an[J] = -sT[(16 * In + 4 * g + sn) * S64_LS + 16 * J + pi];
-                            }
-#pragma unroll
-                            for (int J = 0; J < 4; ++J) T[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[J], XC[I][s2], T[J], 0, 0, 0);
-                            breg[q] = ldg_sc1(gB + (int64_t)(4 * q) * lda, voffB);
-                            XI[I][s2] = ldg_off(gX + (int64_t)(16 * I + s2) * lda, voffX);
-                            // issue order: MFMA, DS read, (VMEM read), MFMA, ... -- everything that is not an MFMA goes
-                            // out while the pipe is busy with the one in front of it
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                                if (q + 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                                if (u & 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                            }
+                        for (int q = 0; q < 8; ++q) {              // column 16 I + 4 g + s: piece 2 I + (g >> 1), column 4 (g & 1) + s of it
+                            xa[q] = -myX[(2 * (q >> 2)) * CHUNK_PITCH + (q & 3) * 16];
+                            xb[q] = -myX[(4 + 2 * (q >> 2)) * CHUNK_PITCH + (q & 3) * 16];
                         }
-                    } else {
+                        __syncthreads();
+                        CP_MARK_NOWAIT(1);
+                        const uint32_t la = (uint32_t)(uintptr_t)((k & 1) ? sT1 : sT0) + (uint32_t)(((2 * g) * CHUNK_PITCH + pi) * 8);
+                        if (more) {
+                            vaB += (int64_t)PB * lda;
+                            vaX += (int64_t)PB * lda;
+                            chunk_half_dmaB(T, xa, la, vaB, st, (k & 1) ? lbB0 : lbB1);
+                            CP_MARK_NOWAIT(2);
+                            chunk_half_dmaX(T, xb, la + 16u * CHUNK_PITCH * 8u, vaX, st, lbX);
+                            CP_MARK_NOWAIT(3);
+                        } else {
+                            chunk_half_plain(T, xa, la);
+                            CP_MARK_NOWAIT(2);
+                            chunk_half_plain(T, xb, la + 16u * CHUNK_PITCH * 8u);
+                            CP_MARK_NOWAIT(3);
+                        }
+                    }
+                } else {
+                    double breg[16];
+                    d4 XI[4];
+                    load_block_regs(breg, A, lda, n, orow0, p.K0);
+                    load_strip(XI, A, lda, n, row0, p.K0, PB);
+                    for (int k = 0; k < j; ++k) {
+                        double* sT = (k & 1) ? sT1 : sT0;
+                        store_block_lds(breg, sT);
+                        d4 XC[4];
+#pragma unroll
+                        for (int J = 0; J < 4; ++J) XC[J] = XI[J];
+                        const bool more = (k + 1 < j);
+                        if (more && !wait_prog(o_prog, p.base + (unsigned long long)(k + 2), have, &s_seen, p.info, false, cb0 + Rr, cb0 + j)) return;
+                        __syncthreads();
                         if (more) {
                             const int64_t kc = p.K0 + (int64_t)(k + 1) * PB;
                             load_block_regs(breg, A, lda, n, orow0, kc);
@@ -400,6 +422,12 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
                         strip64_update(T, XC, sT);
                     }
                 }
+#ifdef PANEL_CHUNK_PROF
+                if (p.trace && threadIdx.x == 0) {
+#pragma unroll
+                    for (int q_ = 0; q_ < 8; ++q_) p.trace[((int64_t)Rr * 40 + 16 + j) * 8 + q_] = cp[q_];
+                }
+#endif
             }
             // ---- X = T L_jj^{-T}
             PANEL_STAMP(1);
@@ -752,7 +780,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
 }  // namespace
 
-size_t panel_ll_smem_bytes() { return (size_t)(3 * PB * S64_LS + PB * POTF2_XS) * sizeof(double); }
+size_t panel_ll_smem_bytes() { return (size_t)(4 * PB * S64_LS + PB * POTF2_XS) * sizeof(double); }
 
 size_t panel_rows_smem_bytes() { return (size_t)(2 * PB * S64_LS) * sizeof(double); }
 

@@ -677,14 +677,16 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
                 // together, which makes every per-launch rate in bench.py's roofline read a quarter lower (0.45 -> 0.36)
                 // for the same work.  Not worth a misleading profile: a switch.
                 static const int defer_split = env_int("GPIRT_DEFER_SPLIT", 2);
-                // GPIRT_DEFER_PAR=1 (off by default): the step's updates of this block column by the panels 0 .. q as ONE
-                // grid -- their products side by side, applied to C one after the other in panel order
-                // (launch_syrk_panels: bit-identical to the separate launches below).  Every panel so far has brought the
-                // block column up to the same column (done_col), which is what makes them one product over contiguous K.
-                // Measured: +2 % on the factorisation at n = 12288, nothing at the metric size (the main stream has slack
-                // there), and the parts' round trip through the workspace takes the launches' memory traffic from 1.9x to
-                // 2.35x their algorithmic bytes -- so it stays a switch.
-                static const int defer_par = env_int("GPIRT_DEFER_PAR", 2);
+                // GPIRT_DEFER_PAR (1 = default): the step's updates of this block column by the panels 0 .. q as ONE grid
+                // -- their products side by side, applied to C one after the other in panel order (launch_syrk_panels:
+                // bit-identical to the separate launches below, which GPIRT_DEFER_PAR=2 restores).  Every panel so far
+                // has brought the block column up to the same column (done_col), which is what makes them one product
+                // over contiguous K.  Round 3 measured +2 % on the factorisation at n = 12288 and nothing at the metric
+                // size; with the LDS-DMA panel kernel (shorter chain, the main stream no longer has slack) it is
+                // 7.29 -> 7.22 ms per iteration at 8192 x 1024 and 12.72 -> 12.18 ms for the factorisation at 12288, and
+                // the launches' rate reads 0.53 instead of 0.49 of peak.  The parts' round trip through the workspace
+                // takes the launches' memory traffic from 1.9x to 2.35x their algorithmic bytes.
+                static const int defer_par = env_int("GPIRT_DEFER_PAR", 1);
                 bool same_lo = done_col.size() >= 2;
                 for (size_t q = 1; q < done_col.size(); ++q) same_lo = same_lo && done_col[q] == done_col[0];
                 if (defer_par == 1 && same_lo && done_col[0] < horizon && (nbo % 16) == 0) {

@@ -45,7 +45,7 @@ def test_fenced_build_gives_the_same_factor_bit_for_bit():
     assert a == b, "\n".join(f"{x}\n{y}" for x, y in zip(a, b) if x != y)
 
 
-@pytest.mark.parametrize("switch", ["GPIRT_HALF_AHEAD=2", "GPIRT_DEFER_PAR=1", "GPIRT_DEFER_SPLIT=1", "GPIRT_ROWS=1", "GPIRT_DEFER=2"])
+@pytest.mark.parametrize("switch", ["GPIRT_HALF_AHEAD=2", "GPIRT_DEFER_PAR=2", "GPIRT_DEFER_SPLIT=1", "GPIRT_ROWS=1", "GPIRT_DEFER=2"])
 def test_schedule_switches_leave_the_factor_bit_identical(switch):
     """Every opt-in / opt-out schedule of the factorisation that claims the SAME products in the same order per element
     (potrf.hip: the early half of the chain-critical update off; the step's deferred updates as one grid with in-order

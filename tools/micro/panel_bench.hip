@@ -69,6 +69,16 @@ int main(int argc, char** argv)
         for (int j = 0; j < ncb && j < (R < ncb ? R : ncb); ++j)
             printf("   j=%2d  %8.2f %8.2f %8.2f %8.2f\n", j, us(tr[(R * 40 + j) * 8]), us(tr[(R * 40 + j) * 8 + 1]), us(tr[(R * 40 + j) * 8 + 2]), us(tr[(R * 40 + j) * 8 + 3]));
     }
+#ifdef PANEL_CHUNK_PROF
+    for (int R : show) {
+        if (R < 0 || R >= nrb) continue;
+        printf("row block %d chunk phases per step (us summed over the step's chunks): [lds store+vmcnt wait, wait_prog+barrier, loads A, mfma A, loads B, mfma B, loop back]\n", R);
+        for (int j = 1; j < ncb && j < (R < ncb ? R : ncb); ++j) {
+            const long long* c = &tr[(R * 40 + 16 + j) * 8];
+            printf("   j=%2d (%d chunks)  %.2f %.2f | %.2f %.2f | %.2f %.2f | %.2f   [mfma A: %lld shader cycles = %.0f per MFMA, clock %.0f MHz]\n", j, j, c[0] / 100.0, c[1] / 100.0, c[5] / 100.0, c[2] / 100.0, c[6] / 100.0, c[3] / 100.0, c[4] / 100.0, c[7], c[7] / (32.0 * j), c[2] ? 100.0 * c[7] / c[2] : 0.0);
+        }
+    }
+#endif
     // residual of the leading W x W block
     std::vector<double> L((size_t)n * W);
     CK(hipMemcpy(L.data(), dA, L.size() * 8, hipMemcpyDeviceToHost));
