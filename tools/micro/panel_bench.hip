@@ -67,7 +67,11 @@ int main(int argc, char** argv)
         if (R < 0 || R >= nrb) continue;
         printf("row block %d: step j: start, gemm done, L_jj seen, step done\n", R);
         for (int j = 0; j < ncb && j < (R < ncb ? R : ncb); ++j)
-            printf("   j=%2d  %8.2f %8.2f %8.2f %8.2f\n", j, us(tr[(R * 40 + j) * 8]), us(tr[(R * 40 + j) * 8 + 1]), us(tr[(R * 40 + j) * 8 + 2]), us(tr[(R * 40 + j) * 8 + 3]));
+        {
+            const long long* q = &tr[(R * 40 + j) * 8];
+            printf("   j=%2d  %8.2f %8.2f %8.2f %8.2f   [after L seen: staged +%.2f, solved +%.2f, stored / X in LDS +%.2f, D updated + published +%.2f]\n", j, us(q[0]), us(q[1]),
+                   us(q[2]), us(q[3]), (q[4] - q[2]) / 100.0, (q[5] - q[4]) / 100.0, (q[6] - q[5]) / 100.0, (q[3] - q[6]) / 100.0);
+        }
     }
 #ifdef PANEL_CHUNK_PROF
     for (int R : show) {
