@@ -10,13 +10,20 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 h = Handle()
 theta = torch.from_numpy(make_responses(n, 2, seed=1)[1]).cuda()
+ignore = os.environ.get("GPIRT_X_IGNORE") == "1"      # timing experiments that break the factor on purpose
+def factor():
+    try:
+        h.factor(theta)
+    except RuntimeError:
+        if not ignore:
+            raise
 for _ in range(3):
-    h.factor(theta)
+    factor()
 torch.cuda.synchronize()
 ts = []
 for _ in range(reps):
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-    e0.record(); h.factor(theta); e1.record(); torch.cuda.synchronize()
+    e0.record(); factor(); e1.record(); torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1))
 tag = " ".join(f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("GPIRT_"))
 print(f"n={n} factor: min {min(ts):.3f} ms  mean {sum(ts)/len(ts):.3f} ms   [{tag}]", flush=True)
