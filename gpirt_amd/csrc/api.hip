@@ -355,6 +355,12 @@ int gpirt_debug_streams_busy(gpirt_handle_t h, int* busy)
     return 0;
 }
 
+int gpirt_debug_ll_term(gpirt_handle_t h, const double* d_a, int64_t n, double* d_out, int fast)
+{
+    GP_ARG(h && (n == 0 || (d_a && d_out)) && n >= 0);
+    return launch_ll_term_probe(h->stream, d_a, n, d_out, fast != 0);
+}
+
 int gpirt_potrf_finish(gpirt_handle_t h)
 {
     GP_ARG(h != nullptr);

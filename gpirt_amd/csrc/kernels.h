@@ -104,6 +104,7 @@ struct EssArgs {
     const double* U; uint64_t* pos; uint64_t cap;
 };
 int launch_ess(hipStream_t stream, const EssArgs& a);
+int launch_ll_term_probe(hipStream_t stream, const double* a, int64_t n, double* out, bool fast);
 int launch_ll_bar(hipStream_t stream, const double* f, const double* y, const double* mu, int64_t n,
                   int64_t m, double* out);
 

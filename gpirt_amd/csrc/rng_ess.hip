@@ -8,10 +8,22 @@
 //                    bracket state, so control flow is work-group uniform.  HBM/L2 bound.
 #include "common.h"
 #include "kernels.h"
+#include "ll_fast.h"
 
 namespace gpirt {
 
 namespace {
+
+// one term of ll(): as written (library exp and log) or the 70-instruction form of ll_fast.h (FAST; the slice kernels of
+// the item-keyed RNG -- an R-stream replay keeps the reference's formula to the letter)
+template <bool FAST>
+__device__ __forceinline__ double ll_t(double a) { return FAST ? ll_term_fast(a) : ll_term(a); }
+
+__global__ void ll_term_probe_kernel(const double* __restrict__ a, int64_t n, double* __restrict__ out, int fast)
+{
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (int64_t)gridDim.x * blockDim.x)
+        out[g] = fast ? ll_term_fast(a[g]) : ll_term(a[g]);
+}
 
 __global__ void item_fill_kernel(uint64_t seed, uint32_t iter, uint32_t stage, uint32_t item0,
                                  int64_t n_items, int64_t n_index, double* __restrict__ out,
@@ -63,6 +75,7 @@ __global__ __launch_bounds__(256) void ll_bar_kernel(const double* __restrict__ 
 
 constexpr int ESS_MAX_TRIALS = 100000;
 
+template <bool FAST>
 __global__ __launch_bounds__(256) void ess_kernel(EssArgs a)
 {
     __shared__ double red[4];
@@ -94,7 +107,7 @@ __global__ __launch_bounds__(256) void ess_kernel(EssArgs a)
     for (int64_t i = threadIdx.x; i < n; i += 256) {
         const double yy = yj[i];
         if (yy != yy) continue;
-        acc += ll_term(yy * (fj[i] + mj[i]));
+        acc += ll_t<FAST>(yy * (fj[i] + mj[i]));
     }
     const double ll0 = -block_sum_256(acc, red);
     const double u = next_u();
@@ -112,7 +125,7 @@ __global__ __launch_bounds__(256) void ess_kernel(EssArgs a)
             const double yy = yj[i];
             if (yy != yy) continue;
             const double fp = fj[i] * c + nj[i] * s;                       // :43
-            acc += ll_term(yy * (fp + mj[i]));
+            acc += ll_t<FAST>(yy * (fp + mj[i]));
         }
         const double llp = -block_sum_256(acc, red);
         if (llp > log_y) break;                                            // :45-47
@@ -135,7 +148,7 @@ __global__ __launch_bounds__(256) void ess_kernel(EssArgs a)
 // Register-resident variant for n <= NTH * EPT: each lane keeps its EPT entries of f, nu, mu and y in
 // registers, so the (2 + k) likelihood passes of a column touch memory once; arithmetic is identical
 // to ess_kernel (same per-element expression, same reduction tree).
-template <int EPT, int NTH>
+template <int EPT, int NTH, bool FAST>
 __global__ __launch_bounds__(NTH) void ess_kernel_reg(EssArgs a)
 {
     __shared__ double red[8];
@@ -161,7 +174,7 @@ __global__ __launch_bounds__(NTH) void ess_kernel_reg(EssArgs a)
     double acc = 0.0;
 #pragma unroll
     for (int e = 0; e < EPT; ++e)
-        if (Y[e] == Y[e]) acc += ll_term(Y[e] * (F[e] + M[e]));
+        if (Y[e] == Y[e]) acc += ll_t<FAST>(Y[e] * (F[e] + M[e]));
     const double ll0 = -block_sum(acc);
     const double u = item_uniform(a.seed, a.iter, GPIRT_ST_F_ESS, item, uidx++);
     const double log_y = ll0 + log(u);                                     // draw-f.cpp:28-29
@@ -177,7 +190,7 @@ __global__ __launch_bounds__(NTH) void ess_kernel_reg(EssArgs a)
         acc = 0.0;
 #pragma unroll
         for (int e = 0; e < EPT; ++e)
-            if (Y[e] == Y[e]) acc += ll_term(Y[e] * ((F[e] * c + V[e] * s) + M[e]));   // :43
+            if (Y[e] == Y[e]) acc += ll_t<FAST>(Y[e] * ((F[e] * c + V[e] * s) + M[e]));   // :43
         const double llp = -block_sum(acc);
         if (llp > log_y) break;                                            // :45-47
         if (llp != llp) { bad = true; break; }
@@ -240,12 +253,29 @@ int launch_ll_bar(hipStream_t stream, const double* f, const double* y, const do
 int launch_ess(hipStream_t stream, const EssArgs& a)
 {
     if (a.m <= 0) return 0;
-    if (a.U == nullptr && a.n <= 256 * 8)
-        hipLaunchKernelGGL((ess_kernel_reg<8, 256>), dim3((unsigned)a.m), dim3(256), 0, stream, a);
-    else if (a.U == nullptr && a.n <= 256 * 32)
-        hipLaunchKernelGGL((ess_kernel_reg<16, 512>), dim3((unsigned)a.m), dim3(512), 0, stream, a);
-    else
-        hipLaunchKernelGGL(ess_kernel, dim3((unsigned)a.m), dim3(256), 0, stream, a);
+    // GPIRT_LL_EXACT=1 (read per call): log(1 + exp(-a)) through the library in every mode
+    const char* ex = getenv("GPIRT_LL_EXACT");
+    const bool fast = a.U == nullptr && !(ex && atoi(ex) == 1);
+    if (a.U == nullptr && a.n <= 256 * 8) {
+        if (fast) hipLaunchKernelGGL((ess_kernel_reg<8, 256, true>), dim3((unsigned)a.m), dim3(256), 0, stream, a);
+        else      hipLaunchKernelGGL((ess_kernel_reg<8, 256, false>), dim3((unsigned)a.m), dim3(256), 0, stream, a);
+    } else if (a.U == nullptr && a.n <= 256 * 32) {
+        if (fast) hipLaunchKernelGGL((ess_kernel_reg<16, 512, true>), dim3((unsigned)a.m), dim3(512), 0, stream, a);
+        else      hipLaunchKernelGGL((ess_kernel_reg<16, 512, false>), dim3((unsigned)a.m), dim3(512), 0, stream, a);
+    } else {
+        if (fast) hipLaunchKernelGGL(ess_kernel<true>, dim3((unsigned)a.m), dim3(256), 0, stream, a);
+        else      hipLaunchKernelGGL(ess_kernel<false>, dim3((unsigned)a.m), dim3(256), 0, stream, a);
+    }
+    GP_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_ll_term_probe(hipStream_t stream, const double* a, int64_t n, double* out, bool fast)
+{
+    if (n <= 0) return 0;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(ll_term_probe_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, n, out, fast ? 1 : 0);
     GP_HIP(hipGetLastError());
     return 0;
 }

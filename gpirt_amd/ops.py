@@ -195,6 +195,13 @@ class Handle:
         check(self.lib.gpirt_ll_bar(self._h, _p(f), _p(y), _p(mu), n, m, _p(out)))
         return out
 
+    def ll_term(self, a, fast=True) -> torch.Tensor:
+        """log(1 + exp(-a)) elementwise: the slice kernel's form (csrc/ll_fast.h) or, fast=False, the formula as written."""
+        a = a.contiguous().to(torch.float64)
+        out = torch.empty_like(a)
+        check(self.lib.gpirt_debug_ll_term(self._h, _p(a), a.numel(), _p(out), int(bool(fast))))
+        return out
+
     def item_normals(self, seed, it, stage, item0, n_items, n_index) -> torch.Tensor:
         out = colmajor(n_index, n_items)
         check(self.lib.gpirt_item_normals(self._h, seed, it, stage, item0, n_items, n_index, _p(out)))

@@ -117,6 +117,11 @@ int gpirt_potrf_panel_copy_part(gpirt_handle_t h, double* d_A, int64_t n, int64_
 /* Debug aid for hosts that enqueue collectives between the pieces: *busy = bit mask of the handle's INTERNAL streams that
  * still have work in flight (0 = every piece has joined the handle's stream, as each must before it returns). */
 int gpirt_debug_streams_busy(gpirt_handle_t h, int* busy);
+/* One term of ll() (src/log-likelihood.cpp:20,34), log(1 + exp(-a)), elementwise for the n device values d_a:
+ * fast = 0 the formula as written through the device library's exp and log (ll_bar, draw_beta, draw_theta and every
+ * R-stream replay use it), fast = 1 the form of csrc/ll_fast.h that the elliptical-slice kernel of the item-keyed RNG
+ * evaluates (within 3 ulp of the exact value; GPIRT_LL_EXACT=1 makes that kernel use the written form too). */
+int gpirt_debug_ll_term(gpirt_handle_t h, const double* d_a, int64_t n, double* d_out, int fast);
 
 /* rmvnorm()'s product `cholS * res` (src/mvnormal.h:10) for all item columns at once:
  * d_out (n x m) = L * Z with L lower triangular; the strict upper triangle of d_L must hold zeros
