@@ -249,13 +249,14 @@ def main():
                         "frac": (v[2] / (v[0] * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS) if v[0] > 0 else None,
                         "ms_per_step": v[0] / n_sampled}
                     for k, v in prof.items()}
-        traffic, traffic_src = None, None
+        traffic, traffic_src, mfma_busy = None, None, None
         tpath = os.path.join(ROOT, "profiles", "trailing_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 traffic, traffic_src = tj.get("hbm_bytes_per_launch"), ("STATIC FILE profiles/trailing_traffic.json (PMC passes of an "
                                                                          "earlier run of this command, not this run): " + str(tj.get("source")))
+                mfma_busy = {k: v.get("mfma_busy_frac") for k, v in (tj.get("by_kernel") or {}).items()}
             except Exception:
                 traffic = None
         sharded = ["draw_f", "draw_beta"] + (["theta_gemm"] if args.theta == "allreduce" else [])
@@ -319,6 +320,11 @@ def main():
                 "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
                 "traffic": traffic,
                 "traffic_source_static_pmc_file": traffic_src,
+                "mfma_busy_static_pmc_file": mfma_busy,
+                "mfma_busy_note": "SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES share of the chip's SIMDs) of these launches, from the same "
+                                  "static PMC file: the share of cycles the matrix pipes are busy.  `frac` above is against the NOMINAL peak "
+                                  "(2.4 GHz); under this load the chip holds ~2.1 GHz (shader-cycle counter, DESIGN.md section 4), where the "
+                                  "MFMA ceiling is 68.8 TFLOP/s",
                 "launches": int(tot_n),
                 "avg_launch_ms": (tot_ms / tot_n) if tot_n else None,
                 "flops_per_launch": (tot_fl / tot_n) if tot_n else None,
