@@ -5,13 +5,16 @@
 //   producer: EVERY handed-off byte is stored sc1 (write-through at agent scope: __hip_atomic_store relaxed/agent),
 //             every storing wave waits s_waitcnt vmcnt(0), the work-group's barrier, then ONE lane stores the counter sc1;
 //   consumer: one lane polls the counter with sc1 loads, the work-group's barrier, then EVERY load of the handed-off
-//             bytes is an sc1 load to registers (__hip_atomic_load relaxed/agent on a global pointer).
+//             bytes is an sc1 load -- to registers (__hip_atomic_load relaxed/agent on a global pointer) or, since the
+//             end of round 3, straight into LDS (global_load_lds_dwordx4 ... sc1 in chunk_asm.h: the same cache policy
+//             bits on the same load path; the wave waits vmcnt(0) and the work-group's barrier before any lane reads
+//             the LDS image).
 // No agent-scope release (buffer_wbl2: it would write back every dirty line of the XCD's L2, the other work-groups'
 // private results included) and no acquire (buffer_inv: it empties the XCD's L2 for all 16 work-groups sharing it,
 // twice per step each) -- measured in round 2: 216 -> ... us per 512-column sub-panel.
 //
 // "One work-group per CU" in the guide's table is the regime the form was MEASURED in.  panel_ll_kernel meets it for
-// its own work-groups (114 KB of LDS each); foreign work-groups that fit beside one (no LDS to speak of, <= 152 registers) do
+// its own work-groups (148 KB of LDS each); foreign work-groups that fit beside one (no LDS to speak of, <= 152 registers) do
 // not change the argument, because it never relied on the CU's L1: every load of a handed-off byte is an sc1 load (served
 // past the L1) and every such byte was stored sc1 (written through, dropped from the producer's L2).  panel_rows_kernel
 // (two or three work-groups per CU, beside update work-groups) is a CONSUMER only, of the same sc1 bytes, and is outside

@@ -253,9 +253,10 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
     extern __shared__ __attribute__((aligned(16))) double smem[];
     // Two 64 x 64 buffers (34 KB each): the "other" GEMM operand alternates between them, and whichever
     // one the last chunk did not use then takes L_jj for the solve and X for the diagonal update; a third holds D
-    // (below).  114 KB in all, so two of these work-groups never share a CU (160 KB).  The kernel runs at 360 registers per
-    // lane (<true>; 422 <false>), not the full 512: a small foreign work-group (<= 46 KB of LDS, <= 152 registers -- a
-    // split-K sum, a copy-back, a flag store) CAN sit beside it.  That does not touch the hand-off protocol: no handed-off
+    // and (PROG) a fourth stages the chunks' own-row operand (below).  148 KB in all (114 without the fourth), so two of
+    // these work-groups never share a CU (160 KB).  The kernel runs at 329 registers per lane (<true>; 422 <false>), not
+    // the full 512: a small foreign work-group (<= 12 KB of LDS, <= 176 registers -- a split-K sum, a copy-back, a flag
+    // store) CAN sit beside it.  That does not touch the hand-off protocol: no handed-off
     // byte is ever read through the CU's L1 or expected in this XCD's L2 (every such store and load is sc1, flagsync.h), so
     // what a co-resident work-group may have left in L1 cannot be observed; exclusivity only matters for speed.
     double* sT0 = smem;
