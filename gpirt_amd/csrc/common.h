@@ -77,6 +77,7 @@ struct gpirt_handle_s {
     gpirt_handle_t aux = nullptr;
     const double* inv_partial_L = nullptr;   // (on the aux handle) the factor whose block inverses are PARTLY built ...
     int64_t      inv_partial_pairs = 0;      //   ... 512-block pairs [0, inv_partial_pairs)
+    bool         slim_leaf = false;       // trsm_inverses_build launches the 256-register form of its leaf kernel (trsm.hip)
     hipEvent_t   ev_prelast = nullptr;    // fires when every outer panel but the last is final (columns [0, prelast_cols))
     int64_t      prelast_cols = 0;        //   ... of the factorisation enqueued last (0: no such point, e.g. a single panel)
     // persistent panel kernel (panel.hip): one progress counter per 64-row block, epoch-tagged

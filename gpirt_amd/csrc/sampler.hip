@@ -178,10 +178,16 @@ int do_draw_f(gpirt_sampler_s* s)
     GP_TRY(beta_sync(s));                     // mu of the previous iteration's draw_beta
     if (!stream_mode(s)) {
         const bool prep = s->haux && s->ext > 0 && !s->ext_grid && s->rows_valid && !s->prep_valid;
-        // With few item columns on this rank (m <= 128: eight GPUs at the metric size) the product below does not
-        // fill the chip and the slice kernel is short, so the side work starts at once -- beside the fill and the product
-        // as well; with all 1024 columns it waits for the product (whose 256 work-groups would starve it).
-        const bool early = prep && m <= 128;
+        // The side work (what the low-rank draw_fstar needs from L alone: the last range of block inverses and the
+        // 64-column transposed solve, ~0.6 ms of small DEPENDENT launches) starts at once, beside the fill and the product
+        // nu = L z.  Until the end of round 3 it waited for the product with all 1024 columns ("its 256 work-groups would
+        // starve it"): what starved was ONE kernel, the 392-register leaf of the block inverses, which cannot share a CU
+        // with a 224-register work-group of the product and sat out its whole 1.09 ms -- the side handle now launches
+        // the 256-register form of that leaf (trsm.hip, slim_leaf) and the chain is done before the slice kernel is:
+        // draw_fstar no longer waits 0.33 ms for it (7.12 -> 6.88 ms per iteration; the product slows by 0.1 ms).
+        // GPIRT_PREP_EARLY=2 (read per call) puts it back behind the product.
+        const char* pe = getenv("GPIRT_PREP_EARLY");
+        const bool early = prep && !(pe && atoi(pe) == 2 && m > 128);
         if (early) GP_HIP(hipEventRecord(s->ev_trmm, st));
         if (s->z_filled_iter == iter && s->ev_zfill) {
             GP_HIP(hipStreamWaitEvent(st, s->ev_zfill, 0));       // filled behind the previous factorisation (do_factor)
@@ -196,12 +202,13 @@ int do_draw_f(gpirt_sampler_s* s)
         a.err = s->flags; a.seed = s->opt.seed; a.iter = iter; a.item0 = (uint32_t)s->opt.item0;
         GP_TRY(launch_ess(st, a));
         if (prep) {
-            // Beside the slice kernel (VALU-bound; the matrix pipes idle): what the low-rank draw_fstar needs from L
-            // alone, on the sampler's own stream.  (Not beside the product above: its 256 work-groups hold every CU for
-            // ~1 ms and anything dispatched next to them starves.)
+            // what the low-rank draw_fstar needs from L alone, on the sampler's own stream (see `early` above)
             hipStream_t ax = s->haux->stream;
             GP_HIP(hipStreamWaitEvent(ax, s->ev_trmm, 0));
-            GP_TRY(fstar_prep(s, s->haux));
+            s->haux->slim_leaf = early;
+            const int rc_prep = fstar_prep(s, s->haux);
+            s->haux->slim_leaf = false;
+            GP_TRY(rc_prep);
             GP_HIP(hipEventRecord(s->ev_prep, ax));
             s->prep_valid = true; s->prep_pending = true;
         }

@@ -105,8 +105,11 @@ constexpr int NL4 = 256;
 // IDENT: the right-hand side is the identity (nothing is read from B) and blockIdx.y walks a batch of
 // diagonal blocks -- L advances by lstride per entry, B by bstride per PAIR of entries plus bhalf for the odd
 // one (the two diagonal quarters of a 512 x 512 inverse): the block inverses of trsm_rec.
-template <bool BACK, bool IDENT = false>
-__global__ __launch_bounds__(256) void trsm_leaf256_kernel(const double* __restrict__ L, int64_t ldl, int nb,
+// OCC = 2: the same code held to 256 registers (269 of them spilled to scratch): it then fits BESIDE a work-group of the
+// 128-tile product (224 registers) on a CU -- the block inverses of the draw_fstar side chain, which start beside
+// nu = L z (sampler.hip); at 392 registers the kernel waited for that product's work-groups to leave (1.09 ms).
+template <bool BACK, bool IDENT = false, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void trsm_leaf256_kernel(const double* __restrict__ L, int64_t ldl, int nb,
                                                            double* __restrict__ B, int64_t ldb, int64_t nrhs,
                                                            long long* trace, int64_t lstride = 0, int64_t bstride = 0,
                                                            int64_t bhalf = 0)
@@ -391,10 +394,16 @@ int trsm_inverses_build(gpirt_handle_t h, hipStream_t stream, const double* L, i
     double* W = h->d_trsm_winv;
     // 256-blocks 2 p0 .. 2 p1 - 1 (+ the odd one when this range closes the matrix)
     const int64_t b0 = 2 * p0, b1 = (p1 == npair) ? nfull : 2 * p1;
-    if (b1 > b0)
-        hipLaunchKernelGGL((trsm_leaf256_kernel<false, true>), dim3(NL4 / CB, (unsigned)(b1 - b0)), dim3(256), 0, stream,
-                           L + b0 * (int64_t)NL4 * (ldl + 1), ldl, NL4, W + p0 * (int64_t)NI * NI, (int64_t)NI, (int64_t)NL4,
-                           (long long*)nullptr, (int64_t)NL4 * (ldl + 1), (int64_t)NI * NI, (int64_t)NL4 * (NI + 1));
+    if (b1 > b0) {
+        if (h->slim_leaf)
+            hipLaunchKernelGGL((trsm_leaf256_kernel<false, true, 2>), dim3(NL4 / CB, (unsigned)(b1 - b0)), dim3(256), 0, stream,
+                               L + b0 * (int64_t)NL4 * (ldl + 1), ldl, NL4, W + p0 * (int64_t)NI * NI, (int64_t)NI, (int64_t)NL4,
+                               (long long*)nullptr, (int64_t)NL4 * (ldl + 1), (int64_t)NI * NI, (int64_t)NL4 * (NI + 1));
+        else
+            hipLaunchKernelGGL((trsm_leaf256_kernel<false, true>), dim3(NL4 / CB, (unsigned)(b1 - b0)), dim3(256), 0, stream,
+                               L + b0 * (int64_t)NL4 * (ldl + 1), ldl, NL4, W + p0 * (int64_t)NI * NI, (int64_t)NI, (int64_t)NL4,
+                               (long long*)nullptr, (int64_t)NL4 * (ldl + 1), (int64_t)NI * NI, (int64_t)NL4 * (NI + 1));
+    }
     const int np = (int)(p1 - p0);
     if (np > 0) {
         const double* Lp = L + p0 * (int64_t)NI * (ldl + 1);

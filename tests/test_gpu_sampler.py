@@ -439,3 +439,31 @@ def test_block_inverses_built_behind_the_factorisation_change_nothing(handle):
     for name in ("fstar", "theta", "f", "beta"):
         assert np.array_equal(a.get(name), b.get(name)), name
     a.close(); b.close()
+
+
+def test_side_chain_beside_the_product_changes_nothing(handle):
+    """The factor-only part of the rank-64 draw_fstar (last range of block inverses, 64-column transposed solve) starts
+    beside nu = L z, with the 256-register form of the inverse leaf so that it fits on a CU next to the product's
+    work-groups (sampler.hip do_draw_f, trsm.hip slim_leaf).  Same arithmetic, other streams and register budget: every
+    draw must be BIT-IDENTICAL to the run that keeps it behind the product (GPIRT_PREP_EARLY=2)."""
+    import os
+    from gpirt_amd import Sampler
+    from gpirt_amd.synthetic import make_responses
+    n, m = 4096, 160            # (m > 128: below that the side chain always started early)
+    y, th0 = make_responses(n, m, seed=47)
+    kw = dict(rng="item", seed=9, theta_stabilise=True, fstar_fused=True, kstar_rank=64)
+    outs = []
+    for mode in ("1", "2"):
+        os.environ["GPIRT_PREP_EARLY"] = mode
+        try:
+            s = Sampler(handle, y, th0, **kw)
+            s.init()
+            for _ in range(3):
+                s.step()
+            s.check()
+            outs.append({name: s.get(name) for name in ("fstar", "theta", "f", "beta")})
+            s.close()
+        finally:
+            os.environ.pop("GPIRT_PREP_EARLY", None)
+    for name in outs[0]:
+        assert np.array_equal(outs[0][name], outs[1][name]), name
