@@ -180,6 +180,7 @@ int gpirt_destroy(gpirt_handle_t h)
     if (h->ev_a) hipEventDestroy(h->ev_a);
     if (h->ev_half) hipEventDestroy(h->ev_half);
     if (h->ev_prelast) hipEventDestroy(h->ev_prelast);
+    if (h->panel_trace && h->panel_trace_cap > 0) hipFree(h->panel_trace);
     if (h->aux) { hipStreamSynchronize(h->aux->stream); gpirt_destroy(h->aux); h->aux = nullptr; }
     if (h->rows_stream) hipStreamDestroy(h->rows_stream);
     if (h->near_stream) hipStreamDestroy(h->near_stream);
@@ -352,6 +353,29 @@ int gpirt_debug_streams_busy(gpirt_handle_t h, int* busy)
         if (st[i] && hipStreamQuery(st[i]) == hipErrorNotReady) m |= 1 << i;
     (void)hipGetLastError();
     *busy = m;
+    return 0;
+}
+
+int gpirt_debug_panel_trace(gpirt_handle_t h, int64_t k0, long long* host_out, int64_t count)
+{
+    GP_ARG(h && count >= 0);
+    if (!host_out) {            // arm: the sub-panel launch that starts at column k0 stamps [row block][40 steps][8 slots]
+        GP_HIP(hipStreamSynchronize(h->stream));
+        if (h->panel_trace_cap < count) {
+            if (h->panel_trace && h->panel_trace_cap > 0) GP_HIP(hipFree(h->panel_trace));
+            h->panel_trace = nullptr; h->panel_trace_cap = 0;
+            GP_HIP(hipMalloc(&h->panel_trace, (size_t)count * sizeof(long long)));
+            h->panel_trace_cap = count;
+        }
+        if (count == 0) { h->panel_trace_k0 = -1; if (h->panel_trace_cap > 0) { GP_HIP(hipFree(h->panel_trace)); h->panel_trace = nullptr; h->panel_trace_cap = 0; } return 0; }
+        GP_HIP(hipMemsetAsync(h->panel_trace, 0, (size_t)count * sizeof(long long), h->stream));
+        GP_HIP(hipStreamSynchronize(h->stream));
+        h->panel_trace_k0 = k0;
+        return 0;
+    }
+    GP_ARG(h->panel_trace && count <= h->panel_trace_cap);
+    GP_HIP(hipDeviceSynchronize());
+    GP_HIP(hipMemcpy(host_out, h->panel_trace, (size_t)count * sizeof(long long), hipMemcpyDeviceToHost));
     return 0;
 }
 

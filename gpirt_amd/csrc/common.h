@@ -95,7 +95,9 @@ struct gpirt_handle_s {
     hipEvent_t   ev_pool[16] = {};        //   ... and the cross-stream events
     size_t       prog_cap = 0;
     unsigned long long prog_seq = 0;
-    long long*   panel_trace = nullptr;   // debug stamps (micro-benchmarks only)
+    long long*   panel_trace = nullptr;   // debug stamps (micro-benchmarks; gpirt_debug_panel_trace)
+    int64_t      panel_trace_k0 = -1;     // >= 0: only the sub-panel launch that starts at this column stamps
+    int64_t      panel_trace_cap = 0;     // entries allocated by gpirt_debug_panel_trace
     int          n_cu = 0;                // compute units of `device` (grid cap of the persistent kernel)
     bool         panel_attr_set = false;  // dynamic-LDS attribute of panel_ll_kernel set on this device
     // gemm_f64.hip: parts of automatically split-K products

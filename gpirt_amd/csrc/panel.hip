@@ -854,7 +854,7 @@ int launch_panel_ll(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, 
     p.base = h->prog_seq * 64ull;                    // a panel publishes at most ncb + 1 <= 17 steps
     if (epoch_out) *epoch_out = p.base;
     p.info = h->d_info;
-    p.trace = h->panel_trace;
+    p.trace = (h->panel_trace && (h->panel_trace_k0 < 0 || h->panel_trace_k0 == K0)) ? h->panel_trace : nullptr;
     p.nrb = (int)((n - K0 + PB - 1) / PB);
     p.ncb = (int)((c1 - K0 + PB - 1) / PB);
     if (p.ncb > 32) { set_error("panel wider than 2048 columns"); return GPIRT_E_ARG; }

@@ -121,6 +121,11 @@ int gpirt_debug_streams_busy(gpirt_handle_t h, int* busy);
  * fast = 0 the formula as written through the device library's exp and log (ll_bar, draw_beta, draw_theta and every
  * R-stream replay use it), fast = 1 the form of csrc/ll_fast.h that the elliptical-slice kernel of the item-keyed RNG
  * evaluates (within 3 ulp of the exact value; GPIRT_LL_EXACT=1 makes that kernel use the written form too). */
+/* In-kernel time stamps of ONE sub-panel launch of the factorisation as it runs inside the schedule (100 MHz wall clock:
+ * [row block relative to the launch][step 0..39][slot 0..7], the layout tools/micro/panel_bench.hip prints).
+ * host_out == NULL arms it for the launch that starts at column k0 (count = entries to allocate, >= 40 * 8 * row blocks;
+ * count = 0 disarms and frees); otherwise copies `count` entries out.  tools/panel_trace_insitu.py. */
+int gpirt_debug_panel_trace(gpirt_handle_t h, int64_t k0, long long* host_out, int64_t count);
 int gpirt_debug_ll_term(gpirt_handle_t h, const double* d_a, int64_t n, double* d_out, int fast);
 
 /* rmvnorm()'s product `cholS * res` (src/mvnormal.h:10) for all item columns at once:
