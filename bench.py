@@ -20,7 +20,12 @@ Rank 0 prints ONE JSON line with the contract fields plus
   cpu_baseline  the CPU oracle (a port of the reference; the reference itself needs R) timed on this
                 host on a bounded sample of the same workload: one thread (reference-shaped) and all cores;
   config.lowrank_check  max|f*_lowrank - f*_full-solve| measured in this run on the state the timed steps ended in
-                (the rank-64 form of draw_fstar is opt-in; if it misses 1e-9 the headline is re-timed with `fused`).
+                (the rank-64 form of draw_fstar is opt-in; if it misses 1e-9 the headline is re-timed with `fused`);
+  config.reference_rng_iterations_per_s  (N = 1) the rate of the literal gpirt_default_options contract on the same
+                problem -- R-stream replay, src/draw-fstar.cpp as written, draw_theta as written: what an R user of the
+                unmodified shim gets -- measured over 2 iterations outside the timed region;
+  item_shard_speedup, whole_iteration_speedup, rccl_ranks  (N > 1) the item-sharded stages and the whole iteration
+                against a single-GPU run of the FULL problem that rank 0 times in the same process, same K and W.
 """
 import argparse
 import json
@@ -62,6 +67,10 @@ def main():
                     help="double_solve: src/draw-fstar.cpp as written; fused: mean = (L^-1 k*)^T (L^-1 f); lowrank: fused + the "
                          "rank-64 Chebyshev factorisation of K(theta, theta*) (exact to 1e-15), 64 + m right-hand sides")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-rng", action="store_true",
+                    help="skip the (untimed for `value`) two iterations under the literal default contract (R-stream replay)")
+    ap.add_argument("--no-single-gpu-reference", action="store_true",
+                    help="N > 1: skip rank 0's single-GPU run of the full problem (item_shard_speedup / whole_iteration_speedup)")
     ap.add_argument("--no-alt-forms", action="store_true",
                     help="skip the extra (untimed for `value`) runs with the other draw_fstar forms")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -85,7 +94,7 @@ def main():
     if args.single_device:
         local_rank = 0
         if world > 2:
-            os.environ.setdefault("GPIRT_PANEL", "2")
+            os.environ.setdefault("GPIRT_PANEL", "2")     # (read once, when the library is loaded below)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -107,10 +116,12 @@ def main():
     FORMS = {"double_solve": dict(fstar_fused=False, kstar_rank=0), "fused": dict(fstar_fused=True, kstar_rank=0),
              "lowrank": dict(fstar_fused=True, kstar_rank=64)}
 
-    def make(form):
+    def make(form, single=False):
         def factory(y_loc, th, pm, ps, st, item0, m_total):
             return Sampler(handle, y_loc, th, pm, ps, st, rng="item", seed=20240, theta_stabilise=True,
                            item0=item0, m_total=m_total, **FORMS[form])
+        if single:      # the FULL problem on this rank alone (rank 0's single-GPU reference inside a sharded run)
+            return ShardedSampler(factory, y, theta0, dist=None)
         return ShardedSampler(factory, y, theta0, dist=dist if world > 1 else None, chol=args.chol, theta=args.theta)
 
     def barrier():
@@ -118,8 +129,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_run(ss):
-        """W warm-up steps, then exactly K timed steps between barrier + synchronize; max over ranks."""
+    def timed_run(ss, local=False):
+        """W warm-up steps, then exactly K timed steps between barrier + synchronize; max over ranks.
+        local: this rank alone (no barrier, no reduction): rank 0's single-GPU reference run."""
+        if local:
+            for _ in range(args.warmup):
+                ss.step()
+            ss.engine.check()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                ss.step()
+            torch.cuda.synchronize()
+            dt_ = time.perf_counter() - t0
+            ss.engine.check()
+            return dt_, None
         for _ in range(args.warmup):
             ss.step()
         ss.engine.check()
@@ -203,23 +227,66 @@ def main():
         ev.record()
         evs.append((name, ev))
 
-    stage_ms = {}
-    for rep in range(2):
-        evs.clear()
-        barrier()
-        timer("start")
-        ss.step(timer)
-        torch.cuda.synchronize()
-        cur = {evs[i][0]: evs[i - 1][1].elapsed_time(evs[i][1]) for i in range(1, len(evs))}
-        stage_ms = cur if not stage_ms else {k: min(stage_ms[k], cur[k]) for k in cur}
-    ss.engine.check()
-    stage_ms = {k: round(v, 3) for k, v in stage_ms.items()}
+    def stage_times(sx, sync=barrier):
+        best = {}
+        for rep in range(2):
+            evs.clear()
+            sync()
+            timer("start")
+            sx.step(timer)
+            torch.cuda.synchronize()
+            cur = {evs[i][0]: evs[i - 1][1].elapsed_time(evs[i][1]) for i in range(1, len(evs))}
+            best = cur if not best else {k: min(best[k], cur[k]) for k in cur}
+        sx.engine.check()
+        return {k: round(v, 3) for k, v in best.items()}
+
+    stage_ms = stage_times(ss)
     # every rank's stage times in rank 0's line: a first multi-GPU run is then diagnosable from one log (a slow rank, a
     # collective that waits, the Cholesky mode in use)
     stage_ms_per_rank = None
     if world > 1:
         stage_ms_per_rank = [None] * world
         dist.all_gather_object(stage_ms_per_rank, stage_ms)        # a few hundred bytes, outside every timed region
+
+    # ---- N > 1: the north star's "item-shard speed-up 1 -> N" as ONE command.  Rank 0 runs the FULL problem alone on its
+    # GPU (the other ranks wait at the barrier, their GPUs idle), same form, same K and W, outside the timed region: stage
+    # times for the item-sharded stages and a timed run for the whole iteration.
+    single = None
+    if world > 1 and not args.no_single_gpu_reference:
+        if rank == 0:
+            s1 = make(form, single=True)
+            s1.init()
+            s1.engine.check()
+            dt1, _ = timed_run(s1, local=True)
+            st1 = stage_times(s1, sync=torch.cuda.synchronize)
+            single = {"iterations_per_s": args.steps / dt1, "stage_ms": st1}
+            del s1
+        barrier()
+
+    # ---- N = 1: what the DEFAULT contract costs (gpirt_default_options: R-stream replay, src/draw-fstar.cpp as written,
+    # draw_theta as written).  The replay is item-sequential by construction -- item j's normals start where item j - 1's
+    # data-dependent slice loop stopped consuming (src/draw-f.cpp:40-58) -- so this is m dependent products per iteration.
+    ref_rng = None
+    if world == 1 and not args.no_reference_rng:
+        from gpirt_amd.ops import RStream
+        sr = Sampler(handle, y, theta0, rng="reference", rstream=RStream(20240), theta_stabilise=False, fstar_fused=False)
+        sr.init()
+        sr.check()
+        sr.step()                       # (first iteration: workspaces)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            sr.step()
+        torch.cuda.synchronize()
+        dtr = time.perf_counter() - t0
+        try:
+            sr.check()
+            ref_rng = {"value": 2.0 / dtr, "iterations": 2,
+                       "contract": "gpirt_default_options: rng = R-stream replay (item-sequential draw_f), draw_fstar = double_solve "
+                                   "as written, theta_stabilise = 0"}
+        except Exception as exc:        # with m >~ 1500 draw_theta as written underflows (quirk Q5): say so instead of dying
+            ref_rng = {"value": None, "iterations": 2, "contract": "gpirt_default_options", "error": repr(exc)}
+        sr.close()
 
     # the same iteration with draw_fstar in the other forms (one GPU only), same K and W: reported beside `value`
     alt = None
@@ -303,6 +370,8 @@ def main():
                     "passed": bool(lowrank_gap <= FSTAR_TOL and lowrank_gap_aw <= FSTAR_TOL * fstar_scale)},
                 "headline_note": headline_note,
                 "iterations_per_s_by_form": alt,
+                "reference_rng_iterations_per_s": None if ref_rng is None else ref_rng["value"],
+                "reference_rng": ref_rng,
                 "item_sharded_stages": sharded + ([] if form == "lowrank" else ["draw_fstar (item part)"]),
                 "replicated_stages": ["factor"] + (["draw_fstar: block inverses of L and the two 64-column solves (per-item part: "
                                                     "64 x m products + epilogue, sharded)"] if form == "lowrank"
@@ -338,6 +407,27 @@ def main():
                 "steps_sampled": n_sampled,
             },
         }
+        if world > 1:
+            # speed-ups against rank 0's single-GPU run of the full problem in this same process (None when it was skipped)
+            out["rccl_ranks"] = dist.get_world_size()
+            out["backend_reported"] = dist.get_backend()
+            if single is not None:
+                sh = [k for k in ("draw_f", "draw_fstar", "draw_beta") if k in single["stage_ms"]]
+                worst = {k: max(r[k] for r in stage_ms_per_rank) for k in sh}          # the slowest rank sets the pace
+                per = {k: (single["stage_ms"][k] / worst[k]) if worst[k] > 1e-3 else None for k in sh}
+                tot1 = sum(single["stage_ms"][k] for k in sh)
+                totN = sum(worst[k] for k in sh)
+                out["item_shard_speedup"] = {"per_stage": per, "total": (tot1 / totN) if totN > 0 else None,
+                                             "single_gpu_stage_ms": {k: single["stage_ms"][k] for k in sh},
+                                             "sharded_stage_ms_max_over_ranks": worst,
+                                             "note": "draw_f, draw_fstar, draw_beta of the FULL problem on rank 0's GPU alone / the same "
+                                                     "stages of the sharded run (slowest rank); draw_beta runs beside the factorisation's "
+                                                     "last outer panel on both sides and is counted where it shows (None: < 1 us)"}
+                out["whole_iteration_speedup"] = out["value"] / single["iterations_per_s"]
+                out["single_gpu_iterations_per_s"] = single["iterations_per_s"]
+            else:
+                out["item_shard_speedup"] = None
+                out["whole_iteration_speedup"] = None
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(n, m, ss.engine, y)

@@ -56,6 +56,11 @@ SIGNATURES = {
     "gpirt_synchronize": (_i32, [_vp]),
     "gpirt_set_stream": (_i32, [_vp, _vp]),
     "gpirt_calibrate_mfma_f64": (_i32, [_vp, _dp]),
+    "gpirt_config_get": (_i32, [_vp, C.c_char_p, C.POINTER(_i32)]),
+    "gpirt_config_set": (_i32, [_vp, C.c_char_p, _i32]),
+    "gpirt_guard_fallbacks": (_i32, [_vp, C.POINTER(_i32)]),
+    "gpirt_debug_trip_guard": (_i32, [_vp, _i32]),
+    "gpirt_debug_last_mcmc_fallbacks": (_i32, []),
     "gpirt_se_kernel": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _dbl]),
     "gpirt_potrf_lower": (_i32, [_vp, _vp, _i64, _i64]),
     "gpirt_factor": (_i32, [_vp, _vp, _i64, _vp, _i64]),
@@ -68,7 +73,7 @@ SIGNATURES = {
     "gpirt_potrf_subpanel_width": (_i64, []),
     "gpirt_potrf_panel_factor_part": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32]),
     "gpirt_potrf_panel_update_part": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _i32]),
-    "gpirt_potrf_panel_copy_part": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _vp, _i32]),
+    "gpirt_potrf_panel_copy_part": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _vp, _i64, _i32]),
     "gpirt_debug_streams_busy": (_i32, [_vp, C.POINTER(_i32)]),
     "gpirt_debug_ll_term": (_i32, [_vp, _vp, _i64, _vp, _i32]),
     "gpirt_debug_panel_trace": (_i32, [_vp, _i64, _vp, _i64]),
@@ -114,7 +119,7 @@ SIGNATURES = {
     "gpirt_sampler_panel_rows": (_i32, [_vp, C.POINTER(_i64)]),
     "gpirt_sampler_panel_factor_part": (_i32, [_vp, _i64, _i32]),
     "gpirt_sampler_panel_update_part": (_i32, [_vp, _i64, _i64, _i32]),
-    "gpirt_sampler_panel_copy_part": (_i32, [_vp, _i64, _i32, _vp, _i32]),
+    "gpirt_sampler_panel_copy_part": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32]),
     "gpirt_sampler_ldl": (_i32, [_vp, C.POINTER(_i64)]),
     "gpirt_sampler_copy_state": (_i32, [_vp, _vp]),
     "gpirt_sampler_accumulate_irf": (_i32, [_vp]),

@@ -11,6 +11,33 @@ namespace gpirt {
 
 static thread_local char g_err[512] = "";
 
+// GPIRT_* switches: the environment is read here, once per process; handles copy the result (gpirt_create)
+static int env_value(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    return atoi(v);
+}
+const Config& env_config()
+{
+    static const Config c = [] {
+        Config d;
+        d.nbo = env_value("GPIRT_NBO", d.nbo);            d.nbp = env_value("GPIRT_NBP", d.nbp);
+        d.lookahead = env_value("GPIRT_LOOKAHEAD", d.lookahead);
+        d.panel = env_value("GPIRT_PANEL", d.panel);      d.defer = env_value("GPIRT_DEFER", d.defer);
+        d.trsm_inv = env_value("GPIRT_TRSM_INV", d.trsm_inv);
+        d.ll_exact = env_value("GPIRT_LL_EXACT", d.ll_exact);
+        d.bordered = env_value("GPIRT_BORDERED", d.bordered);
+        d.early_inv = env_value("GPIRT_EARLY_INV", d.early_inv);
+        d.prep_early = env_value("GPIRT_PREP_EARLY", d.prep_early);
+        d.runtime = env_value("GPIRT_RUNTIME", d.runtime);
+        if (d.nbo < 64) d.nbo = 1024;
+        if (d.nbp < 64) d.nbp = 512;
+        return d;
+    }();
+    return c;
+}
+
 void set_error(const char* fmt, ...)
 {
     va_list ap;
@@ -76,7 +103,7 @@ int report_panel_guard(gpirt_handle_t h, const int* w, hipStream_t stream)
 }
 
 int potrf_panel_copy(hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t p, double* buf, bool to_buf,
-                     int64_t extra_rows, int half)
+                     int64_t extra_rows, int half, int64_t capacity)
 {
     const int64_t W = potrf_panel_width(), H = potrf_subpanel_width(), P0 = p * W;
     if (p < 0 || P0 >= n || half < 0 || half > 2) { set_error("panel %lld / half %d out of range", (long long)p, half); return GPIRT_E_ARG; }
@@ -85,6 +112,11 @@ int potrf_panel_copy(hipStream_t stream, double* A, int64_t n, int64_t lda, int6
     const int64_t K0 = (half == 1) ? mid : P0, K1 = (half == 0) ? mid : P1;     // the columns that travel
     const int64_t w = K1 - K0, rows = n + extra_rows - K0;
     if (w <= 0) return 0;
+    if (capacity >= 0 && rows * w > capacity) {
+        set_error("panel copy: part %d of panel %lld is %lld x %lld doubles, the buffer holds %lld", half, (long long)p,
+                  (long long)rows, (long long)w, (long long)capacity);
+        return GPIRT_E_ARG;
+    }
     double* a = A + K0 + K0 * lda;
     if (to_buf) GP_HIP(hipMemcpy2DAsync(buf, (size_t)rows * 8, a, (size_t)lda * 8, (size_t)rows * 8, (size_t)w, hipMemcpyDeviceToDevice, stream));
     else        GP_HIP(hipMemcpy2DAsync(a, (size_t)lda * 8, buf, (size_t)rows * 8, (size_t)rows * 8, (size_t)w, hipMemcpyDeviceToDevice, stream));
@@ -133,6 +165,7 @@ int gpirt_create(gpirt_handle_t* out, int device, void* stream)
     gpirt_handle_s* h = new (std::nothrow) gpirt_handle_s();
     if (!h) { set_error("out of host memory"); return GPIRT_E_ALLOC; }
     h->device = cur;
+    h->cfg = env_config();
     h->n_cu = prop.multiProcessorCount;
     // stream == NULL is HIP's default (null) stream, like every hipStream_t argument
     h->stream = (hipStream_t)stream;
@@ -161,6 +194,7 @@ int gpirt_create(gpirt_handle_t* out, int device, void* stream)
 int gpirt_destroy(gpirt_handle_t h)
 {
     if (!h) return 0;
+    if (h->live_samplers > 0) { h->zombie = true; return 0; }     // freed by the last sampler's destroy (common.h)
     hipStreamSynchronize(h->stream);
     if (h->d_info) hipFree(h->d_info);
     if (h->h_info) hipHostFree(h->h_info);
@@ -177,18 +211,11 @@ int gpirt_destroy(gpirt_handle_t h)
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->ev_mid) hipEventDestroy(h->ev_mid);
-    if (h->ev_a) hipEventDestroy(h->ev_a);
     if (h->ev_half) hipEventDestroy(h->ev_half);
     if (h->ev_prelast) hipEventDestroy(h->ev_prelast);
     if (h->panel_trace && h->panel_trace_cap > 0) hipFree(h->panel_trace);
     if (h->aux) { hipStreamSynchronize(h->aux->stream); gpirt_destroy(h->aux); h->aux = nullptr; }
-    if (h->rows_stream) hipStreamDestroy(h->rows_stream);
-    if (h->near_stream) hipStreamDestroy(h->near_stream);
-    if (h->chainb_stream) hipStreamDestroy(h->chainb_stream);
-    if (h->d_ready) hipFree(h->d_ready);
-    if (h->d_chain_ws) hipFree(h->d_chain_ws);
     if (h->d_defer_ws) hipFree(h->d_defer_ws);
-    for (auto& e : h->ev_pool) if (e) hipEventDestroy(e);
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -223,6 +250,46 @@ static int create_own_stream(gpirt_handle_t* out, int device, bool high_priority
 }
 
 int gpirt_create_own_stream(gpirt_handle_t* out, int device) { return create_own_stream(out, device, false); }
+
+// The library's switches (README.md), per handle: the value the environment gave at process start, or what a caller set
+// here since.  Geometry (GPIRT_NBO / GPIRT_NBP) is per process and read-only.  Takes effect at the next call that uses it;
+// samplers of the handle read it when they run, their layout switch (GPIRT_BORDERED) when they are created.
+static int* config_slot(gpirt_handle_t h, const char* name, bool* read_only)
+{
+    struct E { const char* k; int* p; bool ro; } tab[] = {
+        { "GPIRT_NBO", &h->cfg.nbo, true }, { "GPIRT_NBP", &h->cfg.nbp, true },
+        { "GPIRT_LOOKAHEAD", &h->cfg.lookahead, false }, { "GPIRT_PANEL", &h->cfg.panel, false },
+        { "GPIRT_DEFER", &h->cfg.defer, false }, { "GPIRT_TRSM_INV", &h->cfg.trsm_inv, false },
+        { "GPIRT_LL_EXACT", &h->cfg.ll_exact, false }, { "GPIRT_BORDERED", &h->cfg.bordered, false },
+        { "GPIRT_EARLY_INV", &h->cfg.early_inv, false }, { "GPIRT_PREP_EARLY", &h->cfg.prep_early, false },
+        { "GPIRT_RUNTIME", &h->cfg.runtime, false },
+    };
+    for (auto& e : tab)
+        if (strcmp(e.k, name) == 0) { if (read_only) *read_only = e.ro; return e.p; }
+    return nullptr;
+}
+
+int gpirt_config_get(gpirt_handle_t h, const char* name, int* value)
+{
+    GP_ARG(h && name && value);
+    int* p = config_slot(h, name, nullptr);
+    if (!p) { set_error("unknown switch '%s'", name); return GPIRT_E_ARG; }
+    *value = *p;
+    return 0;
+}
+
+int gpirt_config_set(gpirt_handle_t h, const char* name, int value)
+{
+    GP_ARG(h && name);
+    bool ro = false;
+    int* p = config_slot(h, name, &ro);
+    if (!p) { set_error("unknown switch '%s'", name); return GPIRT_E_ARG; }
+    if (ro) { set_error("%s is fixed per process (set it in the environment before the library is loaded)", name); return GPIRT_E_ARG; }
+    GP_HIP(hipStreamSynchronize(h->stream));
+    *p = value;
+    if (h->aux) *config_slot(h->aux, name, nullptr) = value;
+    return 0;
+}
 
 int gpirt_set_stream(gpirt_handle_t h, void* stream)
 {
@@ -288,8 +355,42 @@ int gpirt_factor(gpirt_handle_t h, const double* d_theta, int64_t n, double* d_L
     GP_ARG(h && d_theta && d_L && n >= 0 && ldl >= n);
     GP_TRY(launch_se_kernel(h->stream, d_theta, n, d_theta, n, d_L, ldl, GPIRT_JITTER));
     GP_TRY(launch_potrf_lower(h, h->stream, d_L, n, ldl, true));
+    GP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 8 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    GP_HIP(hipStreamSynchronize(h->stream));
+    if (h->h_info[1] != 0 && h->cfg.panel != 2) {
+        // The persistent panel kernel gave up on a progress counter (its work-groups were not co-resident in time, e.g.
+        // beside a foreign tenant).  theta is intact, so K is rebuilt and factored once more with the launch-per-step
+        // panel; only a failure of THAT is an error.
+        GP_TRY(potrf_guard_reset(h, h->stream));
+        const int saved = h->cfg.panel;
+        h->cfg.panel = 2;
+        int rc = launch_se_kernel(h->stream, d_theta, n, d_theta, n, d_L, ldl, GPIRT_JITTER);
+        if (!rc) rc = launch_potrf_lower(h, h->stream, d_L, n, ldl, true);
+        h->cfg.panel = saved;
+        GP_TRY(rc);
+    }
     return finish_info(h);
 }
+
+int gpirt_guard_fallbacks(gpirt_handle_t h, int* count)
+{
+    GP_ARG(h && count);
+    *count = h->guard_fallbacks;
+    return 0;
+}
+
+// Debug: the nth factorisation from now on this handle (nth >= 1; 0 disarms) ends as a hang-guard expiry would leave it --
+// guard word raised, result unfinished -- so the fallback can be tested without spinning a kernel to its bound.
+// h == NULL arms the NEXT handle gpirt_mcmc creates for itself.
+static long long g_trip_next_mcmc = 0;
+int gpirt_debug_trip_guard(gpirt_handle_t h, int nth)
+{
+    GP_ARG(nth >= 0);
+    if (!h) { g_trip_next_mcmc = nth; return 0; }
+    h->trip_guard_at = nth > 0 ? h->factor_count + nth : -1;
+    return 0;
+}
+long long gpirt_debug_take_mcmc_trip(void) { const long long v = g_trip_next_mcmc; g_trip_next_mcmc = 0; return v; }
 
 // ---- distributed factorisation pieces (no host synchronisation; info is read by gpirt_potrf_finish) ----------------
 int64_t gpirt_potrf_panel_width(void) { return potrf_panel_width(); }
@@ -335,22 +436,21 @@ int gpirt_potrf_panel_update_part(gpirt_handle_t h, double* d_A, int64_t n, int6
     return potrf_panel_update(h, h->stream, d_A, n, lda, p, c, 0, part);
 }
 
-int gpirt_potrf_panel_copy_part(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda, int64_t p, int half, double* d_buf, int to_buf)
+int gpirt_potrf_panel_copy_part(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda, int64_t p, int half, double* d_buf,
+                                int64_t buf_doubles, int to_buf)
 {
-    GP_ARG(h && d_A && d_buf && n > 0 && lda >= n && p >= 0);
-    return potrf_panel_copy(h->stream, d_A, n, lda, p, d_buf, to_buf != 0, 0, half);
+    GP_ARG(h && d_A && d_buf && n > 0 && lda >= n && p >= 0 && buf_doubles >= 0);
+    return potrf_panel_copy(h->stream, d_A, n, lda, p, d_buf, to_buf != 0, 0, half, buf_doubles);
 }
 
 // Debug aid for hosts that put collectives between the pieces: every piece must have joined the handle's stream before it
 // returns (the library forks look-ahead work onto streams of its own).  *busy = bit mask of the handle's internal streams
-// that still have work in flight (0 = all idle): side 1, rows 2, near 4, chain-B 8.  Does not synchronise.
+// that still have work in flight (0 = all idle): bit 0 = the look-ahead side stream.  Does not synchronise.
 int gpirt_debug_streams_busy(gpirt_handle_t h, int* busy)
 {
     GP_ARG(h && busy);
     int m = 0;
-    hipStream_t st[4] = { h->side, h->rows_stream, h->near_stream, h->chainb_stream };
-    for (int i = 0; i < 4; ++i)
-        if (st[i] && hipStreamQuery(st[i]) == hipErrorNotReady) m |= 1 << i;
+    if (h->side && hipStreamQuery(h->side) == hipErrorNotReady) m |= 1;
     (void)hipGetLastError();
     *busy = m;
     return 0;

@@ -55,10 +55,30 @@ struct Prof {
     std::vector<ProfPair> free_pairs;
 };
 
+// The library's environment switches.  Read ONCE per process (env_config(), api.hip), copied into every handle at
+// creation; the non-geometry ones can be changed per handle through gpirt_config_set (tests do, instead of editing the
+// environment between calls).  Defaults are the measured optimum at n = 8192 (README.md has the table).
+struct Config {
+    int  nbo = 1024, nbp = 512;   // GPIRT_NBO / GPIRT_NBP: outer panel width (K of a trailing update) / sub-panel width
+    int  lookahead = 1;           // GPIRT_LOOKAHEAD: 1 = the next panel is factored on a side stream beside the updates, 2 = off
+    int  panel = 1;               // GPIRT_PANEL: 1 = persistent sub-panel kernel (panel.hip), 2 = launch-per-step panel (the
+                                  //   fallback a hang-guard expiry refactors with)
+    int  defer = 0;               // GPIRT_DEFER: 3 = trailing updates deferred block column by block column, 2 = plain
+                                  //   right-looking order, 0 = by size (3 up to n = 14336)
+    int  trsm_inv = 1;            // GPIRT_TRSM_INV: 2 = every trsm leaf is a substitution (parity attribution)
+    int  ll_exact = 0;            // GPIRT_LL_EXACT: 1 = the slice kernel evaluates log(1 + exp(-a)) as written
+    int  bordered = 1;            // GPIRT_BORDERED: 2 = draw_fstar solves for L^-1 K(theta, c) / L^-1 k* explicitly
+    int  early_inv = 1;           // GPIRT_EARLY_INV: 2 = no side work beside the factorisation's last outer panel
+    int  prep_early = 1;          // GPIRT_PREP_EARLY: 2 = the factor-only part of the rank-r draw_fstar waits for nu = L z
+    int  runtime = 1;             // GPIRT_RUNTIME: see potrf.hip
+};
+const Config& env_config();
+
 }  // namespace gpirt
 
 struct gpirt_handle_s {
     int          device = 0;
+    gpirt::Config cfg;
     hipStream_t  stream = nullptr;
     bool         own_stream = false;
     // small persistent workspace
@@ -69,7 +89,7 @@ struct gpirt_handle_s {
     gpirt::Prof  prof;
     // look-ahead Cholesky: high-priority side stream for the panel chain + fork/join events
     hipStream_t  side = nullptr;
-    hipEvent_t   ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr, ev_a = nullptr, ev_half = nullptr;
+    hipEvent_t   ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr, ev_half = nullptr;
     // The samplers' side work (the factor-only part of draw_fstar, block inverses, the next draw_f's normals, draw_beta) runs
     // on ONE high-priority handle per main handle, shared by every sampler created on it (samplers of a handle are driven
     // one after the other anyway).  Round 3: a handle per SAMPLER meant a new high-priority stream per sampler, and with
@@ -84,21 +104,26 @@ struct gpirt_handle_s {
     unsigned long long* d_prog = nullptr;
     double*      d_winv = nullptr;        // panel.hip: inverses of the diagonal blocks' 16 x 16 blocks, handed along the pivot chain
     int64_t      winv_blocks = 0;         //   ... one 4 x 256 slot per 64-column block of the matrix
-    hipStream_t  rows_stream = nullptr;   // potrf.hip (windowed schedule): the rows far below the chain launches + their updates
-    hipStream_t  near_stream = nullptr;   //   ... and the rows of the NEXT outer panel (what the chain needs next)
-    hipStream_t  chainb_stream = nullptr; //   ... second sub-panels' chain launches (pre-launched beside the first sub-panel's)
-    unsigned long long* d_ready = nullptr;//   ... [2] ready flags of the pre-launched chain launches (first / second sub-panel)
     double*      d_defer_ws = nullptr;    // potrf.hip: slabs of the panel-parallel deferred updates (launch_syrk_panels)
     size_t       defer_ws_bytes = 0;
-    double*      d_chain_ws = nullptr;    //   ... split-K parts of the small updates on the chain (4 x 1024 x 1024 doubles)
-    int          win_state = 0;           //   ... 0 = not probed, 1 = streams on separate hardware queues (usable), 2 = not usable
-    hipEvent_t   ev_pool[16] = {};        //   ... and the cross-stream events
     size_t       prog_cap = 0;
     unsigned long long prog_seq = 0;
     long long*   panel_trace = nullptr;   // debug stamps (micro-benchmarks; gpirt_debug_panel_trace)
     int64_t      panel_trace_k0 = -1;     // >= 0: only the sub-panel launch that starts at this column stamps
     int64_t      panel_trace_cap = 0;     // entries allocated by gpirt_debug_panel_trace
     int          n_cu = 0;                // compute units of `device` (grid cap of the persistent kernel)
+    // hang-guard fallback (sampler.hip recover_factor, api.hip finish_info): a factorisation whose persistent kernel gave
+    // up on a progress counter is repeated once with the launch-per-step panel; counted here (gpirt_guard_fallbacks)
+    // Samplers borrow the handle (its stream, workspaces, side handle).  A handle destroyed while samplers still live --
+    // e.g. a host language tearing objects down in arbitrary order at exit -- is only marked (zombie) and freed by the last
+    // sampler's destroy: round 3's `std::bad_variant_access` abort at interpreter exit was gpirt_sampler_destroy draining the
+    // stream of a handle that had already been freed.
+    int          live_samplers = 0;
+    bool         zombie = false;
+    int          guard_fallbacks = 0;
+    long long    factor_count = 0;        // factorisations enqueued on this handle (launch_potrf_lower)
+    long long    trip_guard_at = -1;      // debug (gpirt_debug_trip_guard): the factorisation with this count raises the
+                                          //   guard word and poisons its result behind itself, as an expiry would leave it
     bool         panel_attr_set = false;  // dynamic-LDS attribute of panel_ll_kernel set on this device
     // gemm_f64.hip: parts of automatically split-K products
     double*      d_splitk = nullptr;

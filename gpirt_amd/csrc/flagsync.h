@@ -16,9 +16,7 @@
 // "One work-group per CU" in the guide's table is the regime the form was MEASURED in.  panel_ll_kernel meets it for
 // its own work-groups (148 KB of LDS each); foreign work-groups that fit beside one (no LDS to speak of, <= 152 registers) do
 // not change the argument, because it never relied on the CU's L1: every load of a handed-off byte is an sc1 load (served
-// past the L1) and every such byte was stored sc1 (written through, dropped from the producer's L2).  panel_rows_kernel
-// (two or three work-groups per CU, beside update work-groups) is a CONSUMER only, of the same sc1 bytes, and is outside
-// the measured regime: it is opt-in (GPIRT_SCHED=2 / GPIRT_ROWS=1) and checked bit for bit against the one-launch factor.
+// past the L1) and every such byte was stored sc1 (written through, dropped from the producer's L2).
 // The fenced form (-DGPIRT_PANEL_FENCES, `make fences`) is built and compared bit for bit by tests/test_gpu_fences.py.
 //
 // Rules that keep such kernels safe on this hardware:

@@ -23,7 +23,6 @@
 #include "kernels.h"
 #include "potf2.h"
 
-#include <stdlib.h>
 #include <type_traits>
 
 namespace gpirt {
@@ -31,6 +30,7 @@ namespace gpirt {
 namespace {
 
 constexpr int BK = 16;
+constexpr int T128_MIN = 448;        // number of 128 x 128 tiles from which a product uses the 128-tile kernel (2 per CU)
 constexpr int LDS_K = BK + 2;        // [mn][k] row stride (doubles)
 // Block tile T x T (T = 128: 4 x 4 MFMA tiles per wave, the throughput configuration;
 // T = 64: 2 x 2 tiles per wave, 4x as many work-groups and ~4x shorter k-steps -- used when the
@@ -597,86 +597,6 @@ int launch_gemm_update_potf2(hipStream_t stream, int64_t M, int64_t N, int64_t K
     return 0;
 }
 
-// Rectangular piece of a factorisation update (windowed schedule, potrf.hip): C (M x N) = beta C + alpha A B^T with the
-// same PAD = 8 instantiations as the syrk launches (one kernel name per tile size in traces and PMC profiles), never split
-// over K: per element the same sum in the same order as the syrk launch that used to cover these rows.
-bool gemm_rect_uses_128(int64_t M, int64_t N)
-{
-    static const int bmin = getenv("GPIRT_BG128_MIN") ? atoi(getenv("GPIRT_BG128_MIN")) : 448;
-    return ((M + 127) / 128) * ((N + 127) / 128) >= bmin;
-}
-
-int launch_gemm_nosplit(hipStream_t stream, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
-                        int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc)
-{
-    if (M <= 0 || N <= 0) return 0;
-    if (ta || !tb) { set_error("launch_gemm_nosplit: NT form only"); return GPIRT_E_ARG; }
-    GemmParams p;
-    p.A = A; p.B = B; p.C = C;
-    p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-    p.M = (int)M; p.N = (int)N; p.K = (int)K; p.Mr = 0;
-    p.alpha = alpha; p.beta = beta; p.tri = TRI_NONE;
-    p.fz_A = nullptr; p.fz_lda = 0; p.fz_nb = 0; p.fz_k0 = 0; p.fz_info = nullptr;
-    p.sA = p.sB = p.sC = 0; p.ksplit = 0;
-    p.fastA = (((uintptr_t)A & 15) == 0) && (lda % 2 == 0);
-    p.fastB = (((uintptr_t)B & 15) == 0) && (ldb % 2 == 0);
-    if (gemm_rect_uses_128(M, N)) {
-        p.mblocks = (p.M + 127) / 128; p.nblocks = (p.N + 127) / 128;
-        hipLaunchKernelGGL((gemm_f64_kernel<false, true, 128, 8>), dim3((unsigned)((int64_t)p.mblocks * p.nblocks)), dim3(256), 0, stream, p);
-    } else {
-        p.mblocks = (p.M + 63) / 64; p.nblocks = (p.N + 63) / 64;
-        hipLaunchKernelGGL((gemm_f64_kernel<false, true, 64, 8>), dim3((unsigned)((int64_t)p.mblocks * p.nblocks)), dim3(256), 0, stream, p);
-    }
-    GP_HIP(hipGetLastError());
-    return 0;
-}
-
-// Small updates ON THE PIVOT CHAIN of the windowed factorisation (the K = 512 update of a 512 x 512 diagonal triangle, the
-// K = 1024 update of the next 1024 x 1024 diagonal trapezoid): 36 / 136 tiles with 32 / 64 dependent K-steps each run at the
-// latency of a lone work-group per CU (52 / 82 us measured).  Here the K range is cut into `nsplit` parts computed side by
-// side into `work` (nsplit slabs of M x N, ldc = M) and added to C in a FIXED order: the lower trapezoid
-// C[r, c] (r >= c) = beta C + sum_q part_q.  Deterministic; rounding differs from the unsplit launch in the last bits,
-// so every schedule of the factorisation (and its pieces) sends these same regions through here.
-__global__ __launch_bounds__(256) void sum_parts_lower_kernel(const double* __restrict__ part, int64_t M, int64_t N, int64_t stride,
-                                                              int nparts, double beta, double* __restrict__ out, int64_t ldo)
-{
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= M * N) return;
-    const int64_t r = i % M, c = i / M;
-    if (r < c) return;
-    double acc = 0.0;
-    for (int q = 0; q < nparts; ++q) acc += part[i + q * stride];
-    double* o = out + r + c * ldo;
-    *o = (beta != 0.0) ? beta * (*o) + acc : acc;
-}
-
-int launch_syrk_splitk(hipStream_t stream, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
-                       const double* B, int64_t ldb, double beta, double* C, int64_t ldc, double* work, int nsplit)
-{
-    if (M <= 0 || N <= 0) return 0;
-    if (M < N || nsplit < 1) { set_error("launch_syrk_splitk: needs M >= N"); return GPIRT_E_ARG; }
-    constexpr int T = 64;
-    GemmParams p;
-    p.A = A; p.B = B; p.C = work;
-    p.lda = lda; p.ldb = ldb; p.ldc = M;
-    p.M = (int)M; p.N = (int)N; p.K = (int)K; p.Mr = 0;
-    p.alpha = alpha; p.beta = 0.0; p.tri = TRI_SYRK_LOWER;
-    p.fz_A = nullptr; p.fz_lda = 0; p.fz_nb = 0; p.fz_k0 = 0; p.fz_info = nullptr;
-    p.sA = p.sB = 0; p.sC = M * N;
-    p.ksplit = (int)((((K + nsplit - 1) / nsplit) + BK - 1) / BK * BK);
-    const int parts = (int)((K + p.ksplit - 1) / p.ksplit);
-    p.fastA = (((uintptr_t)A & 15) == 0) && (lda % 2 == 0);
-    p.fastB = (((uintptr_t)B & 15) == 0) && (ldb % 2 == 0);
-    p.mblocks = (p.M + T - 1) / T;
-    p.nblocks = (p.N + T - 1) / T;
-    const int64_t grid = (int64_t)p.nblocks * p.mblocks - (int64_t)p.nblocks * (p.nblocks - 1) / 2;
-    hipLaunchKernelGGL((gemm_f64_kernel<false, true, 64, 8>), dim3((unsigned)grid, (unsigned)parts), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(sum_parts_lower_kernel, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, stream, work, M, N, M * N, parts,
-                       beta, C, ldc);
-    GP_HIP(hipGetLastError());
-    return 0;
-}
-
 // Several trailing updates of ONE block column by consecutive panels, as one launch: the panels' columns are contiguous in
 // memory, so  C -= sum_q P_q P_q^T  is a single product over K = parts * kpart cut at the panel boundaries (blockIdx.y picks
 // the panel).  Each part lands in its own slab of `work` as alpha * P_q P_q^T, and the sum kernel then applies them to C ONE
@@ -725,10 +645,9 @@ int launch_syrk_panels(hipStream_t stream, int64_t M, int64_t N, int64_t kpart, 
 
 bool gemm_trailing_uses_128(int64_t M, int64_t N, bool background)
 {
-    static const int tmin = getenv("GPIRT_TRAIL128_MIN") ? atoi(getenv("GPIRT_TRAIL128_MIN")) : 448;
-    static const int bmin = getenv("GPIRT_BG128_MIN") ? atoi(getenv("GPIRT_BG128_MIN")) : 448;
+    (void)background;      // (one threshold for both since round 3: 150-320 measured 4.88-5.24 ms against 4.85)
     const int64_t mb = (M + 127) / 128, nb = (N + 127) / 128;
-    return nb * mb - nb * (nb - 1) / 2 >= (background ? bmin : tmin);
+    return nb * mb - nb * (nb - 1) / 2 >= T128_MIN;
 }
 
 template <int T>
@@ -815,8 +734,8 @@ int launch_gemm_splitk(hipStream_t stream, bool ta, bool tb, int64_t M, int64_t 
 // completely before its result is written by the summing kernel, so C may then alias an operand.
 int gemm_split_count(gpirt_handle_t h, hipStream_t stream, int tri, int64_t M, int64_t N, int64_t K)
 {
-    static const bool splitk_on = !(getenv("GPIRT_SPLITK") && atoi(getenv("GPIRT_SPLITK")) == 2);
-    static const int t128_min = getenv("GPIRT_T128_MIN") ? atoi(getenv("GPIRT_T128_MIN")) : 448;
+    constexpr bool splitk_on = true;
+    constexpr int t128_min = T128_MIN;
     const int64_t tiles64 = ((M + 63) / 64) * ((N + 63) / 64);
     if (!splitk_on || h == nullptr || stream != h->stream || tri != TRI_NONE || tiles64 > 320 || K < 256) return 1;
     if (((M + 127) / 128) * ((N + 127) / 128) >= t128_min) return 1;
@@ -826,11 +745,7 @@ int gemm_split_count(gpirt_handle_t h, hipStream_t stream, int tri, int64_t M, i
     return split >= 2 ? (int)split : 1;
 }
 
-static int t128_min_or_default()
-{
-    static const int v = getenv("GPIRT_T128_MIN") ? atoi(getenv("GPIRT_T128_MIN")) : 448;
-    return v;
-}
+static int t128_min_or_default() { return T128_MIN; }
 
 int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri, int64_t M,
                 int64_t N, int64_t K, double alpha, const double* A, int64_t lda, const double* B,
@@ -860,7 +775,7 @@ int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri,
         // the factorisation's own updates (only potrf.hip asks for this mode): same split between the tile sizes as
         // every other product, but under the PAD = 8 names, so traces tell them apart from draw_theta's NT product
         const int64_t mb_ = (M + 127) / 128, nb_ = (N + 127) / 128;
-        static const int t128_min_ = getenv("GPIRT_T128_MIN") ? atoi(getenv("GPIRT_T128_MIN")) : 448;
+        constexpr int t128_min_ = T128_MIN;
         if (nb_ * mb_ - nb_ * (nb_ - 1) / 2 >= t128_min_) return launch_gemm_trailing(stream, p);
         return launch_gemm_syrk64(stream, p);
     }
@@ -877,7 +792,7 @@ int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri,
     // -- each with the full K range -- do not fill the chip (8192 x 128: 128 of them, 290 us).  The K range of every
     // tile is cut into S parts computed side by side and added in a fixed order, like the split below.
     if ((tri == TRI_A_LOWER || tri == TRI_A_UPPER) && h != nullptr && stream == h->stream && K >= 1024) {
-        static const bool tri_split_on = !(getenv("GPIRT_SPLITK") && atoi(getenv("GPIRT_SPLITK")) == 2);
+        constexpr bool tri_split_on = true;
         const int64_t pairs = (((M + 63) / 64 + 1) / 2) * ((N + 63) / 64);
         int S = (int)(384 / (pairs > 0 ? pairs : 1));
         if (S > 4) S = 4;
@@ -902,7 +817,7 @@ int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri,
     }
     // Few tiles and a long K: a lone work-group per CU runs its K loop at LDS / barrier latency (~1.1 us per
     // K-step against 0.43 us of MFMA), so the K range is cut into `split` parts computed side by side and added
-    // in a fixed order (GPIRT_SPLITK=2 switches it off).  Main stream only: the parts share one workspace.
+    // in a fixed order .  Main stream only: the parts share one workspace.
     {
         const int split = gemm_split_count(h, stream, tri, M, N, K);
         if (split >= 2) {

@@ -22,12 +22,6 @@ int launch_gemm_batched(hipStream_t stream, bool ta, bool tb, int tri, int64_t M
                         const double* A, int64_t lda, int64_t strideA, const double* B, int64_t ldb, int64_t strideB,
                         double beta, double* C, int64_t ldc, int64_t strideC, int batch);
 
-bool gemm_rect_uses_128(int64_t M, int64_t N);
-int launch_gemm_nosplit(hipStream_t stream, bool ta, bool tb, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
-                        int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc);
-// lower trapezoid C (M x N, M >= N) = beta C + alpha A B^T with the K range cut into nsplit parts (work: nsplit * M * N doubles)
-int launch_syrk_splitk(hipStream_t stream, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
-                       const double* B, int64_t ldb, double beta, double* C, int64_t ldc, double* work, int nsplit);
 // nparts consecutive trailing updates of one block column (panel q = columns [q * kpart, (q + 1) * kpart) of A / B) as one
 // launch + an in-order application: bit-identical to nparts separate launches (work: nparts * M * N doubles)
 int launch_syrk_panels(hipStream_t stream, int64_t M, int64_t N, int64_t kpart, int nparts, double alpha, const double* A,
@@ -50,6 +44,8 @@ int launch_se_kernel_lower(hipStream_t stream, const double* x, int64_t n, doubl
 int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda,
                        bool zero_upper, bool reset_info = true, int64_t extra_rows = 0);
 
+int potrf_guard_reset(gpirt_handle_t h, hipStream_t stream);      // hang-guard fallback: see potrf.hip
+
 // the same factorisation in pieces (distributed hosts): outer panel p = columns [p W, (p + 1) W)
 int64_t potrf_panel_width();
 int64_t potrf_subpanel_width();
@@ -60,19 +56,13 @@ int potrf_panel_factor(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
 int potrf_panel_update(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t p, int64_t c,
                        int64_t extra_rows = 0, int part = 2);
 // half as for potrf_panel_factor: the columns of that part of the panel, rows from the part's first row down
+// capacity: doubles the buffer holds (< 0: not checked) -- a part that does not fit is refused, never truncated
 int potrf_panel_copy(hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t p, double* buf, bool to_buf,
-                     int64_t extra_rows = 0, int half = 2);
+                     int64_t extra_rows = 0, int half = 2, int64_t capacity = -1);
 
 // panel.hip: columns [K0, c1) of the Cholesky factor, all rows below, one persistent kernel
 int launch_panel_ll(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t K0, int64_t c1,
-                    int64_t row_end = 0, unsigned long long* epoch_out = nullptr, const unsigned long long* ready = nullptr);
-// ready != nullptr: a PRE launch -- resident at once, starts its sweep when *ready reaches the launch's own epoch
-// (launch_flag_store(stream, ready, epoch) behind the kernel that produces its input)
-int launch_flag_store(hipStream_t stream, unsigned long long* flag, unsigned long long value);
-int panel_queue_probe(hipStream_t spin_stream, hipStream_t set_stream, unsigned long long* flag, int* d_result, int* ok);
-// the rows [r0, r1) a restricted launch_panel_ll left out, against its counters (epoch): beside it or after it
-int launch_panel_rows(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t K0, int64_t c1,
-                      int64_t r0, int64_t r1, unsigned long long epoch, bool lean = true);
+                    int64_t row_end = 0, unsigned long long* epoch_out = nullptr);
 
 // trsm.hip
 int launch_trsm_lower(gpirt_handle_t h, hipStream_t stream, const double* L, int64_t n, int64_t ldl,
@@ -102,6 +92,7 @@ struct EssArgs {
     uint64_t seed; uint32_t iter; uint32_t item0;
     // R-stream replay (U != null): one column per launch, uniforms from U[*pos + 2n ...]
     const double* U; uint64_t* pos; uint64_t cap;
+    int ll_exact;         // 1: log(1 + exp(-a)) through the library's exp and log, as written (GPIRT_LL_EXACT)
 };
 int launch_ess(hipStream_t stream, const EssArgs& a);
 int launch_ll_term_probe(hipStream_t stream, const double* a, int64_t n, double* out, bool fast);

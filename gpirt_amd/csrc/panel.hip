@@ -46,15 +46,8 @@ struct PanelArgs {
     int* info;
     int nrb;                               // row blocks of this panel (rows K0 .. n-1)
     int ncb;                               // column blocks of this panel
-    int rb_begin, rb_end;                  // this launch sweeps the panel's row blocks [rb_begin, rb_end) (relative to K0): the
-                                           // chain launch takes the diagonal owners and the rows just below them, the rest of
-                                           // the rows goes to panel_rows_kernel -- same epoch, so both consume the same counters
+    int rb_begin, rb_end;                  // this launch sweeps the panel's row blocks [rb_begin, rb_end) (relative to K0)
     long long* trace;                      // optional (tools/micro/panel_bench.hip): [row block][step][8] 100 MHz stamps
-    // (PRE) a launch that is enqueued BEFORE its input exists, so that its work-groups -- each needs a whole compute unit
-    // -- are resident when the input arrives instead of waiting for the updates beside them to drain: every work-group
-    // first waits for *ready >= ready_val (raised by flag_store_kernel behind the update that produces the input)
-    const unsigned long long* ready;
-    unsigned long long ready_val;
 };
 
 #define PANEL_STAMP(slot)                                                                         \
@@ -140,9 +133,6 @@ __device__ __forceinline__ void store_block_lds(const double (&v)[16], double* _
 // the wave's 16-row strip of a 64-column block, in the accumulator layout of solve64.h:
 // lane (i, g) gets columns 16J + 4g + r of row  row0 + 16 wave + i.  ncols < 64 only for the matrix's
 // last, ragged block (then the column index is clamped per lane).
-// FRESH: the data was written by a kernel that finished AFTER this one started (PRE launches): no kernel boundary has
-// invalidated this XCD's L2 since, so the loads must bypass it (sc1), like those of a neighbour's hand-off
-template <bool FRESH = false>
 __device__ __forceinline__ void load_strip(d4 (&X)[4], const double* A, int64_t lda, int64_t n,
                                            int64_t row0, int64_t col0, int ncols)
 {
@@ -157,16 +147,14 @@ __device__ __forceinline__ void load_strip(d4 (&X)[4], const double* A, int64_t 
 #pragma unroll
         for (int J = 0; J < 4; ++J)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) X[J][r] = FRESH ? ldg_sc1(A + row0 + (col0 + 16 * J + r) * lda, voff)
-                                                        : ldg_off(A + row0 + (col0 + 16 * J + r) * lda, voff);
+            for (int r = 0; r < 4; ++r) X[J][r] = ldg_off(A + row0 + (col0 + 16 * J + r) * lda, voff);
     } else if (ncols == PB) {
         const uint32_t voff = (uint32_t)((rc + (int64_t)(4 * g) * lda) * 8);
 #pragma unroll
         for (int J = 0; J < 4; ++J)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double x = FRESH ? ldg_sc1(A + row0 + (col0 + 16 * J + r) * lda, voff)
-                                       : ldg_off(A + row0 + (col0 + 16 * J + r) * lda, voff);
+                const double x = ldg_off(A + row0 + (col0 + 16 * J + r) * lda, voff);
                 X[J][r] = live ? x : 0.0;
             }
     } else {
@@ -176,8 +164,7 @@ __device__ __forceinline__ void load_strip(d4 (&X)[4], const double* A, int64_t 
             for (int r = 0; r < 4; ++r) {
                 const int c = 16 * J + 4 * g + r;
                 const bool ok = live && c < ncols;
-                const double x = FRESH ? ldg_sc1(A + row0 + rc + (col0 + (c < ncols ? c : 0)) * lda, 0u)
-                                       : ldg_off(A + row0 + rc + (col0 + (c < ncols ? c : 0)) * lda, 0u);
+                const double x = ldg_off(A + row0 + rc + (col0 + (c < ncols ? c : 0)) * lda, 0u);
                 X[J][r] = ok ? x : 0.0;
             }
     }
@@ -247,13 +234,12 @@ __device__ __forceinline__ void strip_to_lds(const d4 (&X)[4], double* sB)
         for (int r = 0; r < 4; ++r) sB[(16 * J + 4 * g + r) * S64_LS + 16 * wave + i] = X[J][r];
 }
 
-template <bool PROG, bool PRE = false>
 __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     // Two 64 x 64 buffers (34 KB each): the "other" GEMM operand alternates between them, and whichever
     // one the last chunk did not use then takes L_jj for the solve and X for the diagonal update; a third holds D
-    // and (PROG) a fourth stages the chunks' own-row operand (below).  148 KB in all (114 without the fourth), so two of
+    // and a fourth stages the chunks' own-row operand (below).  148 KB in all (114 without the fourth), so two of
     // these work-groups never share a CU (160 KB).  The kernel runs at 329 registers per lane (<true>; 422 <false>), not
     // the full 512: a small foreign work-group (<= 12 KB of LDS, <= 176 registers -- a split-K sum, a copy-back, a flag
     // store) CAN sit beside it.  That does not touch the hand-off protocol: no handed-off
@@ -262,11 +248,11 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
     double* sT0 = smem;
     double* sT1 = smem + PB * S64_LS;
     double* sXT = smem + 2 * PB * S64_LS;             // potf2's multiplier copy
-    // (PROG) the diagonal block D of a diagonal owner lives HERE between its steps, not in 32 accumulator registers:
+    // The diagonal block D of a diagonal owner lives HERE between its steps, not in 32 accumulator registers:
     // each step reads its strip, updates it and writes it back (own rows only: no barrier), potf2 factors it in place,
     // and the register allocator no longer spills D around the chunk loop (its reload sat on the pivot chain)
     double* sDD = smem + 2 * PB * S64_LS + PB * POTF2_XS;
-    // (PROG) staging area of the chunks' own-row operand: one slice of 8 x 136 doubles per wave (below)
+    // Staging area of the chunks' own-row operand: one slice of 8 x 136 doubles per wave (below)
     double* sXI = smem + 3 * PB * S64_LS + PB * POTF2_XS;
     __shared__ unsigned long long s_seen;
 
@@ -276,31 +262,6 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
     double* A = p.A;      // read and written by many work-groups: no restrict anywhere in this file
     const int64_t lda = p.lda, n = p.n;
     const int cb0 = (int)(p.K0 / PB);                 // absolute index of the panel's first block
-    if (PRE) {
-        // resident, waiting for the input: one lane polls (naps between polls: the chain launch in front of this one
-        // shares the chip), bounded like every other wait
-        if (threadIdx.x == 0) {
-            unsigned long long v = ld_prog(p.ready);
-            int spins = 0;
-            while (v < p.ready_val && ++spins < SPIN_LIMIT) { __builtin_amdgcn_s_sleep(8); v = ld_prog(p.ready); }
-            if (v < p.ready_val) {
-                if (atomicCAS(p.info + 1, 0, 1) == 0) {
-                    p.info[2] = -2; p.info[3] = (int)blockIdx.x;
-                    p.info[4] = (int)(p.ready_val & 0xffffffffu); p.info[5] = (int)(p.ready_val >> 32);
-                    p.info[6] = (int)(v & 0xffffffffu);           p.info[7] = (int)(v >> 32);
-                }
-                v = 0;
-            }
-            s_seen = v;
-        }
-        __syncthreads();
-        if (s_seen == 0) return;
-#ifdef GPIRT_PANEL_FENCES
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
-        __syncthreads();
-    }
-
     for (int Rr = p.rb_begin + blockIdx.x; Rr < p.rb_end; Rr += gridDim.x) {
         const int64_t row0 = p.K0 + (int64_t)Rr * PB;
         const bool is_diag = Rr < p.ncb;
@@ -311,17 +272,15 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
         if (is_diag) {
             const int64_t left = p.c1 - row0;
             dcols = (int)(left < PB ? left : PB);
-            load_strip<PRE>(D, A, lda, n, row0, row0, dcols);
-            if (PROG) {
+            load_strip(D, A, lda, n, row0, row0, dcols);
 #pragma unroll
-                for (int J = 0; J < 4; ++J)
+            for (int J = 0; J < 4; ++J)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int c = 16 * J + 4 * g + r, rr = 16 * wave + i;
-                        if (rr >= dcols || c >= dcols) D[J][r] = (rr == c) ? 1.0 : 0.0;      // identity past a ragged end
-                    }
-                strip_to_lds(D, sDD);
-            }
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 16 * J + 4 * g + r, rr = 16 * wave + i;
+                    if (rr >= dcols || c >= dcols) D[J][r] = (rr == c) ? 1.0 : 0.0;      // identity past a ragged end
+                }
+            strip_to_lds(D, sDD);
         }
         for (int j = 0; j < jend; ++j) {
             const int t = tid_here();                 // (shadows the kernel's: per-lane offsets are rebuilt per step)
@@ -336,7 +295,7 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
             PANEL_STAMP(0);
             const int jcols = (int)((p.c1 - col0) < PB ? (p.c1 - col0) : PB);   // < 64 only in the matrix's last block
             d4 T[4];
-            load_strip<PRE>(T, A, lda, n, row0, col0, jcols);
+            load_strip(T, A, lda, n, row0, col0, jcols);
             // ---- T -= sum_k X[R,k] X[j,k]^T, chunks of 64, the other operand double-buffered through LDS
             if (j > 0) {
                 if (!wait_prog(o_prog, p.base + 1, have, &s_seen, p.info, false, cb0 + Rr, cb0 + j)) return;
@@ -348,7 +307,7 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
 #else
 #define CP_MARK_NOWAIT(slot) do { } while (0)
 #endif
-                if (PROG && full_blocks) {
+                if (full_blocks) {
                     // Chunk operands in LDS, filled by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction, lane l
                     // lands at base + 16 l bytes; no VGPR destination, no ds_write pass, half the vector-memory instructions
                     // of 8-byte loads), issued from INSIDE the hand-scheduled MFMA blocks of the chunk before (chunk_asm.h):
@@ -432,7 +391,7 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
             }
             // ---- X = T L_jj^{-T}
             PANEL_STAMP(1);
-            if (PROG && Rr == j + 1 && jcols == PB && row0 + PB <= n) {
+            if (Rr == j + 1 && jcols == PB && row0 + PB <= n) {
                 // The pivot chain: this row block is the next diagonal owner.  L_jj arrives one 16-column block at
                 // a time (potf2_64_lds raises qprog[j] behind block columns 0, 1, 2 and the row block's counter
                 // behind the last; the inverse W_b of each 16 x 16 diagonal block comes with its column) and each
@@ -527,28 +486,22 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
                     const bool ok = r >= c && r <= last && c < jcols;
                     v[q] = ok ? v[q] : ((r == c) ? 1.0 : 0.0);
                 }
-                if (PROG) {
-                    // the diagonal 16 x 16 blocks arrive as their inverses, built once by L_jj's owner (potf2_64_lds)
-                    // instead of by every row block of the panel for itself
-                    const double* o_w = p.winv + (int64_t)(cb0 + j) * 1024;
-                    double wq[4];
+                // the diagonal 16 x 16 blocks arrive as their inverses, built once by L_jj's owner (potf2_64_lds)
+                // instead of by every row block of the panel for itself
+                const double* o_w = p.winv + (int64_t)(cb0 + j) * 1024;
+                double wq[4];
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) wq[b] = ldg_sc1(o_w + 256 * b, (uint32_t)(t * 8));
-                    __syncthreads();                  // every wave is done with sM (previous diagonal update)
+                for (int b = 0; b < 4; ++b) wq[b] = ldg_sc1(o_w + 256 * b, (uint32_t)(t * 8));
+                __syncthreads();                  // every wave is done with sM (previous diagonal update)
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const int c = cq + 4 * q;
-                        if ((r >> 4) != (c >> 4)) sM[c * S64_LS + r] = v[q];
-                    }
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) sM[(16 * b + (t >> 4)) * S64_LS + 16 * b + (t & 15)] = wq[b];
-                } else {
-                    __syncthreads();                  // every wave is done with sM (previous diagonal update)
-                    store_block_lds(v, sM);
+                for (int q = 0; q < 16; ++q) {
+                    const int c = cq + 4 * q;
+                    if ((r >> 4) != (c >> 4)) sM[c * S64_LS + r] = v[q];
                 }
+#pragma unroll
+                for (int b = 0; b < 4; ++b) sM[(16 * b + (t >> 4)) * S64_LS + 16 * b + (t & 15)] = wq[b];
             }
             __syncthreads();
-            if (!PROG) invert_diag16(sM);
             PANEL_STAMP(4);
             solve64_lower_inv(T, sM);
             PANEL_STAMP(5);
@@ -562,14 +515,10 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
                     for (int r = 0; r < 4; ++r) sM[(16 * J + 4 * g + r) * S64_LS + 16 * wave + i] = T[J][r];
                 __syncthreads();
                 PANEL_STAMP(6);
-                if (PROG) {
-                    d4 Dd[4];
-                    strip_from_lds(Dd, sDD);
-                    strip64_update(Dd, T, sM);
-                    strip_to_lds(Dd, sDD);
-                } else {
-                    strip64_update(D, T, sM);
-                }
+                d4 Dd[4];
+                strip_from_lds(Dd, sDD);
+                strip64_update(Dd, T, sM);
+                strip_to_lds(Dd, sDD);
                 // X[R,j] is published only now: its global stores drained behind the MFMAs, so the release
                 // fence is cheaper, and the barrier inside publish() also frees sM for its next use.  The
                 // last one (j == Rr - 1) sits on the pivot chain: potf2_64_lds publishes it one barrier in.
@@ -585,30 +534,14 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
             // potf2_64_lds factors them there, storing L to global on the way
             const int tstep = 39;
             PANEL_STAMP(0);
-            double* sM = PROG ? sDD : sT0;            // both buffers are free (barrier at the end of the last step)
-            if (!PROG) {
-#pragma unroll
-                for (int J = 0; J < 4; ++J)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int c = 16 * J + 4 * g + r, rr = 16 * wave + i;
-                        double v = D[J][r];
-                        if (rr >= dcols || c >= dcols) v = (rr == c) ? 1.0 : 0.0;
-                        sM[c * S64_LS + rr] = v;
-                    }
-            }
-            if (PROG && t < 64) sXT[t * POTF2_XS + 16] = 0.0;               // potf2's hand-shake slots (potf2.h)
+            double* sM = sDD;                         // D lives in LDS between the steps; potf2 factors it in place
+            if (t < 64) sXT[t * POTF2_XS + 16] = 0.0;                       // potf2's hand-shake slots (potf2.h)
             __syncthreads();
             PANEL_STAMP(2);
-            if (PROG)
-                potf2_64_lds<S64_LS, true>(sM, sXT, A + row0 + row0 * lda, lda, dcols, (int)row0, p.info,
-                                           Rr > 0 ? my_prog : nullptr, p.base + (unsigned long long)Rr,
-                                           p.trace ? p.trace + ((int64_t)Rr * 40 + 30) * 8 : nullptr,
-                                           p.qprog + cb0 + Rr, p.base, p.winv + (int64_t)(cb0 + Rr) * 1024, sT1);
-            else
-                potf2_64_lds<S64_LS, false>(sM, sXT, A + row0 + row0 * lda, lda, dcols, (int)row0, p.info,
-                                            Rr > 0 ? my_prog : nullptr, p.base + (unsigned long long)Rr,
-                                            p.trace ? p.trace + ((int64_t)Rr * 40 + 30) * 8 : nullptr);
+            potf2_64_lds<S64_LS, true>(sM, sXT, A + row0 + row0 * lda, lda, dcols, (int)row0, p.info,
+                                       Rr > 0 ? my_prog : nullptr, p.base + (unsigned long long)Rr,
+                                       p.trace ? p.trace + ((int64_t)Rr * 40 + 30) * 8 : nullptr,
+                                       p.qprog + cb0 + Rr, p.base, p.winv + (int64_t)(cb0 + Rr) * 1024, sT1);
             PANEL_STAMP(3);
             publish(my_prog, p.base + (unsigned long long)(Rr + 1));
             PANEL_STAMP(1);
@@ -618,172 +551,9 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
 }
 
 
-// raises a flag PRE launches wait for: enqueued behind the kernel that produces their input, on that kernel's stream
-__global__ void flag_store_kernel(unsigned long long* flag, unsigned long long value)
-{
-    if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// queue probe (potrf.hip, win_setup): spins until *flag >= value or ~20 ms have passed; result[0] = 1 when it saw the flag
-__global__ void flag_wait_probe_kernel(const unsigned long long* flag, unsigned long long value, int* result)
-{
-    if (threadIdx.x != 0) return;
-    const long long t0 = wall_clock64();
-    unsigned long long v = ld_prog(flag);
-    while (v < value && wall_clock64() - t0 < 2000000ll) { __builtin_amdgcn_s_sleep(32); v = ld_prog(flag); }   // 100 MHz clock
-    result[0] = (v >= value) ? 1 : 0;
-}
-
-// ---- the rows BELOW a sub-panel's diagonal blocks, off the pivot chain --------------------------------------------
-// panel_rows_kernel: X[R, j] = (A[R, j] - sum_{k<j} X[R, k] X[j, k]^T) L_jj^-T for row blocks R that own no diagonal
-// block, consuming what the chain launch (panel_ll_kernel on the diagonal owners) publishes: X[j, k], L_jj and the
-// inverses W_b of its 16 x 16 diagonal blocks, through the same epoch-tagged counters.  It may run beside the chain
-// launch (in step with it) or after it (every wait then falls through).  Built to SHARE compute units with the
-// trailing updates instead of waiting for whole ones: 32 rows per work-group, no potf2 / inversion / diagonal block,
-// 68 KB of LDS and 164 registers per lane (amdgpu_waves_per_eu(3, 3): no spills), so a work-group fits the slot ONE finished 64-tile update work-group
-// leaves (158 registers, 40 KB; three of those per CU).  Two waves share a 16-row strip, 32 columns each, so a chunk is
-// 32 MFMAs per wave instead of 64 and a row block's 36 sequential chunks + 8 solves take about half as long.
-// Arithmetic per accumulator is that of panel_ll_kernel (same terms, same order): L does not depend on which kernel
-// swept a row block.
-struct RowsArgs {
-    double* A; int64_t lda; int64_t n;     // n: rows of the matrix (incl. the rows of a bordered factorisation)
-    int64_t K0, c1;                        // the sub-panel's columns [K0, c1), whole 64-column blocks
-    int64_t r0, r1;                        // rows [r0, r1) of this launch, r0 >= c1 and a multiple of 64
-    const unsigned long long* prog;        // counters of the chain launch (absolute 64-row block index)
-    const double* winv;                    // its W_b (absolute column block)
-    unsigned long long base;               // its epoch
-    int* info;
-    int ncb;
-};
-
-constexpr int RB = 32;                     // rows per work-group
-
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void panel_rows_kernel(RowsArgs p)
-{
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* sT0 = smem;
-    double* sT1 = smem + PB * S64_LS;
-    __shared__ unsigned long long s_seen;
-    __builtin_amdgcn_s_setprio(2);         // above the update waves it shares SIMDs with, below the pivot chain
-    double* A = p.A;
-    const int64_t lda = p.lda, n = p.n;
-    const int cb0 = (int)(p.K0 / PB);
-    // (the grid is capped below the CU count, launch_panel_rows: a work-group takes every gridDim.x-th 32-row block)
-    for (int64_t row0 = p.r0 + (int64_t)blockIdx.x * RB; row0 < p.r1; row0 += (int64_t)gridDim.x * RB) {
-    const int t = tid_here();
-    const int lane = t & 63, wave = t >> 6;
-    const int i = lane & 15, g = lane >> 4;
-    const int rs = wave & 1, ch = wave >> 1;            // row strip (16 rows), column half (32 columns)
-    const int rr = 16 * rs + i;
-    const int last = (int)(p.r1 - 1 - row0);            // rows past the launch's end are clamped and never stored
-    const bool live = rr <= last;
-    const int rc = live ? rr : last;
-    const uint32_t voffX = (uint32_t)((rc + (int64_t)(4 * g) * lda) * 8);
-    const int pi = 4 * (i & 3) + (i >> 2);
-    for (int j = 0; j < p.ncb; ++j) {
-        const int64_t col0 = p.K0 + (int64_t)j * PB;
-        const int64_t orow0 = col0;
-        const unsigned long long* o_prog = p.prog + cb0 + j;
-        unsigned long long have = 0;
-        double* sM = (j & 1) ? sT1 : sT0;               // free: the last chunk (k = j - 1) reads the other buffer
-        double* sO = (j & 1) ? sT0 : sT1;
-        // own tiles of T = A[R, j]: column blocks J = 2 ch, 2 ch + 1
-        d4 T[2];
-#pragma unroll
-        for (int Jl = 0; Jl < 2; ++Jl)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) T[Jl][r] = ldg_off(A + row0 + (col0 + 16 * (2 * ch + Jl) + r) * lda, voffX);
-        if (j > 0) {
-            double breg[16];
-            d4 XI[4];
-            if (!wait_prog(o_prog, p.base + 1, have, &s_seen, p.info, false, (int)(row0 / PB), cb0 + j)) return;
-            load_block_regs(breg, A, lda, n, orow0, p.K0);
-#pragma unroll
-            for (int I = 0; I < 4; ++I)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) XI[I][r] = ldg_off(A + row0 + (p.K0 + 16 * I + r) * lda, voffX);
-            for (int k = 0; k < j; ++k) {
-                double* sT = (k & 1) ? sT1 : sT0;
-                store_block_lds(breg, sT);
-                d4 XC[4];
-#pragma unroll
-                for (int I = 0; I < 4; ++I) XC[I] = XI[I];
-                const bool more = (k + 1 < j);
-                if (more && !wait_prog(o_prog, p.base + (unsigned long long)(k + 2), have, &s_seen, p.info, false,
-                                       (int)(row0 / PB), cb0 + j)) return;
-                __syncthreads();
-                // the next chunk's loads first (they fly behind the MFMAs; repeated for the last chunk rather than
-                // branched around), then the chunk: per accumulator the terms come in panel_ll_kernel's order
-                const int64_t kc = p.K0 + (int64_t)(more ? k + 1 : k) * PB;
-                const double* gB = A + orow0 + kc * lda;
-                const double* gX = A + row0 + kc * lda;
-                const uint32_t voffB = (uint32_t)(((t & 63) + (int64_t)(t >> 6) * lda) * 8);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int I = q >> 2, s2 = q & 3;
-                    double a[2];
-#pragma unroll
-                    for (int Jl = 0; Jl < 2; ++Jl) a[Jl] = -sT[(16 * I + 4 * g + s2) * S64_LS + 16 * (2 * ch + Jl) + pi];
-#pragma unroll
-                    for (int Jl = 0; Jl < 2; ++Jl) T[Jl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[Jl], XC[I][s2], T[Jl], 0, 0, 0);
-                    breg[q] = ldg_sc1(gB + (int64_t)(4 * q) * lda, voffB);
-                    XI[I][s2] = ldg_off(gX + (int64_t)(16 * I + s2) * lda, voffX);
-                }
-            }
-        }
-        // ---- X = T L_jj^-T: L_jj's off-diagonal 16-blocks and the owner-built inverses of its diagonal ones
-        if (!wait_prog(o_prog, p.base + (unsigned long long)(j + 1), have, &s_seen, p.info, false, (int)(row0 / PB), cb0 + j)) return;
-        {
-            double v[16], wq[4];
-            const int r = t & 63, cq = t >> 6;
-            const uint32_t voff = (uint32_t)((r + (int64_t)cq * lda) * 8);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) v[q] = ldg_sc1(A + orow0 + (col0 + 4 * q) * lda, voff);
-            const double* o_w = p.winv + (int64_t)(cb0 + j) * 1024;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) wq[b] = ldg_sc1(o_w + 256 * b, (uint32_t)(t * 8));
-            // (sM was last read two chunks ago, with a barrier since; sO may still be read by a slower wave's last chunk)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int c = cq + 4 * q;
-                if ((r >> 4) != (c >> 4)) sM[c * S64_LS + r] = (r >= c) ? v[q] : 0.0;
-            }
-#pragma unroll
-            for (int b = 0; b < 4; ++b) sM[(16 * b + (t >> 4)) * S64_LS + 16 * b + (t & 15)] = wq[b];
-        }
-        __syncthreads();                                // every wave is past the last chunk: sO is free
-        // the two column halves of a strip meet in LDS: each wave then solves its strip's whole 64 columns (the
-        // substitution runs across them) and stores the half it owns
-#pragma unroll
-        for (int Jl = 0; Jl < 2; ++Jl)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sO[(16 * (2 * ch + Jl) + 4 * g + r) * S64_LS + 16 * rs + i] = T[Jl][r];
-        __syncthreads();
-        d4 Tf[4];
-#pragma unroll
-        for (int J = 0; J < 4; ++J)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Tf[J][r] = sO[(16 * J + 4 * g + r) * S64_LS + 16 * rs + i];
-        solve64_lower_inv(Tf, sM);
-        if (live) {
-            const uint32_t svoff = (uint32_t)((rr + (int64_t)(4 * g) * lda) * 8);
-#pragma unroll
-            for (int Jl = 0; Jl < 2; ++Jl)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) stg_plain(A + row0 + (col0 + 16 * (2 * ch + Jl) + r) * lda, svoff, Tf[2 * ch + Jl][r]);
-        }
-        // the strip's other wave reads these columns back as X[R, j] from the next step on (same CU, same L1 / L2)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    }
-}
-
 }  // namespace
 
 size_t panel_ll_smem_bytes() { return (size_t)(4 * PB * S64_LS + PB * POTF2_XS) * sizeof(double); }
-
-size_t panel_rows_smem_bytes() { return (size_t)(2 * PB * S64_LS) * sizeof(double); }
 
 namespace {
 
@@ -797,8 +567,6 @@ int panel_workspaces(gpirt_handle_t h, hipStream_t stream, int64_t n)
         // does not wait for it).
         GP_HIP(hipStreamSynchronize(stream));
         if (h->side) GP_HIP(hipStreamSynchronize(h->side));
-        if (h->rows_stream) GP_HIP(hipStreamSynchronize(h->rows_stream));
-        if (h->near_stream) GP_HIP(hipStreamSynchronize(h->near_stream));
         if (h->stream != stream) GP_HIP(hipStreamSynchronize(h->stream));
         if (h->d_prog) GP_HIP(hipFree(h->d_prog));
         h->d_prog = nullptr;
@@ -811,8 +579,6 @@ int panel_workspaces(gpirt_handle_t h, hipStream_t stream, int64_t n)
     if (h->winv_blocks < need) {            // W_b: one 4 x 256 slot per 64-column block of the matrix
         GP_HIP(hipStreamSynchronize(stream));
         if (h->side) GP_HIP(hipStreamSynchronize(h->side));
-        if (h->rows_stream) GP_HIP(hipStreamSynchronize(h->rows_stream));
-        if (h->near_stream) GP_HIP(hipStreamSynchronize(h->near_stream));
         if (h->d_winv) GP_HIP(hipFree(h->d_winv));
         h->d_winv = nullptr; h->winv_blocks = 0;
         const int64_t blocks = need < 160 ? 160 : need;
@@ -820,14 +586,8 @@ int panel_workspaces(gpirt_handle_t h, hipStream_t stream, int64_t n)
         h->winv_blocks = blocks;
     }
     if (!h->panel_attr_set) {
-        GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_ll_kernel<true>),
+        GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_ll_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel_ll_smem_bytes()));
-        GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_ll_kernel<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel_ll_smem_bytes()));
-        GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_ll_kernel<true, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel_ll_smem_bytes()));
-        GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_rows_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel_rows_smem_bytes()));
         h->panel_attr_set = true;
     }
     return 0;
@@ -836,10 +596,9 @@ int panel_workspaces(gpirt_handle_t h, hipStream_t stream, int64_t n)
 }  // namespace
 
 // Factor panel columns [K0, c1) with the persistent kernel, sweeping the rows [K0, row_end) (row_end <= 0: all n rows).
-// Opens a new epoch of the progress counters; launch_panel_rows() with the returned epoch takes the rows a restricted
-// launch left out.
+// Opens a new epoch of the progress counters.
 int launch_panel_ll(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t K0, int64_t c1,
-                    int64_t row_end, unsigned long long* epoch_out, const unsigned long long* ready)
+                    int64_t row_end, unsigned long long* epoch_out)
 {
     if (K0 >= c1) return 0;
     GP_TRY(panel_workspaces(h, stream, n));
@@ -847,8 +606,7 @@ int launch_panel_ll(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, 
     PanelArgs p;
     p.A = A; p.lda = lda; p.n = n; p.K0 = K0; p.c1 = c1;
     p.prog = h->d_prog;
-    static const bool progressive = !(getenv("GPIRT_PANEL_COLS") && atoi(getenv("GPIRT_PANEL_COLS")) == 0);
-    p.qprog = progressive ? h->d_prog + h->prog_cap : nullptr;
+    p.qprog = h->d_prog + h->prog_cap;
     p.winv = h->d_winv;
     h->prog_seq += 1;
     p.base = h->prog_seq * 64ull;                    // a panel publishes at most ncb + 1 <= 17 steps
@@ -866,86 +624,8 @@ int launch_panel_ll(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, 
     }
     const int nb = p.rb_end - p.rb_begin;
     const int grid = nb < n_cu ? nb : n_cu;
-    p.ready = ready; p.ready_val = p.base;           // (PRE) the launch starts when *ready reaches its own epoch
-    if (ready && !progressive) { set_error("pre-launched panel kernels need GPIRT_PANEL_COLS != 0"); return GPIRT_E_ARG; }
-    if (ready)            hipLaunchKernelGGL((panel_ll_kernel<true, true>), dim3((unsigned)grid), dim3(256), panel_ll_smem_bytes(), stream, p);
-    else if (progressive) hipLaunchKernelGGL(panel_ll_kernel<true>, dim3((unsigned)grid), dim3(256), panel_ll_smem_bytes(), stream, p);
-    else                  hipLaunchKernelGGL(panel_ll_kernel<false>, dim3((unsigned)grid), dim3(256), panel_ll_smem_bytes(), stream, p);
+    hipLaunchKernelGGL(panel_ll_kernel, dim3((unsigned)grid), dim3(256), panel_ll_smem_bytes(), stream, p);
     GP_HIP(hipGetLastError());
-    return 0;
-}
-
-// The rows [r0, r1) below the diagonal blocks of panel columns [K0, c1), against the chain launch of epoch `epoch`
-// (launch_panel_ll with row_end = r0 or less ... any launch that swept the diagonal owners): beside it or after it.
-// lean = true: panel_rows_kernel (32-row work-groups that share CUs with the updates); false: the persistent kernel's
-// own row-block sweep on whole CUs (cross-check).
-int launch_panel_rows(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t K0, int64_t c1,
-                      int64_t r0, int64_t r1, unsigned long long epoch, bool lean)
-{
-    if (K0 >= c1 || r0 >= r1) return 0;
-    if (r0 < c1 || (r0 % PB) != 0 || ((c1 - K0) % PB) != 0 || r1 > n) { set_error("panel rows launch: bad row / column range"); return GPIRT_E_ARG; }
-    static const bool progressive = !(getenv("GPIRT_PANEL_COLS") && atoi(getenv("GPIRT_PANEL_COLS")) == 0);
-    if (!progressive) { set_error("panel rows launch needs the owner-built inverses (GPIRT_PANEL_COLS != 0)"); return GPIRT_E_ARG; }
-    GP_TRY(panel_workspaces(h, stream, n));
-    if (lean) {
-        RowsArgs q;
-        q.A = A; q.lda = lda; q.n = n; q.K0 = K0; q.c1 = c1; q.r0 = r0; q.r1 = r1;
-        q.prog = h->d_prog; q.winv = h->d_winv; q.base = epoch; q.info = h->d_info;
-        q.ncb = (int)((c1 - K0) / PB);
-        // Work-groups of this launch may spin on the chain launch's counters, and a chain work-group needs a WHOLE compute
-        // unit.  At any time at most one launch of the far rows, one of the near rows (1024 rows = 32 work-groups) and one
-        // chain launch (<= 16 work-groups) are in flight (potrf.hip), and the dispatcher may spread them one per CU: the
-        // far-rows grid stays 64 CUs short of the chip, so the chain launch always finds free CUs once the updates beside it
-        // drain (flagsync.h: nobody may wait for a work-group that cannot be dispatched).  Round 3 found this the hard
-        // way: 224 + 32 lean work-groups on 256 CUs, the chain launch outside, every spin expired (n = 12288).
-        int64_t grid = (r1 - r0 + RB - 1) / RB;
-        const int64_t cap = h->n_cu > 128 ? h->n_cu - 64 : h->n_cu / 2;
-        if (grid > cap) grid = cap;
-        hipLaunchKernelGGL(panel_rows_kernel, dim3((unsigned)grid), dim3(256), panel_rows_smem_bytes(), stream, q);
-    } else {
-        PanelArgs p;
-        p.A = A; p.lda = lda; p.n = r1; p.K0 = K0; p.c1 = c1;
-        p.prog = h->d_prog; p.qprog = h->d_prog + h->prog_cap; p.winv = h->d_winv;
-        p.base = epoch; p.info = h->d_info; p.trace = nullptr;
-        p.nrb = (int)((r1 - K0 + PB - 1) / PB);
-        p.ncb = (int)((c1 - K0) / PB);
-        p.rb_begin = (int)((r0 - K0) / PB);
-        p.rb_end = p.nrb;
-        p.ready = nullptr; p.ready_val = 0;
-        const int nb = p.rb_end - p.rb_begin;
-        const int grid = nb < h->n_cu ? nb : h->n_cu;
-        hipLaunchKernelGGL(panel_ll_kernel<true>, dim3((unsigned)grid), dim3(256), panel_ll_smem_bytes(), stream, p);
-    }
-    GP_HIP(hipGetLastError());
-    return 0;
-}
-
-
-int launch_flag_store(hipStream_t stream, unsigned long long* flag, unsigned long long value)
-{
-    hipLaunchKernelGGL(flag_store_kernel, dim3(1), dim3(64), 0, stream, flag, value);
-    GP_HIP(hipGetLastError());
-    return 0;
-}
-
-// Does a kernel spinning on `spin_stream` let a kernel on `set_stream` run?  (Only if the two streams sit on different
-// hardware queues: the runtime maps streams onto a handful of them, and a packet behind a spinning kernel in the same queue
-// never starts.)  Synchronises both streams.  *ok = 1 if the spinner saw the flag within its 20 ms bound.
-int panel_queue_probe(hipStream_t spin_stream, hipStream_t set_stream, unsigned long long* flag, int* d_result, int* ok)
-{
-    GP_HIP(hipMemsetAsync(flag, 0, sizeof(unsigned long long), spin_stream));
-    GP_HIP(hipMemsetAsync(d_result, 0, sizeof(int), spin_stream));
-    GP_HIP(hipStreamSynchronize(spin_stream));
-    hipLaunchKernelGGL(flag_wait_probe_kernel, dim3(1), dim3(64), 0, spin_stream, flag, 1ull, d_result);
-    hipLaunchKernelGGL(flag_store_kernel, dim3(1), dim3(64), 0, set_stream, flag, 1ull);
-    GP_HIP(hipGetLastError());
-    GP_HIP(hipStreamSynchronize(set_stream));
-    GP_HIP(hipStreamSynchronize(spin_stream));
-    int r = 0;
-    GP_HIP(hipMemcpy(&r, d_result, sizeof(int), hipMemcpyDeviceToHost));
-    GP_HIP(hipMemsetAsync(flag, 0, sizeof(unsigned long long), spin_stream));
-    GP_HIP(hipStreamSynchronize(spin_stream));
-    *ok = r;
     return 0;
 }
 

@@ -253,9 +253,8 @@ int launch_ll_bar(hipStream_t stream, const double* f, const double* y, const do
 int launch_ess(hipStream_t stream, const EssArgs& a)
 {
     if (a.m <= 0) return 0;
-    // GPIRT_LL_EXACT=1 (read per call): log(1 + exp(-a)) through the library in every mode
-    const char* ex = getenv("GPIRT_LL_EXACT");
-    const bool fast = a.U == nullptr && !(ex && atoi(ex) == 1);
+    // a.ll_exact (GPIRT_LL_EXACT=1): log(1 + exp(-a)) through the library in every mode
+    const bool fast = a.U == nullptr && a.ll_exact != 1;
     if (a.U == nullptr && a.n <= 256 * 8) {
         if (fast) hipLaunchKernelGGL((ess_kernel_reg<8, 256, true>), dim3((unsigned)a.m), dim3(256), 0, stream, a);
         else      hipLaunchKernelGGL((ess_kernel_reg<8, 256, false>), dim3((unsigned)a.m), dim3(256), 0, stream, a);

@@ -90,6 +90,9 @@ struct gpirt_sampler_s {
     int iter = 0;                     // completed iterations
     bool initialised = false;
     bool sticky_info = false;         // gpirt_mcmc: potrf info is not cleared between iterations
+    bool factor_fresh = false;        // the L enqueued last has not been read by any stage yet (recover_factor)
+    bool counted = false;             // registered in h->live_samplers (a fully created sampler)
+    bool in_init = false;             // do_factor runs for gpirt_sampler_init (no prefill of Z: init fills it itself)
     bool timing = false;
     hipEvent_t ev[ST_COUNT + 1] = {};
     double stage_ms[ST_COUNT] = {};
@@ -154,20 +157,77 @@ uint64_t stream_window(const gpirt_sampler_s* s)
     return m * (2 * n + 2) + 512 * m + 4096 + 2 * N * m + n + s->beta_total;
 }
 
-// thread-per-row product nu = L z (one right-hand side; R-stream replay path)
-__global__ void trmv_lower_kernel(const double* __restrict__ L, int64_t n, int64_t ldl,
-                                  const double* __restrict__ z, double* __restrict__ out)
+// nu = L z for ONE right-hand side -- the R-stream replay's rmvnorm (src/mvnormal.h:10).  Under R's stream item j's
+// normals start where item j - 1's data-dependent slice loop stopped consuming (src/draw-f.cpp:40-58), so the m products
+// of an iteration are DEPENDENT (no batching, and nothing of item j can start beside item j - 1's loop): what is left is
+// to make one product cost what its bytes cost.  It is memory-bound -- the lower triangle, n^2 / 2 doubles, read once --
+// so the shape is chosen for bytes in flight: 32 rows per work-group (lane = row: 256-byte row segments per column), 8
+// column phases per work-group, and TRMV_SPLIT column ranges of every row block side by side (1024 work-groups at n = 8192,
+// four per CU), their parts added in a fixed order.  Round 3's thread-per-row kernel (one 64-thread work-group per 64
+// rows, each thread walking its whole row) kept 8192 loads in flight on the chip.
+// (The strict upper triangle of L holds zeros -- gpirt_sampler_create -- so the diagonal 32 x 32 block is read whole.)
+constexpr int TRMV_ROWS = 32, TRMV_SPLIT = 4;
+
+__global__ __launch_bounds__(256) void trmv_lower_part_kernel(const double* __restrict__ L, int64_t n, int64_t ldl,
+                                                              const double* __restrict__ z, double* __restrict__ part)
+{
+    __shared__ double sred[8][TRMV_ROWS];
+    const int r = threadIdx.x & 31, ph = threadIdx.x >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * TRMV_ROWS, row = row0 + r;
+    const int64_t kall = (row0 + TRMV_ROWS < n) ? row0 + TRMV_ROWS : n;        // columns that can be non-zero in these rows
+    const int64_t chunk = ((kall + TRMV_SPLIT - 1) / TRMV_SPLIT + 7) / 8 * 8;
+    const int64_t k0 = (int64_t)blockIdx.y * chunk, k1 = (k0 + chunk < kall) ? k0 + chunk : kall;
+    double acc = 0.0;
+    if (row < n) {
+        const double* Lr = L + row;
+        int64_t k = k0 + ph;
+        for (; k + 24 < k1; k += 32) {                    // four loads in flight per lane
+            const double a0 = Lr[k * ldl], a1 = Lr[(k + 8) * ldl], a2 = Lr[(k + 16) * ldl], a3 = Lr[(k + 24) * ldl];
+            acc += a0 * z[k]; acc += a1 * z[k + 8]; acc += a2 * z[k + 16]; acc += a3 * z[k + 24];
+        }
+        for (; k < k1; k += 8) acc += Lr[k * ldl] * z[k];
+    }
+    sred[ph][r] = acc;
+    __syncthreads();
+    if (ph == 0 && row < n) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += sred[q][r];
+        part[(int64_t)blockIdx.y * n + row] = s;
+    }
+}
+
+__global__ void trmv_sum_kernel(const double* __restrict__ part, int64_t n, double* __restrict__ out)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    double acc = 0.0;
-    for (int64_t k = 0; k <= i; ++k) acc += L[i + k * ldl] * z[k];
-    out[i] = acc;
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < TRMV_SPLIT; ++q) s += part[(int64_t)q * n + i];
+    out[i] = s;
+}
+
+int launch_trmv_lower(hipStream_t st, const double* L, int64_t n, int64_t ldl, const double* z, double* part, double* out)
+{
+    hipLaunchKernelGGL(trmv_lower_part_kernel, dim3((unsigned)((n + TRMV_ROWS - 1) / TRMV_ROWS), TRMV_SPLIT), dim3(256), 0, st,
+                       L, n, ldl, z, part);
+    hipLaunchKernelGGL(trmv_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, n, out);
+    GP_HIP(hipGetLastError());
+    return 0;
 }
 
 int fstar_prep(gpirt_sampler_s* s, gpirt_handle_t hh);
 int rebuild_rows(gpirt_sampler_s* s);
 int beta_sync(gpirt_sampler_s* s);
+
+// Z may still be being filled on the sampler's own stream (do_factor's prefill of the NEXT draw_f's normals): whoever reads or
+// rewrites Z, or changes the iteration the prefill was keyed by, joins it first and drops it
+int z_sync(gpirt_sampler_s* s)
+{
+    if (s->z_filled_iter != 0 && s->ev_zfill) GP_HIP(hipStreamWaitEvent(s->h->stream, s->ev_zfill, 0));
+    s->z_filled_iter = 0;
+    return 0;
+}
 
 int do_draw_f(gpirt_sampler_s* s)
 {
@@ -176,6 +236,7 @@ int do_draw_f(gpirt_sampler_s* s)
     const int64_t n = s->n, m = s->m;
     const uint32_t iter = (uint32_t)(s->iter + 1);
     GP_TRY(beta_sync(s));                     // mu of the previous iteration's draw_beta
+    s->factor_fresh = false;
     if (!stream_mode(s)) {
         const bool prep = s->haux && s->ext > 0 && !s->ext_grid && s->rows_valid && !s->prep_valid;
         // The side work (what the low-rank draw_fstar needs from L alone: the last range of block inverses and the
@@ -185,21 +246,22 @@ int do_draw_f(gpirt_sampler_s* s)
         // with a 224-register work-group of the product and sat out its whole 1.09 ms -- the side handle now launches
         // the 256-register form of that leaf (trsm.hip, slim_leaf) and the chain is done before the slice kernel is:
         // draw_fstar no longer waits 0.33 ms for it (7.12 -> 6.88 ms per iteration; the product slows by 0.1 ms).
-        // GPIRT_PREP_EARLY=2 (read per call) puts it back behind the product.
-        const char* pe = getenv("GPIRT_PREP_EARLY");
-        const bool early = prep && !(pe && atoi(pe) == 2 && m > 128);
+        // GPIRT_PREP_EARLY=2 puts it back behind the product.
+        const bool early = prep && !(h->cfg.prep_early == 2 && m > 128);
         if (early) GP_HIP(hipEventRecord(s->ev_trmm, st));
         if (s->z_filled_iter == iter && s->ev_zfill) {
             GP_HIP(hipStreamWaitEvent(st, s->ev_zfill, 0));       // filled behind the previous factorisation (do_factor)
+            s->z_filled_iter = 0;
         } else {
+            GP_TRY(z_sync(s));                                    // a prefill for ANOTHER iteration may still be writing Z
             GP_TRY(launch_item_uniforms(st, s->opt.seed, iter, GPIRT_ST_F_Z, (uint32_t)s->opt.item0, m, n, s->Z, true));
         }
-        s->z_filled_iter = 0;
         GP_TRY(launch_gemm(h, st, false, false, TRI_A_LOWER, n, m, n, 1.0, s->L, s->ldl, s->Z, n, 0.0, s->NU, n));
         if (prep && !early) GP_HIP(hipEventRecord(s->ev_trmm, st));
         EssArgs a{};
         a.f = s->f; a.nu = s->NU; a.y = s->y; a.mu = s->mu; a.n = n; a.m = m; a.k_out = s->ess_k;
         a.err = s->flags; a.seed = s->opt.seed; a.iter = iter; a.item0 = (uint32_t)s->opt.item0;
+        a.ll_exact = h->cfg.ll_exact;
         GP_TRY(launch_ess(st, a));
         if (prep) {
             // what the low-rank draw_fstar needs from L alone, on the sampler's own stream (see `early` above)
@@ -217,7 +279,7 @@ int do_draw_f(gpirt_sampler_s* s)
     // exact R order: item j draws its n normals, then u, eps0 and one uniform per rejection
     for (int64_t j = 0; j < m; ++j) {
         GP_TRY(launch_rstream_normals(st, s->U, s->pos, 0, n, 1, s->Z));
-        hipLaunchKernelGGL(trmv_lower_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, s->L, n, s->ldl, s->Z, s->NU);
+        GP_TRY(launch_trmv_lower(st, s->L, n, s->ldl, s->Z, s->NU + n, s->NU));        // (the parts go behind NU's first column)
         EssArgs a{};
         a.f = s->f + j * n; a.nu = s->NU; a.y = s->y + j * n; a.mu = s->mu + j * n; a.n = n; a.m = 1;
         a.k_out = s->ess_k + j; a.err = s->flags; a.item0 = (uint32_t)j;
@@ -263,6 +325,7 @@ int do_draw_fstar(gpirt_sampler_s* s, uint32_t iter)
     double* W = s->rhs + (size_t)n * N;      // n x m : L^-1 f, then L^-T L^-1 f
     const bool fused = s->opt.fstar_fused != 0;
     GP_TRY(beta_sync(s));                     // mu_star
+    s->factor_fresh = false;
     GP_TRY(rebuild_rows(s));
     if (s->kr > 0) {
         // K*^T = U V^T exactly (see gpirt_sampler_create), so with B = L^-1 U and C = L^-T B = S^-1 U:
@@ -401,8 +464,7 @@ int beta_sync(gpirt_sampler_s* s)
 
 int do_draw_beta(gpirt_sampler_s* s)
 {
-    const char* ei = getenv("GPIRT_EARLY_INV");
-    const bool defer = !(ei && atoi(ei) == 2) && !stream_mode(s) && s->haux && s->ev_beta && s->initialised;
+    const bool defer = s->h->cfg.early_inv != 2 && !stream_mode(s) && s->haux && s->ev_beta && s->initialised;
     GP_TRY(beta_sync(s));
     if (defer) { s->beta_deferred = true; return 0; }     // do_factor launches it behind the factorisation's last outer panel
     return launch_beta_on(s, s->h->stream);
@@ -417,12 +479,14 @@ void invalidate_factor_products(gpirt_sampler_s* s)
     if (s->haux && s->haux->trsm_winv_L == s->L) s->haux->trsm_winv_L = nullptr;
 }
 
-// the main stream waits for whatever the sampler's own stream still has in flight
-int aux_join(gpirt_sampler_s* s, bool beta_too = true)
+// the main stream waits for whatever the sampler's own stream still has in flight.  z_too: also a prefill of the next
+// draw_f's normals, which is then dropped (every caller but do_factor, whose own prefill it would be)
+int aux_join(gpirt_sampler_s* s, bool beta_too = true, bool z_too = true)
 {
     hipStream_t st = s->h->stream;
     if (s->prep_pending) { GP_HIP(hipStreamWaitEvent(st, s->ev_prep, 0)); s->prep_pending = false; }
     if (beta_too) GP_TRY(beta_sync(s));
+    if (z_too) GP_TRY(z_sync(s));
     return 0;
 }
 
@@ -453,7 +517,7 @@ int rebuild_rows(gpirt_sampler_s* s)
 int do_factor(gpirt_sampler_s* s)
 {
     hipStream_t st = s->h->stream;
-    GP_TRY(aux_join(s, false));           // nothing of the old factor may still be read when it is overwritten (a held-back
+    GP_TRY(aux_join(s, false, true));     // nothing of the old factor may still be read when it is overwritten (a held-back
                                           // draw_beta does not read it: it is launched below, behind the factorisation)
     invalidate_factor_products(s);
     GP_TRY(build_cov(s));                                                                                  // :76-77
@@ -463,8 +527,7 @@ int do_factor(gpirt_sampler_s* s)
     // ~5 GFLOP to build at n = 8192, and they only need the DIAGONAL blocks, final panel by panel.  Those of every outer
     // panel but the last are built on the sampler's own stream while the last outer panel is factored (16 + 8 whole-CU
     // work-groups and small updates: most of the chip is idle then); only the last block and the solve are left behind.
-    const char* ei = getenv("GPIRT_EARLY_INV");        // (read per call: tests switch it inside one process)
-    const bool early_inv = !(ei && atoi(ei) == 2);
+    const bool early_inv = s->h->cfg.early_inv != 2;
     if (early_inv && s->haux && s->kr > 0 && s->ext > 0 && !s->ext_grid && !stream_mode(s) && s->h->prelast_cols >= 2048) {
         const int64_t p1 = (s->h->prelast_cols / 512) & ~(int64_t)1;
         hipStream_t ax = s->haux->stream;
@@ -474,8 +537,8 @@ int do_factor(gpirt_sampler_s* s)
         GP_TRY(trsm_inverses_build(s->haux, ax, s->L, s->n, s->ldl, true, 0, p1));
         s->haux->inv_partial_L = s->L; s->haux->inv_partial_pairs = p1;
     }
-    if (early_inv && s->initialised && s->haux && s->ev_zfill && !stream_mode(s) && s->h->prelast_cols >= 2048) {
-        // (not from gpirt_sampler_init: it fills Z itself for the initial f right behind its factorisation)
+    if (early_inv && s->initialised && !s->in_init && s->haux && s->ev_zfill && !stream_mode(s) && s->h->prelast_cols >= 2048) {
+        // (not from gpirt_sampler_init, first or repeated: it fills Z itself for the initial f right behind its factorisation)
         // ... and the next draw_f's N(0,1) draws (the factorisation closes iteration s->iter + 1; the next draw_f is
         // iteration s->iter + 2).  Z was last read by this iteration's nu = L z, long finished on the main stream.
         hipStream_t ax = s->haux->stream;
@@ -499,6 +562,41 @@ int do_factor(gpirt_sampler_s* s)
             GP_TRY(launch_beta_on(s, st));
         }
     }
+    s->factor_fresh = true;               // nothing has read this L yet: a hang-guard expiry in it can still be repaired in place
+    return 0;
+}
+
+// The factorisation enqueued last ended in a hang-guard expiry (info[1]) and nothing has consumed its L yet (factor_fresh):
+// theta is intact, so K is rebuilt from it and factored once more with the launch-per-step panel -- the schedule differs,
+// the products do not, and the chain goes on as if nothing had happened (L within rounding of the undisturbed factor).
+// Whatever was launched behind the bad factor on the sampler's own stream and depends on it (early block inverses) is
+// dropped; the Z prefill and a held-back draw_beta do not depend on L and stay.
+int recover_factor(gpirt_sampler_s* s)
+{
+    gpirt_handle_t h = s->h;
+    hipStream_t st = h->stream;
+    if (s->haux) GP_HIP(hipStreamSynchronize(s->haux->stream));
+    GP_TRY(potrf_guard_reset(h, st));
+    s->prep_pending = false;
+    invalidate_factor_products(s);
+    const int saved = h->cfg.panel;
+    h->cfg.panel = 2;
+    int rc = build_cov(s);
+    if (!rc) rc = launch_potrf_lower(h, st, s->L, s->n, s->ldl, false, true, s->ext);
+    h->cfg.panel = saved;
+    GP_TRY(rc);
+    s->rows_valid = true;
+    s->factor_fresh = true;
+    return 0;
+}
+
+// drains the stream and repairs a hang-guard expiry of the factorisation enqueued last (callers that drain it anyway)
+int factor_guard_sync(gpirt_sampler_s* s)
+{
+    gpirt_handle_t h = s->h;
+    GP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 8 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    GP_HIP(hipStreamSynchronize(h->stream));
+    if (h->h_info[1] != 0 && s->factor_fresh && h->cfg.panel != 2) GP_TRY(recover_factor(s));
     return 0;
 }
 
@@ -544,16 +642,16 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
     int rc = 0;
 #define GP_A(p, cnt) do { rc = dalloc(s, &(p), (size_t)(cnt)); if (rc) { gpirt_sampler_destroy(s); return rc; } } while (0)
     GP_A(s->y, n * m);       GP_A(s->Ypm, n * 2 * m);  GP_A(s->theta, n);       GP_A(s->theta_new, n);
-    GP_A(s->f, n * m);       GP_A(s->Z, n * m);        GP_A(s->NU, n * m);      GP_A(s->beta, 2 * m);
+    GP_A(s->f, n * m);       GP_A(s->Z, n * m);        GP_A(s->NU, n * (m > 1 + TRMV_SPLIT ? m : 1 + TRMV_SPLIT));   GP_A(s->beta, 2 * m);   // (NU: >= 1 + TRMV_SPLIT columns, launch_trmv_lower's parts)
     s->kr = s->opt.reserved[2];
     if (s->kr != 0 && (!s->opt.fstar_fused || s->kr < 16 || s->kr > 128 || (s->kr % 16) != 0)) {
         set_error("kstar_rank must be a multiple of 16 in 16..128 and needs fstar_fused");
         gpirt_sampler_destroy(s);
         return GPIRT_E_ARG;
     }
-    const bool bordered_ok = (n % 64) == 0 && !(getenv("GPIRT_BORDERED") && atoi(getenv("GPIRT_BORDERED")) == 2);
+    const bool bordered_ok = (n % 64) == 0 && h->cfg.bordered != 2;
     s->ext = (s->kr > 0 && bordered_ok) ? s->kr : 0;
-    if (s->kr == 0 && bordered_ok && n >= 1024 && !(getenv("GPIRT_BORDERED_GRID") && atoi(getenv("GPIRT_BORDERED_GRID")) == 2)) {
+    if (s->kr == 0 && bordered_ok && n >= 1024) {
         s->ext = (N + 63) / 64 * 64;          // 1001 grid rows + 23 rows that stay zero
         s->ext_grid = true;
     }
@@ -659,11 +757,10 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
     if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) {
         set_error("sampler upload failed"); gpirt_sampler_destroy(s); return GPIRT_E_HIP;
     }
-    if (!stream_mode(s) && !(getenv("GPIRT_AUX") && atoi(getenv("GPIRT_AUX")) == 2)) {
-        if (!h->aux && (getenv("GPIRT_AUX_PRIO") && atoi(getenv("GPIRT_AUX_PRIO")) == 2 ? gpirt_create_own_stream(&h->aux, h->device)
-                                                                                         : create_side_handle(&h->aux, h->device)) != 0) {
-            gpirt_sampler_destroy(s);
-            return GPIRT_E_HIP;
+    if (!stream_mode(s)) {
+        if (!h->aux) {
+            if (create_side_handle(&h->aux, h->device) != 0) { gpirt_sampler_destroy(s); return GPIRT_E_HIP; }
+            h->aux->cfg = h->cfg;
         }
         s->haux = h->aux;
         if (
@@ -678,6 +775,8 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
     // keep pm/ps on the host for the R-stream init of beta
     s->host_tmp.assign(h_pm, h_pm + 2 * m);
     s->host_tmp.insert(s->host_tmp.end(), h_ps, h_ps + 2 * m);
+    h->live_samplers += 1;
+    s->counted = true;
     *out = s;
     return 0;
 }
@@ -701,7 +800,13 @@ int gpirt_sampler_destroy(gpirt_sampler_t s)
     if (s->h_pos) hipHostFree(s->h_pos);
     if (s->h_flags) hipHostFree(s->h_flags);
     for (int i = 0; i <= ST_COUNT; ++i) if (s->ev[i]) hipEventDestroy(s->ev[i]);
+    gpirt_handle_t h = s->h;
+    const bool counted = s->counted;
     delete s;
+    if (h && counted) {
+        h->live_samplers -= 1;
+        if (h->zombie && h->live_samplers == 0) { h->zombie = false; gpirt_destroy(h); }    // the handle outlived by its samplers
+    }
     return 0;
 }
 
@@ -712,7 +817,12 @@ int gpirt_sampler_init(gpirt_sampler_t s)
     gpirt_handle_t h = s->h;
     hipStream_t st = h->stream;
     const int64_t n = s->n, m = s->m, N = s->N;
-    GP_TRY(do_factor(s));                                                         // :15-17
+    GP_TRY(aux_join(s));                  // (a repeated init: nothing of the previous chain may still be in flight)
+    s->in_init = true;
+    const int rc_f = do_factor(s);                                                // :15-17
+    s->in_init = false;
+    GP_TRY(rc_f);
+    GP_TRY(factor_guard_sync(s));         // (init drains the stream below anyway)
     if (!stream_mode(s)) {
         GP_TRY(launch_item_uniforms(st, s->opt.seed, 0, GPIRT_ST_INIT_F, (uint32_t)s->opt.item0, m, n, s->Z, true));
         GP_TRY(launch_gemm(h, st, false, false, TRI_A_LOWER, n, m, n, 1.0, s->L, s->ldl, s->Z, n, 0.0, s->f, n)); // :18-21
@@ -863,6 +973,7 @@ int gpirt_sampler_adopt_factor(gpirt_sampler_t s, int rows_with_L)
     GP_ARG(s && s->initialised);
     GP_TRY(beta_sync(s));                // a held-back draw_beta belongs to the iteration that closes here
     invalidate_factor_products(s);
+    s->factor_fresh = false;             // (nothing here could rebuild a factor that arrived from elsewhere)
     s->rows_valid = rows_with_L != 0;
     s->iter += 1;
     return 0;
@@ -925,7 +1036,15 @@ int gpirt_sampler_check(gpirt_sampler_t s)
     GP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
     GP_HIP(hipMemcpyAsync(s->h_flags, s->flags, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     GP_HIP(hipStreamSynchronize(st));
-    if (h->h_info[1] != 0) return report_panel_guard(h, h->h_info, st);
+    if (h->h_info[1] != 0) {
+        // hang-guard expiry.  Repairable in place while nothing has read the bad L (the usual case: check() right behind a
+        // step) and the launch-per-step panel was not what failed; otherwise the chain has already consumed garbage.
+        if (!s->factor_fresh || h->cfg.panel == 2) return report_panel_guard(h, h->h_info, st);
+        GP_TRY(recover_factor(s));
+        GP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+        GP_HIP(hipStreamSynchronize(st));
+        if (h->h_info[1] != 0) return report_panel_guard(h, h->h_info, st);
+    }
     if (*h->h_info > 0) {
         set_error("chol(): decomposition failed (leading minor of order %d is not positive definite)", *h->h_info);
         return *h->h_info;
@@ -1009,10 +1128,10 @@ int gpirt_sampler_panel_update_part(gpirt_sampler_t s, int64_t p, int64_t c, int
     return potrf_panel_update(s->h, s->h->stream, s->L, s->n, s->ldl, p, c, s->ext, part);
 }
 
-int gpirt_sampler_panel_copy_part(gpirt_sampler_t s, int64_t p, int half, double* d_buf, int to_buf)
+int gpirt_sampler_panel_copy_part(gpirt_sampler_t s, int64_t p, int half, double* d_buf, int64_t buf_doubles, int to_buf)
 {
-    GP_ARG(s && s->initialised && d_buf);
-    return potrf_panel_copy(s->h->stream, s->L, s->n, s->ldl, p, d_buf, to_buf != 0, s->ext, half);
+    GP_ARG(s && s->initialised && d_buf && buf_doubles >= 0);
+    return potrf_panel_copy(s->h->stream, s->L, s->n, s->ldl, p, d_buf, to_buf != 0, s->ext, half, buf_doubles);
 }
 
 // dst's chain state := src's (theta, f, beta, mu, mu_star, fstar, the n x n factor, the iteration counter): lets a second
@@ -1023,6 +1142,7 @@ int gpirt_sampler_copy_state(gpirt_sampler_t dst, gpirt_sampler_t src)
     hipStream_t st = dst->h->stream;
     const int64_t n = dst->n, m = dst->m, N = dst->N;
     GP_TRY(aux_join(dst)); GP_TRY(aux_join(src));
+    src->factor_fresh = false;
     invalidate_factor_products(dst);
     GP_HIP(hipMemcpyAsync(dst->theta, src->theta, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
     GP_HIP(hipMemcpyAsync(dst->f, src->f, sizeof(double) * (size_t)(n * m), hipMemcpyDeviceToDevice, st));
@@ -1110,6 +1230,10 @@ int gpirt_sampler_stage_times(gpirt_sampler_t s, double* ms_out, int max_stages,
 }
 
 // Whole-call drop-in: src/gpirtMCMC.cpp:5-117 behind src/RcppExports.cpp:16-30.
+long long gpirt_debug_take_mcmc_trip(void);
+static int g_last_mcmc_fallbacks = 0;
+int gpirt_debug_last_mcmc_fallbacks(void) { return g_last_mcmc_fallbacks; }
+
 int gpirt_mcmc(const double* h_y, int64_t n, int64_t m, const double* h_theta0, int S_it, int B_it,
                const double* h_pm, const double* h_ps, const double* h_step, const gpirt_options* opts,
                gpirt_rstream_t rs, gpirt_tick_fn tick, void* tick_ctx, double* h_theta_draws,
@@ -1121,115 +1245,190 @@ int gpirt_mcmc(const double* h_y, int64_t n, int64_t m, const double* h_theta0, 
     if (opts) o = *opts; else gpirt_default_options(&o);
     gpirt_handle_t h = nullptr;
     GP_TRY(gpirt_create_own_stream(&h, o.device));
+    { const long long trip = gpirt_debug_take_mcmc_trip(); if (trip > 0) h->trip_guard_at = trip; }
     gpirt_sampler_t s = nullptr;
     int rc = gpirt_sampler_create(&s, h, h_y, n, m, h_theta0, h_pm, h_ps, h_step, &o, rs);
     if (rc) { gpirt_destroy(h); return rc; }
-    // Storage of the sampled draws (src/gpirtMCMC.cpp:99-101) is taken off the critical path: after a
-    // sampled iteration theta / beta / f are snapshotted device-to-device on the compute stream, the next
-    // iteration is enqueued, and only then is the snapshot copied to the caller's arrays on a second
-    // stream -- the PCIe transfer (64 MiB per stored iteration at the metric size) overlaps the next
-    // iteration's kernels.  Errors (potrf info, sampler flags) are sticky on the device and polled
-    // without synchronising.
+    const int64_t N = s->N;
+    const int total = S_it + B_it;
+    const bool replay = stream_mode(s);
     std::vector<double> th((size_t)n);
-    double *snap_f = nullptr, *snap_small = nullptr;       // snap_small: [theta (n) | beta (2m)]
-    hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_snap = nullptr, ev_flags = nullptr;
-    int* h_poll = nullptr;                                 // pinned: [potrf info + panel guard record (8) | flag0, flag1]
-    auto cleanup = [&]() {
-        if (snap_f) hipFree(snap_f);
-        if (snap_small) hipFree(snap_small);
-        if (copy_stream) hipStreamDestroy(copy_stream);
-        if (ev_snap) hipEventDestroy(ev_snap);
-        if (ev_flags) hipEventDestroy(ev_flags);
-        if (h_poll) hipHostFree(h_poll);
-    };
-    auto fail_hip = [&](const char* what) { set_error("%s failed in gpirt_mcmc", what); return (int)GPIRT_E_HIP; };
     auto store_sync = [&](int slot) -> int {
-        // theta_draws.row(slot), beta_draws.slice(slot), f_draws.slice(slot): :53-55
+        // theta_draws.row(slot), beta_draws.slice(slot), f_draws.slice(slot): :53-55, :99-101
         GP_TRY(gpirt_sampler_get(s, "theta", th.data(), n));
         for (int64_t i = 0; i < n; ++i) h_theta_draws[slot + i * (int64_t)(S_it + 1)] = th[(size_t)i];
         GP_TRY(gpirt_sampler_get(s, "beta", h_beta_draws + (int64_t)slot * 2 * m, 2 * m));
         GP_TRY(gpirt_sampler_get(s, "f", h_f_draws + (int64_t)slot * n * m, n * m));
         return 0;
     };
-    auto snapshot = [&]() -> int {                          // enqueue on the compute stream
-        hipStream_t st = h->stream;
-        if (beta_sync(s) != 0) return fail_hip("draw_beta join");
-        if (hipMemcpyAsync(snap_f, s->f, sizeof(double) * (size_t)(n * m), hipMemcpyDeviceToDevice, st) != hipSuccess ||
-            hipMemcpyAsync(snap_small, s->theta, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st) != hipSuccess ||
-            hipMemcpyAsync(snap_small + n, s->beta, sizeof(double) * (size_t)(2 * m), hipMemcpyDeviceToDevice, st) != hipSuccess ||
-            hipEventRecord(ev_snap, st) != hipSuccess)
-            return fail_hip("snapshot");
-        return 0;
-    };
-    auto drain = [&](int slot) -> int {                     // blocking for the host, not for the compute stream
-        if (hipStreamWaitEvent(copy_stream, ev_snap, 0) != hipSuccess) return fail_hip("hipStreamWaitEvent");
-        if (hipMemcpyAsync(h_f_draws + (int64_t)slot * n * m, snap_f, sizeof(double) * (size_t)(n * m),
-                           hipMemcpyDeviceToHost, copy_stream) != hipSuccess ||
-            hipMemcpyAsync(th.data(), snap_small, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, copy_stream) != hipSuccess ||
-            hipMemcpyAsync(h_beta_draws + (int64_t)slot * 2 * m, snap_small + n, sizeof(double) * (size_t)(2 * m),
-                           hipMemcpyDeviceToHost, copy_stream) != hipSuccess ||
-            hipStreamSynchronize(copy_stream) != hipSuccess)
-            return fail_hip("draw copy");
-        for (int64_t i = 0; i < n; ++i) h_theta_draws[slot + i * (int64_t)(S_it + 1)] = th[(size_t)i];
-        return 0;
-    };
-    auto post_flags = [&]() -> int {                        // async read-back of the sticky error words
-        hipStream_t st = h->stream;
-        if (hipMemcpyAsync(h_poll, h->d_info, 8 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipMemcpyAsync(h_poll + 8, s->flags, 2 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipEventRecord(ev_flags, st) != hipSuccess)
-            return fail_hip("flag read-back");
-        return 0;
-    };
-    auto inspect_flags = [&]() -> int {
-        if (h_poll[1] != 0) return report_panel_guard(h, h_poll, h->stream);
-        if (h_poll[0] > 0) {
-            set_error("chol(): decomposition failed (leading minor of order %d is not positive definite)", h_poll[0]);
-            return h_poll[0];
-        }
-        if (h_poll[8] != 0) { set_error("sampler state is not finite (flag %d)", h_poll[8]); return h_poll[8]; }
-        if (h_poll[9] != 0) return report_degenerate_theta(s, h_poll[9]);
-        return 0;
-    };
-    const int total = S_it + B_it;
     rc = gpirt_sampler_init(s);
     if (!rc) rc = gpirt_sampler_check(s);
     if (!rc) rc = store_sync(0);
+
+    if (replay) {
+        // R-stream replay is item-sequential and drains the stream every iteration anyway (the cursor comes back to the
+        // host): check, repair a hang-guard expiry in place (gpirt_sampler_check: nothing has read the new L yet) and store,
+        // synchronously.
+        for (int it = 0; it < total && !rc; ++it) {
+            if (tick && tick(tick_ctx, it, total)) { set_error("interrupted"); rc = GPIRT_E_INTERRUPT; break; }
+            rc = gpirt_sampler_step(s);
+            if (!rc) rc = gpirt_sampler_check(s);
+            if (!rc && it >= B_it) {
+                rc = gpirt_sampler_accumulate_irf(s);                          // :103
+                if (!rc) rc = store_sync(it - B_it + 1);
+            }
+        }
+        if (!rc) rc = gpirt_sampler_finish_irfs(s, S_it, h_irfs);
+        g_last_mcmc_fallbacks = h->guard_fallbacks;
+        gpirt_sampler_destroy(s);
+        gpirt_destroy(h);
+        return rc;
+    }
+
+    // Item RNG: the host runs ahead of the device, errors are sticky words polled without draining the stream, and the
+    // stored draws (src/gpirtMCMC.cpp:99-101; 64 MiB per stored iteration at the metric size) travel on a second stream
+    // while the next iterations run.  Both hang off ONE mechanism: after every iteration the chain state is copied
+    // device-to-device into one of three checkpoint slots (theta, beta, f, mu, mu*, f*, the IRF sums: ~1 % of an iteration),
+    // followed by a read-back of the error words.  A checkpoint is VERIFIED once its error words have come back clean;
+    // the host never enqueues iteration it before checkpoint it - 1 is verified (so it is at most two iterations ahead,
+    // and a verified slot is never the one being overwritten).  Stored draws are copied out of verified checkpoints.
+    // If the words come back with the panel kernel's hang guard raised (flagsync.h: its work-groups were not co-resident
+    // within the spin bound -- a foreign tenant on the GPU can do that), the iterations enqueued since the last verified
+    // checkpoint have consumed an unfinished factor: the state is rolled back to that checkpoint, its factor is rebuilt
+    // from theta with the launch-per-step panel, the lost iterations are repeated on that panel too, and the chain goes
+    // on -- the same draws as an undisturbed run (counter-based RNG keyed by the iteration; L equal to rounding).  Only a
+    // second expiry without progress ends the call.
+    constexpr int NS = 3;
+    const size_t ck_doubles = (size_t)n + 2 * (size_t)m + 2 * (size_t)(n * m) + 3 * (size_t)(N * m);
+    double* ck[NS] = { nullptr, nullptr, nullptr };
+    hipEvent_t ev_flags[NS] = {}, ev_copied[NS] = {};
+    bool copy_pending[NS] = { false, false, false };
+    int copy_slot[NS] = { 0, 0, 0 };
+    std::vector<double> th_stage[NS];
+    hipStream_t copy_stream = nullptr;
+    int* h_poll = nullptr;                                 // pinned, per slot: [potrf info + guard record (8) | flag0, flag1]
+    auto fail_hip = [&](const char* what) { set_error("%s failed in gpirt_mcmc", what); return (int)GPIRT_E_HIP; };
     if (!rc) {
-        if (hipMalloc(&snap_f, sizeof(double) * (size_t)(n * m)) != hipSuccess ||
-            hipMalloc(&snap_small, sizeof(double) * (size_t)(n + 2 * m)) != hipSuccess ||
-            hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&ev_snap, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ev_flags, hipEventDisableTiming) != hipSuccess ||
-            hipHostMalloc(&h_poll, 16 * sizeof(int), hipHostMallocDefault) != hipSuccess)
-            rc = fail_hip("allocation");
+        bool ok = hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) == hipSuccess &&
+                  hipHostMalloc(&h_poll, NS * 16 * sizeof(int), hipHostMallocDefault) == hipSuccess;
+        for (int q = 0; q < NS && ok; ++q) {
+            ok = hipMalloc(&ck[q], ck_doubles * sizeof(double)) == hipSuccess &&
+                 hipEventCreateWithFlags(&ev_flags[q], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&ev_copied[q], hipEventDisableTiming) == hipSuccess;
+            th_stage[q].resize((size_t)n);
+        }
+        if (!ok) rc = fail_hip("allocation");
     }
+    struct Part { double* p; size_t cnt; };
+    auto parts = [&]() {
+        return std::vector<Part>{ { s->theta, (size_t)n }, { s->beta, (size_t)(2 * m) }, { s->f, (size_t)(n * m) },
+                                  { s->mu, (size_t)(n * m) }, { s->mu_star, (size_t)(N * m) }, { s->fstar, (size_t)(N * m) },
+                                  { s->irf_sum, (size_t)(N * m) } };
+    };
+    auto save_ckpt = [&](int k) -> int {                    // state after k iterations -> slot k % NS, on the compute stream
+        const int q = k % NS;
+        hipStream_t st = h->stream;
+        if (beta_sync(s) != 0) return fail_hip("draw_beta join");
+        if (copy_pending[q] && hipStreamWaitEvent(st, ev_copied[q], 0) != hipSuccess) return fail_hip("hipStreamWaitEvent");
+        double* d = ck[q];
+        for (const Part& pt : parts()) {
+            if (hipMemcpyAsync(d, pt.p, pt.cnt * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) return fail_hip("checkpoint");
+            d += pt.cnt;
+        }
+        if (hipMemcpyAsync(h_poll + 16 * q, h->d_info, 8 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(h_poll + 16 * q + 8, s->flags, 2 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipEventRecord(ev_flags[q], st) != hipSuccess)
+            return fail_hip("flag read-back");
+        return 0;
+    };
+    auto finish_store = [&](int q) -> int {                 // theta travels through a staging row: scatter it once it is here
+        if (!copy_pending[q]) return 0;
+        if (hipEventSynchronize(ev_copied[q]) != hipSuccess) return fail_hip("draw copy");
+        const int slot = copy_slot[q];
+        for (int64_t i = 0; i < n; ++i) h_theta_draws[slot + i * (int64_t)(S_it + 1)] = th_stage[q][(size_t)i];
+        copy_pending[q] = false;
+        return 0;
+    };
+    auto start_store = [&](int k) -> int {                  // verified checkpoint k -> draw slot k - B_it, on the copy stream
+        const int q = k % NS, slot = k - B_it;
+        GP_TRY(finish_store(q));
+        const double* d = ck[q];
+        if (hipMemcpyAsync(th_stage[q].data(), d, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, copy_stream) != hipSuccess ||
+            hipMemcpyAsync(h_beta_draws + (int64_t)slot * 2 * m, d + n, sizeof(double) * (size_t)(2 * m), hipMemcpyDeviceToHost, copy_stream) != hipSuccess ||
+            hipMemcpyAsync(h_f_draws + (int64_t)slot * n * m, d + n + 2 * m, sizeof(double) * (size_t)(n * m), hipMemcpyDeviceToHost, copy_stream) != hipSuccess ||
+            hipEventRecord(ev_copied[q], copy_stream) != hipSuccess)
+            return fail_hip("draw copy");
+        copy_pending[q] = true; copy_slot[q] = slot;
+        return 0;
+    };
+    auto rollback = [&](int k) -> int {                     // chain state := verified checkpoint k, factor rebuilt on the fallback panel
+        hipStream_t st = h->stream;
+        if (hipStreamSynchronize(st) != hipSuccess) return fail_hip("hipStreamSynchronize");
+        if (h->side) hipStreamSynchronize(h->side);
+        if (s->haux) hipStreamSynchronize(s->haux->stream);
+        s->beta_deferred = false; s->beta_pending = false; s->prep_pending = false; s->z_filled_iter = 0;
+        const double* d = ck[k % NS];
+        for (const Part& pt : parts()) {
+            if (hipMemcpyAsync(pt.p, d, pt.cnt * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) return fail_hip("rollback");
+            d += pt.cnt;
+        }
+        if (hipMemsetAsync(s->flags, 0, 4 * sizeof(int), st) != hipSuccess) return fail_hip("rollback");
+        s->iter = k;
+        return recover_factor(s);
+    };
     s->sticky_info = true;            // potrf no longer clears its info word: first failure sticks
-    int pending = -1;
-    bool flags_posted = false;
-    for (int it = 0; it < total && !rc; ++it) {
-        if (tick && tick(tick_ctx, it, total)) { set_error("interrupted"); rc = GPIRT_E_INTERRUPT; break; }
-        if (flags_posted && hipEventQuery(ev_flags) == hipSuccess) {       // non-blocking poll
-            rc = inspect_flags();
-            if (rc) break;
+    const int panel_mode = h->cfg.panel;
+    int it = 0, verified = 0, fallback_until = 0, last_fallback = -1;
+    if (!rc) rc = save_ckpt(0);
+    if (!rc && hipEventSynchronize(ev_flags[0]) != hipSuccess) rc = fail_hip("hipEventSynchronize");
+    while (!rc && verified < total) {
+        if (it < total && verified >= it - 1) {
+            if (tick && tick(tick_ctx, it, total)) { set_error("interrupted"); rc = GPIRT_E_INTERRUPT; break; }
+            h->cfg.panel = (it < fallback_until) ? 2 : panel_mode;          // iterations lost to a guard expiry are repeated on the fallback panel
+            if (h->aux) h->aux->cfg.panel = h->cfg.panel;
+            rc = gpirt_sampler_step(s);
+            h->cfg.panel = panel_mode;
+            if (h->aux) h->aux->cfg.panel = panel_mode;
+            if (!rc && it >= B_it) rc = gpirt_sampler_accumulate_irf(s);   // :103
+            if (!rc) rc = save_ckpt(it + 1);
+            ++it;
+            continue;
         }
-        rc = gpirt_sampler_step(s);
-        if (!rc) { rc = post_flags(); flags_posted = true; }
-        if (!rc && pending >= 0) { rc = drain(pending); pending = -1; }    // overlaps the step just enqueued
-        if (!rc && it >= B_it) {
-            rc = gpirt_sampler_accumulate_irf(s);                          // :103
-            if (!rc) rc = snapshot();
-            pending = it - B_it + 1;
+        const int k = verified + 1, q = k % NS;
+        if (hipEventSynchronize(ev_flags[q]) != hipSuccess) { rc = fail_hip("hipEventSynchronize"); break; }
+        const int* w = h_poll + 16 * q;
+        if (w[1] != 0) {
+            if (panel_mode == 2 || last_fallback == verified) { rc = report_panel_guard(h, w, h->stream); break; }
+            rc = rollback(verified);
+            last_fallback = verified; fallback_until = it; it = verified;
+            continue;
+        }
+        if (w[0] > 0) {
+            set_error("chol(): decomposition failed (leading minor of order %d is not positive definite)", w[0]);
+            rc = w[0];
+        } else if (w[8] != 0) {
+            set_error("sampler state is not finite (flag %d)", w[8]); rc = w[8];
+        } else if (w[9] != 0) {
+            rc = report_degenerate_theta(s, w[9]);
+        } else {
+            verified = k;
+            if (k > B_it) rc = start_store(k);
         }
     }
-    if (!rc && pending >= 0) rc = drain(pending);
+    for (int q = 0; q < NS; ++q) { const int r2 = finish_store(q); if (!rc) rc = r2; }
     if (rc != GPIRT_E_INTERRUPT) {
         const int rc2 = gpirt_sampler_check(s);                            // final, synchronising
         if (!rc) rc = rc2;
     }
-    cleanup();
+    if (copy_stream) { hipStreamSynchronize(copy_stream); hipStreamDestroy(copy_stream); }
+    for (int q = 0; q < NS; ++q) {
+        if (ck[q]) hipFree(ck[q]);
+        if (ev_flags[q]) hipEventDestroy(ev_flags[q]);
+        if (ev_copied[q]) hipEventDestroy(ev_copied[q]);
+    }
+    if (h_poll) hipHostFree(h_poll);
     if (!rc) rc = gpirt_sampler_finish_irfs(s, S_it, h_irfs);
+    g_last_mcmc_fallbacks = h->guard_fallbacks;
     gpirt_sampler_destroy(s);
     gpirt_destroy(h);
     return rc;

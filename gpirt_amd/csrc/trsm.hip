@@ -453,10 +453,9 @@ int launch_trsm_lower(gpirt_handle_t h, hipStream_t stream, const double* L, int
                       double* B, int64_t nrhs, int64_t ldb, bool trans, bool reuse_inverses)
 {
     if (n <= 0 || nrhs <= 0) return 0;
-    // GPIRT_TRSM_INV=2 keeps every leaf a substitution (read per call: tests/test_gpu_configs.py switches it inside one
-    // process to price the block inverses against LAPACK)
-    const char* inv_env = getenv("GPIRT_TRSM_INV");
-    const bool use_inv = !(inv_env && atoi(inv_env) == 2);
+    // GPIRT_TRSM_INV=2 keeps every leaf a substitution (tests/test_gpu_configs.py sets it through gpirt_config_set to
+    // price the block inverses against LAPACK)
+    const bool use_inv = h->cfg.trsm_inv != 2;
     const double* winv = nullptr;
     const int64_t nfull = n / NL4, npair = nfull / 2;
     const bool odd = (nfull & 1) != 0;

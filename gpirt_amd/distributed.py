@@ -114,21 +114,27 @@ class ShardedSampler:
         rows = e.panel_rows                         # n, plus the rows of a bordered factorisation
         owner = lambda p: p % self.world
         mine = lambda p: owner(p) == self.rank
-        if self._panel_bufs is None:
-            # two broadcast buffers: one half travels while the previous one is still being unpacked / applied
-            self._panel_bufs = [torch.empty(rows * min(H, n), dtype=torch.float64, device=e.torch_device) for _ in range(2)]
-        seq = [0]
-
         def cols(p, half):
             P0, P1 = p * W, min((p + 1) * W, n)
             mid = min(P0 + H, P1)
             return (P0, mid) if half == 0 else (mid, P1)
+
+        if self._panel_bufs is None:
+            # two broadcast buffers: one half travels while the previous one is still being unpacked / applied.  Sized for
+            # the LARGEST part that will travel: half 1 ("the rest") is W - H columns wide -- wider than half 0 whenever
+            # the sub-panel is narrower than half an outer panel (GPIRT_NBP < GPIRT_NBO / 2; round-3 advisor finding: the
+            # buffers held rows * H doubles and a torch slice past the end truncates silently)
+            need = max((rows - k0) * (k1 - k0) for p in range(NP) for k0, k1 in (cols(p, 0), cols(p, 1)))
+            self._panel_bufs = [torch.empty(need, dtype=torch.float64, device=e.torch_device) for _ in range(2)]
+        seq = [0]
 
         def send(p, half):      # collective: every rank calls it, in the same order
             k0, k1 = cols(p, half)
             if k1 <= k0:
                 return None
             buf = self._panel_bufs[seq[0] % 2][: (rows - k0) * (k1 - k0)]
+            if buf.numel() != (rows - k0) * (k1 - k0):
+                raise RuntimeError("panel broadcast buffer too small for part (%d, %d)" % (p, half))
             seq[0] += 1
             if mine(p):
                 e.panel_copy_part(p, half, buf, True)

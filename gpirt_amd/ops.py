@@ -78,13 +78,24 @@ class Handle:
             h = C.c_void_p()
             check(self.lib.gpirt_create(C.byref(h), device, C.c_void_p(self.stream.cuda_stream)))
         self._h = h
+        self._samplers = []                # weak references to the samplers created on this handle
 
     @property
     def ptr(self):
         return self._h
 
+    def _register(self, sampler):
+        import weakref
+        self._samplers = [r for r in self._samplers if r() is not None]
+        self._samplers.append(weakref.ref(sampler))
+
     def close(self):
         if getattr(self, "_h", None):
+            for r in getattr(self, "_samplers", []):      # samplers first: they drain this handle's streams when they go
+                s = r()
+                if s is not None:
+                    s.close()
+            self._samplers = []
             self.lib.gpirt_destroy(self._h)
             self._h = None
 
@@ -96,6 +107,42 @@ class Handle:
 
     def synchronize(self):
         check(self.lib.gpirt_synchronize(self._h))
+
+    # ---------------------------------------------------------------- switches / hang-guard fallback
+    def config_get(self, name: str) -> int:
+        v = C.c_int()
+        check(self.lib.gpirt_config_get(self._h, name.encode(), C.byref(v)))
+        return v.value
+
+    def config_set(self, name: str, value: int):
+        """Set one of the library's switches (README.md) for this handle; the environment is only read at process start."""
+        check(self.lib.gpirt_config_set(self._h, name.encode(), int(value)))
+
+    class _Override:
+        def __init__(self, h, name, value):
+            self.h, self.name, self.value = h, name, value
+
+        def __enter__(self):
+            self.old = self.h.config_get(self.name)
+            self.h.config_set(self.name, self.value)
+            return self.h
+
+        def __exit__(self, *exc):
+            self.h.config_set(self.name, self.old)
+
+    def config(self, name: str, value: int):
+        """`with handle.config("GPIRT_TRSM_INV", 2): ...` -- the switch for the duration of the block."""
+        return Handle._Override(self, name, value)
+
+    @property
+    def guard_fallbacks(self) -> int:
+        v = C.c_int()
+        check(self.lib.gpirt_guard_fallbacks(self._h, C.byref(v)))
+        return v.value
+
+    def debug_trip_guard(self, nth: int = 1):
+        """Debug: the nth factorisation from now ends as a hang-guard expiry would leave it (include/gpirt_hip.h)."""
+        check(self.lib.gpirt_debug_trip_guard(self._h, int(nth)))
 
     def calibrate_mfma_f64(self) -> float:
         v = C.c_double()
@@ -147,7 +194,8 @@ class Handle:
         check(self.lib.gpirt_potrf_panel_update_part(self._h, _p(A), A.shape[0], _ld(A), int(p), int(c), int(part)))
 
     def potrf_panel_copy_part(self, A: torch.Tensor, p: int, half: int, buf: torch.Tensor, to_buf: bool):
-        check(self.lib.gpirt_potrf_panel_copy_part(self._h, _p(A), A.shape[0], _ld(A), int(p), int(half), _p(buf), int(bool(to_buf))))
+        check(self.lib.gpirt_potrf_panel_copy_part(self._h, _p(A), A.shape[0], _ld(A), int(p), int(half), _p(buf), buf.numel(),
+                                                   int(bool(to_buf))))
 
     def potrf_finish(self):
         info = self.lib.gpirt_potrf_finish(self._h)

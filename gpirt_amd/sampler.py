@@ -124,8 +124,11 @@ class Sampler:
                                             _ptr(ps), _ptr(st), C.byref(o),
                                             rstream.ptr if rstream is not None else None))
         self._s = s
+        handle._register(self)
 
     def close(self):
+        """Destroy the device state.  Idempotent; Handle.close() closes the samplers still alive on it first, so no order of
+        teardown (fixtures, garbage collection at interpreter exit) can leave a sampler draining a freed handle."""
         if getattr(self, "_s", None):
             self.lib.gpirt_sampler_destroy(self._s)
             self._s = None
@@ -205,7 +208,8 @@ class Sampler:
         check(self.lib.gpirt_sampler_panel_update_part(self._s, int(p), int(c), int(part)))
 
     def panel_copy_part(self, p: int, half: int, buf, to_buf: bool):
-        check(self.lib.gpirt_sampler_panel_copy_part(self._s, int(p), int(half), C.c_void_p(buf.data_ptr()), int(bool(to_buf))))
+        check(self.lib.gpirt_sampler_panel_copy_part(self._s, int(p), int(half), C.c_void_p(buf.data_ptr()), buf.numel(),
+                                                     int(bool(to_buf))))
 
     def streams_busy(self) -> int:
         """bit mask of the handle's internal streams with work in flight (0: every piece has joined the handle stream)"""

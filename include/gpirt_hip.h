@@ -70,6 +70,22 @@ int         gpirt_create_own_stream(gpirt_handle_t* h, int device);
 int         gpirt_destroy(gpirt_handle_t h);
 int         gpirt_synchronize(gpirt_handle_t h);
 int         gpirt_set_stream(gpirt_handle_t h, void* stream);
+/* The library's switches (README.md: GPIRT_PANEL, GPIRT_LOOKAHEAD, GPIRT_DEFER, GPIRT_TRSM_INV, GPIRT_LL_EXACT,
+ * GPIRT_BORDERED, GPIRT_EARLY_INV, GPIRT_PREP_EARLY, GPIRT_RUNTIME; GPIRT_NBO / GPIRT_NBP read-only).  The environment
+ * is read ONCE per process; every handle starts from those values and a caller may change them per handle here (drains
+ * the handle's stream; takes effect from the next call on).  Nothing in the library reads the environment per call. */
+int         gpirt_config_get(gpirt_handle_t h, const char* name, int* value);
+int         gpirt_config_set(gpirt_handle_t h, const char* name, int value);
+/* Hang-guard fallbacks taken on this handle so far: a factorisation whose persistent sub-panel kernel gave up on a
+ * progress counter (its work-groups were not co-resident within the spin bound, e.g. beside a foreign tenant of the GPU)
+ * is repeated ONCE from the intact theta with the launch-per-step panel (GPIRT_PANEL=2's path) by gpirt_factor,
+ * gpirt_sampler_check and gpirt_mcmc; only a failure of the repeat is an error. */
+int         gpirt_guard_fallbacks(gpirt_handle_t h, int* count);
+/* Debug: the nth factorisation enqueued on h from now (nth >= 1; 0 disarms) ends the way a guard expiry leaves it -- guard
+ * word raised, result unfinished -- without spinning any kernel.  h == NULL arms the handle the NEXT gpirt_mcmc call
+ * creates for itself (that call reports its fallbacks through gpirt_debug_last_mcmc_fallbacks). */
+int         gpirt_debug_trip_guard(gpirt_handle_t h, int nth);
+int         gpirt_debug_last_mcmc_fallbacks(void);
 /* Peak fp64 MFMA rate of this device measured by a back-to-back v_mfma_f64_16x16x4_f64 loop
  * (TFLOP/s); used to calibrate the roofline. */
 int         gpirt_calibrate_mfma_f64(gpirt_handle_t h, double* tflops);
@@ -109,11 +125,14 @@ int gpirt_potrf_finish(gpirt_handle_t h);
  *   part: 0 = what needs only panel p's first sub-panel, 1 = everything else, 2 = all     (update)
  * let the next owner start on a panel's first half while its second half is still being factored or travelling.
  * Factoring / updating by halves launches exactly what the whole-panel calls launch, in the same order: L is the same
- * bit for bit.  copy_part moves the part's columns, rows from the part's first row down (dense, ld = that row count). */
+ * bit for bit.  copy_part moves the part's columns, rows from the part's first row down (dense, ld = that row count);
+ * buf_doubles is the capacity of d_buf in doubles: a part that does not fit is refused (GPIRT_E_ARG), never truncated
+ * (half 1 is W - H columns wide, wider than half 0 whenever GPIRT_NBP < GPIRT_NBO / 2). */
 int64_t gpirt_potrf_subpanel_width(void);
 int gpirt_potrf_panel_factor_part(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda, int64_t p, int half);
 int gpirt_potrf_panel_update_part(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda, int64_t p, int64_t c, int part);
-int gpirt_potrf_panel_copy_part(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda, int64_t p, int half, double* d_buf, int to_buf);
+int gpirt_potrf_panel_copy_part(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda, int64_t p, int half, double* d_buf,
+                                int64_t buf_doubles, int to_buf);
 /* Debug aid for hosts that enqueue collectives between the pieces: *busy = bit mask of the handle's INTERNAL streams that
  * still have work in flight (0 = every piece has joined the handle's stream, as each must before it returns). */
 int gpirt_debug_streams_busy(gpirt_handle_t h, int* busy);
@@ -276,7 +295,7 @@ int gpirt_sampler_panel_rows(gpirt_sampler_t s, int64_t* rows);
 /* ... and by halves of an outer panel (gpirt_potrf_panel_*_part above) */
 int gpirt_sampler_panel_factor_part(gpirt_sampler_t s, int64_t p, int half);
 int gpirt_sampler_panel_update_part(gpirt_sampler_t s, int64_t p, int64_t c, int part);
-int gpirt_sampler_panel_copy_part(gpirt_sampler_t s, int64_t p, int half, double* d_buf, int to_buf);
+int gpirt_sampler_panel_copy_part(gpirt_sampler_t s, int64_t p, int half, double* d_buf, int64_t buf_doubles, int to_buf);
 /* Close the iteration WITHOUT factoring: "L" arrived from elsewhere (a broadcast into the "L" devptr, the distributed
  * pieces, gpirt_sampler_set).  rows_with_L != 0: the rows below the n x n factor (gpirt_sampler_ldl) arrived with it,
  * i.e. the whole ldl x n buffer was received; 0: only the n x n factor is current and the rows are rebuilt by the

@@ -5,8 +5,9 @@
  * returned list (src/gpirtMCMC.cpp:112-116), same RNG bracketing (Rcpp::RNGScope,
  * src/RcppExports.cpp:19), same progress text and interrupt polling (src/gpirtMCMC.cpp:64-66,105).
  *
- * NOT compiled in the build container (R.h / Rinternals.h are absent there);
- * every behaviour it relies on is exercised through the same C ABI by the Python harness
+ * NOT built in the build container (R.h / Rinternals.h are absent there): tests/test_host.py only
+ * checks that it still PARSES and type-checks, against declarations-only stand-ins for the R headers it names
+ * (tests/r_stub/); every behaviour it relies on is exercised through the same C ABI by the Python harness
  * (gpirt_amd/sampler.py).  Build inside the R package with:
  *     PKG_CPPFLAGS = -I<repo>/include      PKG_LIBS = -L<repo>/gpirt_amd -lgpirt_hip
  */
@@ -21,11 +22,18 @@
 
 static void chk_interrupt(void* dummy) { (void)dummy; R_CheckUserInterrupt(); }
 
-/* Rprintf("\r%6.3f %% complete") + Rcpp::checkUserInterrupt(), src/gpirtMCMC.cpp:64-66 */
+/* Rprintf("\r%6.3f %% complete", progress); progress += progress_increment; Rcpp::checkUserInterrupt() --
+ * src/gpirtMCMC.cpp:57-66, 83-85.  The reference ACCUMULATES progress_increment = (1.0 / total) * 100.0 once per
+ * iteration, so the number printed in front of iteration `iter` is that increment added `iter` times (not
+ * 100 * iter / total, which differs in the last printed digit now and then).  Recomputed from `iter` on every call:
+ * the core may call tick again for an iteration it repeats after a hang-guard fallback (gpirt_mcmc). */
 static int tick(void* ctx, int iter, int total)
 {
     (void)ctx;
-    Rprintf("\r%6.3f %% complete", 100.0 * (double)iter / (double)(total > 0 ? total : 1));
+    const double progress_increment = (1.0 / (double)total) * 100.0;
+    double progress = 0.0;
+    for (int k = 0; k < iter; ++k) progress += progress_increment;
+    Rprintf("\r%6.3f %% complete", progress);
     /* R_ToplevelExec returns FALSE when the user interrupted: ask the core to stop cleanly so
      * device memory is released before the R condition is raised */
     return R_ToplevelExec(chk_interrupt, NULL) ? 0 : 1;
@@ -34,9 +42,14 @@ static int tick(void* ctx, int iter, int total)
 /* R's Mersenne-Twister state lives in .Random.seed: [kind, mti, mt[0..623]].  The reference reads
  * and writes it through GetRNGstate()/PutRNGstate(); the HIP core replays the same stream, so the
  * state is handed over explicitly and written back. */
+/* .Random.seed[1] = RNG kind + 100 * normal kind + 10000 * sample kind (R's RNG.c): Mersenne-Twister is kind 3 and
+ * INVERSION is normal kind 4 -- BOTH are needed: under RNGkind(normal.kind = "Box-Muller") R::rnorm no longer is
+ * qnorm of two uniforms, and replaying inversion normals would silently draw something else. */
 static int rng_is_default_mt(SEXP seedvec)
 {
-    return TYPEOF(seedvec) == INTSXP && LENGTH(seedvec) == 626 && (INTEGER(seedvec)[0] % 100) == 3;
+    if (TYPEOF(seedvec) != INTSXP || LENGTH(seedvec) != 626) return 0;
+    const int code = INTEGER(seedvec)[0];
+    return (code % 100) == 3 && ((code / 100) % 100) == 4;
 }
 
 SEXP _gpirt_gpirtMCMC(SEXP ySEXP, SEXP thetaSEXP, SEXP sample_iterationsSEXP, SEXP burn_iterationsSEXP,

@@ -15,13 +15,14 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(rank, world, port, chol, outdir, theta="gather", m=7):
+def _run(rank, world, port, chol, outdir, theta="gather", m=7, sub=8):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from _oracle_engine import OracleEngine
+    OracleEngine.subpanel_width = sub
     from gpirt_amd.distributed import ShardedSampler
     from gpirt_amd.synthetic import make_responses
     y, th0 = make_responses(40, m, seed=4)
@@ -33,25 +34,29 @@ def _run(rank, world, port, chol, outdir, theta="gather", m=7):
     beta = ss.gather("beta")
     fstar = ss.gather("fstar")
     if rank == 0:
-        np.savez(os.path.join(outdir, f"sharded_{chol}_{theta}_{m}.npz"), f=f, beta=beta, fstar=fstar, theta=ss.engine.theta,
+        np.savez(os.path.join(outdir, f"sharded_{chol}_{theta}_{m}_{sub}.npz"), f=f, beta=beta, fstar=fstar, theta=ss.engine.theta,
                  L=ss.engine.L)
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("chol,theta,m", [("replicated", "gather", 7), ("bcast", "gather", 8), ("replicated", "allreduce", 7),
-                                          ("bcast", "allreduce", 7), ("distributed", "gather", 8)])
-def test_two_ranks_reproduce_single_process(tmp_path, chol, theta, m):
+@pytest.mark.parametrize("chol,theta,m,sub", [("replicated", "gather", 7, 8), ("bcast", "gather", 8, 8), ("replicated", "allreduce", 7, 8),
+                                              ("bcast", "allreduce", 7, 8), ("distributed", "gather", 8, 8),
+                                              ("distributed", "gather", 8, 4)])
+def test_two_ranks_reproduce_single_process(tmp_path, chol, theta, m, sub):
     """theta="gather": f* is all-gathered (m = 8: equal shards, flat all-gather; m = 7: unequal shards, the
     all-reduce-of-disjoint-supports fallback) and each rank draws theta for its block of respondents;
-    theta="allreduce": the partial log-posteriors are all-reduced."""
+    theta="allreduce": the partial log-posteriors are all-reduced.  sub = 4: a sub-panel narrower than half an outer
+    panel (16), so the second half of a panel ("the rest", 12 columns) is WIDER than the first -- the broadcast buffers
+    must be sized for it (round-3 advisor finding: they held rows x sub doubles and the slice truncated silently)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from _oracle_engine import OracleEngine
     from gpirt_amd.distributed import ShardedSampler
     from gpirt_amd.synthetic import make_responses
     port = 29500 + (os.getpid() % 2000) + (1 if chol == "bcast" else 0) + (2 if theta == "gather" else 0)
-    mp.spawn(_run, args=(2, port, chol, str(tmp_path), theta, m), nprocs=2, join=True)
-    got = np.load(tmp_path / f"sharded_{chol}_{theta}_{m}.npz")
+    mp.spawn(_run, args=(2, port + sub, chol, str(tmp_path), theta, m, sub), nprocs=2, join=True)
+    got = np.load(tmp_path / f"sharded_{chol}_{theta}_{m}_{sub}.npz")
     y, th0 = make_responses(40, m, seed=4)
+    OracleEngine.subpanel_width = sub
     ref = ShardedSampler(OracleEngine, y, th0, dist=None)
     ref.init()
     for _ in range(2):

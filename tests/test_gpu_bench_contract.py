@@ -30,3 +30,29 @@ def test_bench_json_contract():
         assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    # what the DEFAULT contract (R-stream replay, everything as written) costs on the same problem, in the same line
+    rr = d["config"]["reference_rng"]
+    assert rr["iterations"] == 2 and rr["value"] > 0 and d["config"]["reference_rng_iterations_per_s"] == rr["value"]
+    assert rr["value"] < d["value"]
+
+
+def test_bench_two_rank_rehearsal_carries_the_speedup_fields():
+    """The first multi-GPU run must be self-contained (round-3 verdict, item 4): with --gpus N > 1 rank 0 also runs the
+    FULL problem alone and the line carries item_shard_speedup (per stage and total), whole_iteration_speedup and the
+    world size the backend reports.  Rehearsed here with two gloo ranks sharing the one GPU (the numbers mean nothing on
+    one card; the fields, the barriers and the order of collectives are what is tested)."""
+    port = 29650 + (os.getpid() % 300)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device",
+           "--n", "2048", "--m", "128", "--steps", "2", "--warmup", "1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["backend_reported"] == "gloo" and d["scaling"] == "strong"
+    sp = d["item_shard_speedup"]
+    assert set(sp["per_stage"]) >= {"draw_f", "draw_fstar"} and sp["total"] > 0
+    assert sp["single_gpu_stage_ms"]["draw_f"] > 0 and sp["sharded_stage_ms_max_over_ranks"]["draw_f"] > 0
+    assert d["whole_iteration_speedup"] > 0 and d["single_gpu_iterations_per_s"] > 0
+    assert len(d["config"]["stage_ms_per_rank"]) == 2

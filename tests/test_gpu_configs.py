@@ -96,12 +96,9 @@ def _run_forms(handle, n, m, seed, iters, cols):
             worst["factor_share"] = max(worst["factor_share"], float(np.abs(mean_devL - mean_h).max()))
             # attribution: the same draw_fstar with every trsm leaf a substitution (no 512 x 512 block inverses) -- f, theta, L
             # and the RNG keys are unchanged, so only the two solves behind `mean` differ
-            os.environ["GPIRT_TRSM_INV"] = "2"
-            try:
+            with handle.config("GPIRT_TRSM_INV", 2):
                 ref.draw_fstar()
                 mean_sub = ref.get("mean")[:, cols]
-            finally:
-                os.environ.pop("GPIRT_TRSM_INV", None)
             worst["mean_lapack_subst"] = max(worst["mean_lapack_subst"], float(np.abs(mean_sub - mean_h).max()))
             worst["mean_inv_vs_subst"] = max(worst["mean_inv_vs_subst"], float(np.abs(mean_sub - mean_dev).max()))
             ref.draw_fstar()                      # back on the default leaves (fstar is what theta consumes next)

@@ -45,13 +45,12 @@ def test_fenced_build_gives_the_same_factor_bit_for_bit():
     assert a == b, "\n".join(f"{x}\n{y}" for x, y in zip(a, b) if x != y)
 
 
-@pytest.mark.parametrize("switch", ["GPIRT_HALF_AHEAD=2", "GPIRT_DEFER_PAR=2", "GPIRT_DEFER_SPLIT=1", "GPIRT_ROWS=1", "GPIRT_DEFER=2"])
+@pytest.mark.parametrize("switch", ["GPIRT_DEFER=2", "GPIRT_LOOKAHEAD=2"])
 def test_schedule_switches_leave_the_factor_bit_identical(switch):
-    """Every opt-in / opt-out schedule of the factorisation that claims the SAME products in the same order per element
-    (potrf.hip: the early half of the chain-critical update off; the step's deferred updates as one grid with in-order
-    application; the same cut in two by rows on two streams; the lean rows kernel beside the chain launch; the plain
-    right-looking order) must reproduce the default factor bit for bit -- operator sizes 257 ... 8192 and the sampler's
-    bordered factorisations.  (The switches are read once per process: each runs in a child.)"""
+    """The schedules of the factorisation that apply the SAME products in the same order per element (potrf.hip: the plain
+    right-looking order instead of the deferred updates; no look-ahead side stream) must reproduce the default factor bit
+    for bit -- operator sizes 257 ... 8192 and the sampler's bordered factorisations.  (The environment is read once per
+    process: each switch runs in a child.)"""
     k, v = switch.split("=")
     a = _default_hashes()
     b = _hashes(**{k: v})

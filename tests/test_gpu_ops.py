@@ -97,70 +97,6 @@ def test_potrf_matches_oracle(handle, oracle, n):
     assert np.abs(L - Lref).max() <= 1e-11
 
 
-def test_potrf_previous_panel_kernel_agrees():
-    """GPIRT_PANEL_COLS=0 (the sub-panel kernel without the column-by-column hand-off of L_jj) is read once per
-    process: factor the same matrices in a child process under it and compare with this process's factor.  The two
-    kernels apply the 16 x 16 diagonal blocks through inverses built from different reciprocals, so L agrees to
-    rounding, not bit for bit."""
-    import os, subprocess, sys, tempfile
-    from gpirt_amd.ops import Handle, to_device, to_host
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sizes = [1000, 2048, 3000]
-    code = (
-        "import sys, numpy as np\n"
-        "sys.path.insert(0, %r)\n"
-        "from gpirt_amd.ops import Handle, to_device, to_host\n"
-        "h = Handle()\n"
-        "out = {}\n"
-        "for n in %r:\n"
-        "    rng = np.random.default_rng(n)\n"
-        "    k = np.clip(np.rint((rng.standard_normal(n) + 5.0) / 0.01), 0, 1000)\n"
-        "    out[str(n)] = to_host(h.factor(to_device(-5.0 + k * 0.01)))\n"
-        "np.savez(sys.argv[1], **out)\n" % (root, sizes))
-    with tempfile.TemporaryDirectory() as d:
-        path = os.path.join(d, "L.npz")
-        env = dict(os.environ, GPIRT_PANEL_COLS="0")
-        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        other = np.load(path)
-        h = Handle()
-        for n in sizes:
-            theta = _theta_grid(n, n)
-            L = to_host(h.factor(to_device(theta)))
-            S = np.exp(-0.5 * (theta[:, None] - theta[None, :]) ** 2)
-            S[np.diag_indices(n)] += 0.001
-            for name, M in (("progressive", L), ("previous", other[str(n)])):
-                resid = np.linalg.norm(M @ M.T - S) / np.linalg.norm(S)
-                assert resid <= 1e-14 * n, (name, n, resid)
-            assert np.abs(L - other[str(n)]).max() <= 1e-11, n
-
-
-@pytest.mark.parametrize("n", [2560, 3100, 4160, 8192])
-def test_potrf_windowed_schedule_agrees(handle, n):
-    """GPIRT_SCHED=2 (potrf.hip: the sub-panel split into a chain launch on the outer panel's own rows +
-    panel_rows_kernel -- lean 32-row work-groups -- on the rows below, five streams; the pre-launched, flag-started form
-    of the chain launches stays behind GPIRT_WIN_PRE=1 and is not part of this test) against the default
-    one-kernel-per-sub-panel schedule.  Every product is the same except the two small split-K updates on the chain and
-    the undivided K = 1024 update of the next panel's first columns: L agrees to rounding (1e-12), factors the same
-    matrix to the same residual, and the schedule never trips the hang guard.  (Opt-in: it measured slower)"""
-    import os
-    import torch
-    from gpirt_amd.ops import to_device
-    g = torch.Generator(device="cpu"); g.manual_seed(n)
-    theta = torch.randn(n, generator=g, dtype=torch.float64)
-    theta = to_device((torch.round((theta + 5.0) / 0.01).clamp(0, 1000) * 0.01 - 5.0).numpy())   # grid-valued: steady state
-    L1 = torch.tril(handle.factor(theta)).clone()
-    os.environ["GPIRT_SCHED"] = "2"
-    try:
-        L2 = torch.tril(handle.factor(theta)).clone()
-        L3 = torch.tril(handle.factor(theta)).clone()        # a second run: the epochs, flags and streams are reused
-    finally:
-        os.environ.pop("GPIRT_SCHED", None)
-    assert torch.isfinite(L2).all()
-    assert torch.equal(L2, L3)
-    assert (L1 - L2).abs().max().item() <= 1e-12
-
-
 @pytest.mark.parametrize("n,G", [(5000, 3), (8192, 8), (1500, 2), (900, 4)])
 def test_potrf_in_pieces_is_bit_identical(handle, n, G):
     """the factorisation as a distributing host drives it -- 1-D block-cyclic ownership of the outer

@@ -66,6 +66,24 @@ def test_senate116_plumbing(handle, oracle):
     assert res["IRFs"].shape == (1001, 418) and np.all((res["IRFs"] >= 0) & (res["IRFs"] <= 1))
 
 
+def test_senate116_one_hundred_iterations_under_r_stream(handle, oracle):
+    """Config C1 AS BASELINE.json STATES IT: senate116 (n = 100, m = 418), 100 iterations (60 burn-in + 40 sampled), the
+    default contract -- R's Mersenne-Twister stream replayed draw for draw, src/draw-fstar.cpp and src/draw-theta.cpp as
+    written -- against the CPU restatement of the reference: every stored theta, beta, f and the IRFs."""
+    import os
+    from gpirt_amd import gpirtMCMC
+    from gpirt_amd.ops import RStream
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "senate116_y.npz"))
+    y = d["y"].astype(np.float64)
+    y[y == 0] = np.nan
+    res = gpirtMCMC(y, 40, 60, vote_codes=dict(yea=[1], nay=[-1], missing=[None]), rng="reference", rstream=RStream(1119))
+    r = oracle.RStream(1119)
+    th0 = r.rnorm(100)
+    ref = oracle.gpirt_mcmc(r, y, th0, 40, 60)
+    _check(res, ref)
+    assert res["theta"].shape == (41, 100) and res["f"].shape == (100, 418, 41)
+
+
 def test_sampler_stage_api_equals_step(handle, oracle):
     from gpirt_amd import Sampler
     from gpirt_amd.synthetic import make_responses
@@ -307,7 +325,7 @@ def test_lowrank_kstar_equals_full_solve(handle, n, m, rank):
 
 
 @pytest.mark.parametrize("form", ["lowrank", "fused", "double_solve"])
-def test_bordered_factorisation_equals_explicit_solve(handle, form, monkeypatch):
+def test_bordered_factorisation_equals_explicit_solve(handle, form):
     """L^-1 K(theta, c) (rank-64 form) and L^-1 k* (the 1001 grid columns; fused and as-written forms) come out of the
     factorisation as extra rows below S (potrf.hip, extra_rows).  With GPIRT_BORDERED=2 the same sampler solves for them
     explicitly (src/draw-fstar.cpp:19 as a trsm): same theta, f, L and RNG keys, so f*, theta and f must agree to
@@ -318,9 +336,9 @@ def test_bordered_factorisation_equals_explicit_solve(handle, form, monkeypatch)
     y, th0 = make_responses(n, m, seed=21)
     kw = dict(lowrank=dict(fstar_fused=True, kstar_rank=64), fused=dict(fstar_fused=True), double_solve=dict())[form]
     out = []
-    for bordered in ("1", "2"):
-        monkeypatch.setenv("GPIRT_BORDERED", bordered)
-        s = Sampler(handle, y, th0, rng="item", seed=9, theta_stabilise=True, **kw)
+    for bordered in (1, 2):
+        with handle.config("GPIRT_BORDERED", bordered):      # (the layout is chosen when the sampler is created)
+            s = Sampler(handle, y, th0, rng="item", seed=9, theta_stabilise=True, **kw)
         s.init()
         for _ in range(3):
             s.step()
@@ -427,15 +445,12 @@ def test_block_inverses_built_behind_the_factorisation_change_nothing(handle):
     for _ in range(3):
         a.step()
     a.check()
-    os.environ["GPIRT_EARLY_INV"] = "2"
-    try:
+    with handle.config("GPIRT_EARLY_INV", 2):
         b = Sampler(handle, y, th0, **kw)
         b.init()
         for _ in range(3):
             b.step()
         b.check()
-    finally:
-        os.environ.pop("GPIRT_EARLY_INV", None)
     for name in ("fstar", "theta", "f", "beta"):
         assert np.array_equal(a.get(name), b.get(name)), name
     a.close(); b.close()
@@ -453,9 +468,8 @@ def test_side_chain_beside_the_product_changes_nothing(handle):
     y, th0 = make_responses(n, m, seed=47)
     kw = dict(rng="item", seed=9, theta_stabilise=True, fstar_fused=True, kstar_rank=64)
     outs = []
-    for mode in ("1", "2"):
-        os.environ["GPIRT_PREP_EARLY"] = mode
-        try:
+    for mode in (1, 2):
+        with handle.config("GPIRT_PREP_EARLY", mode):
             s = Sampler(handle, y, th0, **kw)
             s.init()
             for _ in range(3):
@@ -463,7 +477,5 @@ def test_side_chain_beside_the_product_changes_nothing(handle):
             s.check()
             outs.append({name: s.get(name) for name in ("fstar", "theta", "f", "beta")})
             s.close()
-        finally:
-            os.environ.pop("GPIRT_PREP_EARLY", None)
     for name in outs[0]:
         assert np.array_equal(outs[0][name], outs[1][name]), name

@@ -92,16 +92,14 @@ def test_slice_sampler_with_the_written_form_agrees():
     y, th0 = make_responses(n, m, seed=31)
     h = Handle()
     outs = []
-    for exact in ("0", "1"):
-        os.environ["GPIRT_LL_EXACT"] = exact
-        try:
+    for exact in (0, 1):
+        with h.config("GPIRT_LL_EXACT", exact):
             s = Sampler(h, y, th0, rng="item", seed=77, theta_stabilise=True, fstar_fused=True, kstar_rank=64)
             s.init()
             for _ in range(3):
                 s.step()
             outs.append((s.get("f"), s.get("ess_k"), s.get("theta")))
-        finally:
-            os.environ.pop("GPIRT_LL_EXACT", None)
+            s.close()
     (f0, k0, t0), (f1, k1, t1) = outs
     assert np.array_equal(k0, k1)
     assert np.array_equal(t0, t1)

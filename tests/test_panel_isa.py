@@ -18,8 +18,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CENSUS = os.path.join(ROOT, "tests", "golden", "panel_isa_census.json")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-unused-function", "-Wno-unused-value"]
-NAMES = {"panel_ll_kernelILb1ELb0": "panel_ll_kernel<true,false>", "panel_ll_kernelILb0ELb0": "panel_ll_kernel<false,false>",
-         "panel_ll_kernelILb1ELb1": "panel_ll_kernel<true,true>", "panel_rows_kernel": "panel_rows_kernel"}
+NAMES = {"panel_ll_kernel": "panel_ll_kernel"}
 
 
 def census():
@@ -65,8 +64,6 @@ def test_panel_isa_census_unchanged():
             f"{k}: the number of PLAIN global accesses changed ({w['loads_plain']} loads / {w['stores_plain']} stores -> "
             f"{g['loads_plain']} / {g['stores_plain']}): check that the new access is to own rows only, then refresh the census")
         assert g["loads_sc1"] >= 1 and g["mfma"] >= 1, (k, g)
-    # the lean rows kernel must fit beside two 64-tile update work-groups (160 registers each): <= 168 of 512
-    assert got["panel_rows_kernel"]["next_free_vgpr"] <= 168, got["panel_rows_kernel"]
 
 
 if __name__ == "__main__":

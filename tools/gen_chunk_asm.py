@@ -8,6 +8,12 @@ instructions of 8-byte loads), whose instructions have to sit BETWEEN the MFMAs 
 chunk's 32 loads cost 0.8 us (tools/micro/panel_bench, -DPANEL_CHUNK_PROF).
 
     python tools/gen_chunk_asm.py          (re-run after changing the LDS images or the schedule)
+
+The blocks that carry LDS-DMA rewrite M0 (s_add_u32 m0, ...: that also writes SCC).  SCC is declared clobbered -- LLVM
+assumes any register an asm does not name survives it, so a scalar compare kept live across the block would otherwise be
+miscompiled silently (round-3 advisor finding).  M0 is a RESERVED register for this compiler (naming it in the clobber
+list is diagnosed as possible undefined behaviour): it is saved and restored inside the block instead, so it does survive.
+tests/test_host.py checks that the committed header is this script's output byte for byte.
 """
 import os
 
@@ -91,7 +97,7 @@ __device__ __forceinline__ void chunk_half_dma{name}(d4 (&T)[4], const double (&
         : {t_out},
           [va] "+v"(va), [keep] "=&s"(keep)
         : {x_in}, [st] "s"(st), [lb] "s"(lb)
-        : "memory");
+        : "memory", "scc");
 }}
 
 // the eight pieces alone (a step's first chunk)
@@ -102,7 +108,7 @@ __device__ __forceinline__ void chunk_dma{name}(const double* va, uint64_t st, u
 {emit(dma_only(sc1))}
         : [va] "+v"(va), [keep] "=&s"(keep)
         : [st] "s"(st), [lb] "s"(lb)
-        : "memory");
+        : "memory", "scc");
 }}
 ''')
     text = f'''// chunk_asm.h -- GENERATED by tools/gen_chunk_asm.py, do not edit.
@@ -132,6 +138,11 @@ __device__ __forceinline__ void chunk_half_plain(d4 (&T)[4], const double (&x)[{
 {"".join(parts)}
 }}  // namespace gpirt
 '''
+    return out, text
+
+
+def write():
+    out, text = main()
     with open(out, "w") as f:
         f.write(text)
     print("wrote", os.path.normpath(out))
@@ -139,4 +150,4 @@ __device__ __forceinline__ void chunk_half_plain(d4 (&T)[4], const double (&x)[{
 
 DMA_SLOT_STEP = 1
 if __name__ == "__main__":
-    main()
+    write()
