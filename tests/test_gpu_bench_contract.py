@@ -44,7 +44,7 @@ def test_bench_two_rank_rehearsal_carries_the_speedup_fields():
     port = 29650 + (os.getpid() % 300)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device",
-           "--n", "2048", "--m", "128", "--steps", "2", "--warmup", "1"]
+           "--respondents", "2048", "--items", "128", "--steps", "2", "--warmup", "1"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
