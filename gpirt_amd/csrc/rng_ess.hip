@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void ess_kernel(EssArgs a)
     const uint64_t p0 = stream ? (*a.pos + 2ull * (uint64_t)n) : 0ull;   // after the n normals
     const uint32_t item = a.item0 + (uint32_t)j;
     uint32_t uidx = 0;
-    bool overflow = false;
+    bool overflow = false, nan_state = false;
     auto next_u = [&]() -> double {
         double u;
         if (stream) {
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void ess_kernel(EssArgs a)
         }
         const double llp = -block_sum_256(acc, red);
         if (llp > log_y) break;                                            // :45-47
-        if (llp != llp) { overflow = true; break; }                        // NaN state: never accepts
+        if (llp != llp) { nan_state = true; break; }                       // NaN state: never accepts
         if (eps < 0.0) eps_min = eps; else eps_max = eps;                  // :50-55
         if (eps_min == eps_max) eps = eps_min;                             // R::runif(a,a) = a
         else eps = eps_min + (eps_max - eps_min) * next_u();               // :56
@@ -140,7 +140,8 @@ __global__ __launch_bounds__(256) void ess_kernel(EssArgs a)
     for (int64_t i = threadIdx.x; i < n; i += 256) fj[i] = fj[i] * c + nj[i] * s;
     if (threadIdx.x == 0) {
         if (a.k_out) a.k_out[j] = k;
-        if (overflow && a.err) atomicCAS(a.err, 0, stream ? GPIRT_E_RNG : GPIRT_E_NUMERIC);
+        if (nan_state && a.err) atomicCAS(a.err, 0, (int)GPIRT_E_NUMERIC);
+        else if (overflow && a.err) atomicCAS(a.err, 0, stream ? GPIRT_E_RNG : GPIRT_E_NUMERIC);
         if (stream) *a.pos = p0 + uidx;
     }
 }

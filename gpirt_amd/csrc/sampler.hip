@@ -119,6 +119,8 @@ int dalloc(gpirt_sampler_s* s, T** p, size_t count)
 
 inline bool stream_mode(const gpirt_sampler_s* s) { return s->opt.rng_kind == GPIRT_RNG_RSTREAM; }
 
+int report_degenerate_theta(gpirt_sampler_s* s, int count);
+
 // ---- R-stream window: generate `count` uniforms ahead, upload, reset the device cursor -------
 int stream_begin(gpirt_sampler_s* s, uint64_t count)
 {
@@ -142,9 +144,12 @@ int stream_end(gpirt_sampler_s* s)
     s->stream_open = false;
     if (s->h_flags[0] != 0) {
         set_error(s->h_flags[0] == GPIRT_E_RNG ? "R-stream replay ran out of pre-generated uniforms"
-                                               : "elliptical slice sampler did not terminate");
+                                               : "sampler state is not finite (elliptical slice sampler met a NaN log-likelihood or did not terminate)");
         return s->h_flags[0];
     }
+    // draw_theta as written underflows to 0/0 for some respondents (quirk Q5: the reference then reads theta_star[N] out
+    // of bounds): reported at the iteration it happens in, not as whatever the NaN theta breaks next
+    if (s->h_flags[1] != 0) return report_degenerate_theta(s, s->h_flags[1]);
     const uint64_t used = *s->h_pos;
     *s->rs = s->saved;
     for (uint64_t i = 0; i < used; ++i) (void)s->rs->next32();
@@ -217,6 +222,7 @@ int launch_trmv_lower(hipStream_t st, const double* L, int64_t n, int64_t ldl, c
 }
 
 int fstar_prep(gpirt_sampler_s* s, gpirt_handle_t hh);
+int report_degenerate_theta(gpirt_sampler_s* s, int count);
 int rebuild_rows(gpirt_sampler_s* s);
 int beta_sync(gpirt_sampler_s* s);
 
