@@ -31,6 +31,9 @@ const Config& env_config()
         d.early_inv = env_value("GPIRT_EARLY_INV", d.early_inv);
         d.prep_early = env_value("GPIRT_PREP_EARLY", d.prep_early);
         d.runtime = env_value("GPIRT_RUNTIME", d.runtime);
+        d.guard_verbose = env_value("GPIRT_GUARD_VERBOSE", d.guard_verbose);
+        d.rt_workers = env_value("GPIRT_RT_WORKERS", 0);
+        d.rt_reserved = env_value("GPIRT_RT_RESERVED", 0);
         if (d.nbo < 64) d.nbo = 1024;
         if (d.nbp < 64) d.nbp = 512;
         return d;
@@ -216,6 +219,9 @@ int gpirt_destroy(gpirt_handle_t h)
     if (h->panel_trace && h->panel_trace_cap > 0) hipFree(h->panel_trace);
     if (h->aux) { hipStreamSynchronize(h->aux->stream); gpirt_destroy(h->aux); h->aux = nullptr; }
     if (h->d_defer_ws) hipFree(h->d_defer_ws);
+    potrf_runtime_destroy(h);
+    if (h->rt_census) hipFree(h->rt_census);
+
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -370,6 +376,26 @@ int gpirt_factor(gpirt_handle_t h, const double* d_theta, int64_t n, double* d_L
         GP_TRY(rc);
     }
     return finish_info(h);
+}
+
+// Debug: where the work-groups of the dependency-driven factorisation land.  host_out == NULL arms it (the next
+// factorisations record), otherwise copies out [2][4096][4] words: {HW_ID, XCC_ID, arrival index, stayed} per update worker
+// (first half) and per CU holder (second half).
+int gpirt_debug_rt_census(gpirt_handle_t h, unsigned int* host_out)
+{
+    GP_ARG(h != nullptr);
+    const size_t bytes = (size_t)2 * 4096 * 4 * sizeof(unsigned int) + (size_t)4096 * 8 * sizeof(long long) +  // + per-worker stats
+                         (size_t)65536 * 2 * sizeof(long long);                                               // + [start, end] per task
+    GP_HIP(hipStreamSynchronize(h->stream));
+    if (!host_out) {
+        if (!h->rt_census) GP_HIP(hipMalloc(&h->rt_census, bytes));
+        GP_HIP(hipMemset(h->rt_census, 0xff, bytes));
+        return 0;
+    }
+    GP_ARG(h->rt_census != nullptr);
+    GP_HIP(hipDeviceSynchronize());
+    GP_HIP(hipMemcpy(host_out, h->rt_census, bytes, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 int gpirt_guard_fallbacks(gpirt_handle_t h, int* count)

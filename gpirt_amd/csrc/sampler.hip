@@ -55,6 +55,7 @@ struct gpirt_sampler_s {
     // from outside, rebuilt by an explicit solve on demand (rebuild_rows).
     int64_t ext = 0, ldl = 0;
     bool ext_grid = false, rows_valid = false;
+    bool scratch = false;             // the L buffer carries the scratch rows of the dependency-driven factorisation (runtime.hip)
     // Work that needs only L (not this iteration's f) runs on a stream of the sampler's own, beside draw_f's elliptical
     // slice kernel: the part of the low-rank draw_fstar that depends on the factor alone (C = L^-T B, G = B^T B).
     // haux is the main handle's side handle (h->aux, shared by the samplers of that handle, not owned) on that stream (its own trsm / split-K workspaces: several
@@ -528,7 +529,7 @@ int do_factor(gpirt_sampler_s* s)
     invalidate_factor_products(s);
     GP_TRY(build_cov(s));                                                                                  // :76-77
     s->rows_valid = true;
-    GP_TRY(launch_potrf_lower(s->h, st, s->L, s->n, s->ldl, false, !s->sticky_info, s->ext));             // :78
+    GP_TRY(launch_potrf_lower(s->h, st, s->L, s->n, s->ldl, false, !s->sticky_info, s->ext, s->scratch)); // :78
     // The low-rank draw_fstar's transposed solve (fstar_prep) goes through the inverses of L's 1024 x 1024 diagonal blocks:
     // ~5 GFLOP to build at n = 8192, and they only need the DIAGONAL blocks, final panel by panel.  Those of every outer
     // panel but the last are built on the sampler's own stream while the last outer panel is factored (16 + 8 whole-CU
@@ -662,6 +663,12 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
         s->ext_grid = true;
     }
     s->ldl = n + s->ext;
+    if (!stream_mode(s) && potrf_runtime_usable(h, n, n + s->ext)) {
+        // GPIRT_RUNTIME=2 (runtime.hip): rows of scratch below the factor -- the identity rows whose sweep leaves the inverse
+        // of a sub-panel's diagonal block -- from the next multiple of an outer panel on
+        s->scratch = true;
+        s->ldl = potrf_runtime_scratch_row0(n + s->ext) + potrf_runtime_scratch_rows();
+    }
     GP_A(s->mu, n * m);      GP_A(s->mu_star, N * m + 1); GP_A(s->fstar, N * m + 1); GP_A(s->L, s->ldl * n);
     GP_A(s->tstar, N + 1);   GP_A(s->rhs, n * (N + m) + 2); GP_A(s->mean, N * m + 1); GP_A(s->s, N + 1);
     GP_A(s->Gpm, ((N + 127) / 128 * 128) * 2 * m + 2); GP_A(s->logpost, N * n + 2); GP_A(s->irf_sum, N * m + 1);

@@ -86,6 +86,10 @@ int         gpirt_guard_fallbacks(gpirt_handle_t h, int* count);
  * creates for itself (that call reports its fallbacks through gpirt_debug_last_mcmc_fallbacks). */
 int         gpirt_debug_trip_guard(gpirt_handle_t h, int nth);
 int         gpirt_debug_last_mcmc_fallbacks(void);
+/* Debug (GPIRT_RUNTIME=2): where the work-groups of the dependency-driven factorisation land.  host_out == NULL arms it;
+ * otherwise copies out [2][4096][4] words {HW_ID, XCC_ID, arrival index, stayed} (update workers, then CU holders), then
+ * [4096][8] 64-bit per-worker counters and [65536][2] 64-bit task start / end stamps (100 MHz): tools/rt_trace.py. */
+int         gpirt_debug_rt_census(gpirt_handle_t h, unsigned int* host_out);
 /* Peak fp64 MFMA rate of this device measured by a back-to-back v_mfma_f64_16x16x4_f64 loop
  * (TFLOP/s); used to calibrate the roofline. */
 int         gpirt_calibrate_mfma_f64(gpirt_handle_t h, double* tflops);
