@@ -340,10 +340,16 @@ int potrf_runtime(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, in
         link.rows_per_group = RT_W;
         link.extra_row0 = rt->nid;
         link.ev_cnt = W + rt->off_ctl + 4;
-        // (Measured and not kept: the window's third row group as a launch of its own on a second stream, so that rows the
-        // pivot chain does not need yet cannot hold up the next chain launch -- 12.8 -> 9.0 ms at n = 8192, but work-groups
-        // are dealt to shader engines statically and only two compute units per engine are reserved: a third-group
-        // work-group dealt to an engine whose two are taken waits for chain work-groups that wait for it.  Guard expiry.)
+        // (A launch's last row group -- two dependent tile products behind the previous sub-panel -- ends after its diagonal
+        // rows, and the next launch cannot become resident before that.  Two ways around it were built and removed, both for
+        // the same reason -- a work-group that spins while it HOLDS a compute unit must never be resident before everything it
+        // waits for is: (i) that row group as a launch of its own on a second stream: work-groups are dealt to shader engines
+        // statically and only two compute units per engine are reserved, so one of its work-groups waited for chain
+        // work-groups that waited for it (guard expiry; 9.0 ms instead of 12.8 when it did not); (ii) first and second
+        // sub-panels on two alternating streams: the second sub-panel's work-groups took compute units the first one's last
+        // work-groups still needed and spun on them (guard expiry at n = 4096).  A third change that expired the guard and was
+        // taken back: the trailing updates of the rows the chain needs soonest moved to the front of their step in the bulk
+        // queue.)
         GP_TRY(launch_panel_ll(h, chain, A, ntot, lda, s.k0, s.k1, s.near_end, nullptr, &link));
         if ((sid & 1) && s.p == rt->P - 2) {
             if (!h->ev_prelast) GP_HIP(hipEventCreateWithFlags(&h->ev_prelast, hipEventDisableTiming));
