@@ -915,53 +915,59 @@ __global__ __launch_bounds__(256, 3) void update_worker_kernel(RtArgs a)
             int got = -1, gq = 0;
             for (;;) {
                 const unsigned long long ev0 = rt_ld(a.ctl + 4);
-                bool finished = true, moved = false;
+                bool finished = true;
                 if (rt_ld(a.ctl + 2) >= a.epoch) got = -2;
                 for (int q = 0; q < 2 && got == -1; ++q) {
                     const int nt = a.ntasks[q];
                     const int h = __builtin_amdgcn_readfirstlane((int)rt_ld(a.head + q));
                     if (h >= nt) continue;
                     finished = false;
-                    const int i = h + lane;
-                    int st = 1;
-                    bool rdy = false;
-                    if (i < nt) {
-                        st = __hip_atomic_load(a.state[q] + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (st == 0) rdy = rt_ready(a, a.tasks[q][i]);
-                    }
-                    const unsigned long long claimed = __ballot(i < nt && st != 0);
-                    const int lead = (~claimed == 0ull) ? 64 : (__ffsll((unsigned long long)~claimed) - 1);
-                    if (lane == 0 && lead > 0) {
-                        unsigned long long expect = (unsigned long long)h;
-                        __hip_atomic_compare_exchange_strong(a.head + q, &expect, (unsigned long long)(h + lead), __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                             __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    // Claim ONE of the ready entries, starting from a different one per worker: with every worker going for the
-                    // first, 500 of them lost the same compare-and-swap 60 times in a row (64 claims per ~100 us, chip-wide).
-                    const unsigned long long m = __ballot(rdy);
-                    const int nrdy = __popcll(m);
-                    if (nrdy > 0) {
-                        unsigned long long mm = m;
-                        const int skip = (int)(((unsigned)blockIdx.x * 40503u + (unsigned)ev0 * 7u) % (unsigned)nrdy);
-                        for (int s2 = 0; s2 < skip; ++s2) mm &= mm - 1;
-                        for (int tries = 0; tries < nrdy; ++tries) {
-                            if (!mm) mm = m;
-                            const int l = __ffsll(mm) - 1;
-                            mm &= mm - 1;
-                            int ok = 0;
-                            if (lane == l) {
-                                int expect = 0;
-                                ok = __hip_atomic_compare_exchange_strong(a.state[q] + i, &expect, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+                    // 64 entries at a time from the head on, UNTIL a ready one turns up or the queue ends: entries that wait for
+                    // work of the other queue may sit in front of ready ones for a while (the head cannot pass an unclaimed
+                    // entry), and a look-ahead of one window let eight such entries wall off the rest of the urgent queue
+                    // while what they waited for sat behind 400 not-yet-ready entries of the bulk queue (guard expiry).
+                    for (int base = h; base < nt && got == -1; base += 64) {
+                        const int i = base + lane;
+                        int st = 1;
+                        bool rdy = false;
+                        if (i < nt) {
+                            st = __hip_atomic_load(a.state[q] + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (st == 0) rdy = rt_ready(a, a.tasks[q][i]);
+                        }
+                        if (base == h) {
+                            const unsigned long long claimed = __ballot(i < nt && st != 0);
+                            const int lead = (~claimed == 0ull) ? 64 : (__ffsll((unsigned long long)~claimed) - 1);
+                            if (lane == 0 && lead > 0) {
+                                unsigned long long expect = (unsigned long long)h;
+                                __hip_atomic_compare_exchange_strong(a.head + q, &expect, (unsigned long long)(h + lead), __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                     __HIP_MEMORY_SCOPE_AGENT);
                             }
-                            ok = __shfl(ok, l);
-                            if (ok) { got = h + l; gq = q; break; }
+                        }
+                        // Claim ONE of the ready entries, starting from a different one per worker: with every worker going for
+                        // the first, 500 of them lost the same compare-and-swap 60 times in a row (64 claims per ~100 us).
+                        const unsigned long long m = __ballot(rdy);
+                        const int nrdy = __popcll(m);
+                        if (nrdy > 0) {
+                            unsigned long long mm = m;
+                            const int skip = (int)(((unsigned)blockIdx.x * 40503u + (unsigned)ev0 * 7u) % (unsigned)nrdy);
+                            for (int s2 = 0; s2 < skip; ++s2) mm &= mm - 1;
+                            for (int tries = 0; tries < nrdy; ++tries) {
+                                if (!mm) mm = m;
+                                const int l = __ffsll(mm) - 1;
+                                mm &= mm - 1;
+                                int ok = 0;
+                                if (lane == l) {
+                                    int expect = 0;
+                                    ok = __hip_atomic_compare_exchange_strong(a.state[q] + i, &expect, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+                                }
+                                ok = __shfl(ok, l);
+                                if (ok) { got = base + l; gq = q; break; }
+                            }
                         }
                     }
-                    if (lead > 0) moved = true;
                 }
                 if (got == -1 && finished) got = -2;
                 if (got != -1) break;
-                if (moved) continue;                       // a head moved: the entries behind it have not been looked at yet
                 // nothing ready (and a head that just moved is looked at again at once)
                 int spins = 0, expired = 0;
                 if (lane == 0) {

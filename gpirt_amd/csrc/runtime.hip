@@ -156,11 +156,15 @@ int build(gpirt_handle_t h, RtState* rt, int64_t n, int64_t nr)
                     q[0].push_back(e);
                 } else if (u[k].cls == 4) {
                     const int step = r - 2;
-                    // (the rows the chain needs soonest first: their later updates are in the urgent queue and wait for these)
-                    e.k[0] = step; e.k[1] = (u[k].kb / RT_GB < r - 2) ? 0 : 3; e.k[2] = (gi <= r + RT_WINDOW_GROUPS) ? 0 : 1; e.k[3] = u[k].kb; e.k[4] = bi; e.k[5] = bj;
+                    // The rows the chain needs soonest -- the next-but-one outer panel's own rows and the group below, whose later
+                    // updates sit in the urgent queue and wait for these -- go first in their step, ahead of the far rows of the
+                    // step's other products; the rest of the block column behind those (its operands' far rows come from them).
+                    const bool soon = gi <= r + 1;
+                    const bool early = u[k].kb / RT_GB < r - 2;
+                    e.k[0] = step; e.k[1] = soon ? (early ? 0 : 1) : (early ? 4 : 5); e.k[2] = u[k].kb; e.k[3] = bi; e.k[4] = bj;
                     q[1].push_back(e);
                 } else {
-                    e.k[0] = pk; e.k[1] = (sk & 1) ? 2 : 1; e.k[2] = gi; e.k[3] = 1; e.k[4] = u[k].cls; e.k[5] = bi; e.k[6] = bj;
+                    e.k[0] = pk; e.k[1] = (sk & 1) ? 3 : 2; e.k[2] = gi; e.k[3] = 1; e.k[4] = u[k].cls; e.k[5] = bi; e.k[6] = bj;
                     q[1].push_back(e);
                 }
             }
@@ -188,7 +192,7 @@ int build(gpirt_handle_t h, RtState* rt, int64_t n, int64_t nr)
                     e.k[0] = sid; e.k[1] = 1; e.k[2] = 0; e.k[3] = bi; e.k[4] = jb;
                     q[0].push_back(e);
                 } else {
-                    e.k[0] = s.p; e.k[1] = (sid & 1) ? 2 : 1; e.k[2] = gi; e.k[3] = 0; e.k[4] = 0; e.k[5] = bi; e.k[6] = jb;
+                    e.k[0] = s.p; e.k[1] = (sid & 1) ? 3 : 2; e.k[2] = gi; e.k[3] = 0; e.k[4] = 0; e.k[5] = bi; e.k[6] = jb;
                     q[1].push_back(e);
                 }
             }
@@ -347,9 +351,7 @@ int potrf_runtime(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, in
         // statically and only two compute units per engine are reserved, so one of its work-groups waited for chain
         // work-groups that waited for it (guard expiry; 9.0 ms instead of 12.8 when it did not); (ii) first and second
         // sub-panels on two alternating streams: the second sub-panel's work-groups took compute units the first one's last
-        // work-groups still needed and spun on them (guard expiry at n = 4096).  A third change that expired the guard and was
-        // taken back: the trailing updates of the rows the chain needs soonest moved to the front of their step in the bulk
-        // queue.)
+        // work-groups still needed and spun on them (guard expiry at n = 4096).)
         GP_TRY(launch_panel_ll(h, chain, A, ntot, lda, s.k0, s.k1, s.near_end, nullptr, &link));
         if ((sid & 1) && s.p == rt->P - 2) {
             if (!h->ev_prelast) GP_HIP(hipEventCreateWithFlags(&h->ev_prelast, hipEventDisableTiming));
