@@ -62,6 +62,7 @@ SIGNATURES = {
     "gpirt_debug_trip_guard": (_i32, [_vp, _i32]),
     "gpirt_debug_last_mcmc_fallbacks": (_i32, []),
     "gpirt_debug_rt_census": (_i32, [_vp, _vp]),
+    "gpirt_debug_rt_tasks": (_i32, [_vp, _vp, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "gpirt_se_kernel": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _dbl]),
     "gpirt_potrf_lower": (_i32, [_vp, _vp, _i64, _i64]),
     "gpirt_factor": (_i32, [_vp, _vp, _i64, _vp, _i64]),

@@ -398,6 +398,12 @@ int gpirt_debug_rt_census(gpirt_handle_t h, unsigned int* host_out)
     return 0;
 }
 
+int gpirt_debug_rt_tasks(gpirt_handle_t h, void* host_out, int max_tasks, int* n_urgent, int* n_bulk)
+{
+    GP_ARG(h && host_out && n_urgent && n_bulk && max_tasks >= 0);
+    return potrf_runtime_tasks(h, reinterpret_cast<RtTask*>(host_out), max_tasks, n_urgent, n_bulk);
+}
+
 int gpirt_guard_fallbacks(gpirt_handle_t h, int* count)
 {
     GP_ARG(h && count);

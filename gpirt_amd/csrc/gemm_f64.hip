@@ -917,29 +917,31 @@ __global__ __launch_bounds__(256, 3) void update_worker_kernel(RtArgs a)
                 const unsigned long long ev0 = rt_ld(a.ctl + 4);
                 bool finished = true;
                 if (rt_ld(a.ctl + 2) >= a.epoch) got = -2;
-                for (int q = 0; q < 2 && got == -1; ++q) {
-                    const int nt = a.ntasks[q];
-                    const int h = __builtin_amdgcn_readfirstlane((int)rt_ld(a.head + q));
-                    if (h >= nt) continue;
+                // one range of a queue: 64 entries at a time from its head on, until a ready one turns up, the range ends or
+                // `max_chunks` have been looked at.  (Entries that wait for work of another queue may sit in front of ready
+                // ones for a while -- the head cannot pass an unclaimed entry -- and with a look-ahead of ONE window eight such
+                // entries walled off the rest of the urgent queue: guard expiry.  So a search that found nothing anywhere is
+                // repeated without the limit before the worker naps.)
+                auto scan = [&](const int q, unsigned long long* hp, const int begin, const int end, const int max_chunks) {
+                    const unsigned long long hraw = rt_ld(hp);
+                    const int h = __builtin_amdgcn_readfirstlane((int)hraw < begin ? begin : (int)hraw);
+                    if (h >= end) return;
                     finished = false;
-                    // 64 entries at a time from the head on, UNTIL a ready one turns up or the queue ends: entries that wait for
-                    // work of the other queue may sit in front of ready ones for a while (the head cannot pass an unclaimed
-                    // entry), and a look-ahead of one window let eight such entries wall off the rest of the urgent queue
-                    // while what they waited for sat behind 400 not-yet-ready entries of the bulk queue (guard expiry).
-                    for (int base = h; base < nt && got == -1; base += 64) {
+                    int chunks = 0;
+                    for (int base = h; base < end && got == -1 && chunks < max_chunks; base += 64, ++chunks) {
                         const int i = base + lane;
                         int st = 1;
                         bool rdy = false;
-                        if (i < nt) {
+                        if (i < end) {
                             st = __hip_atomic_load(a.state[q] + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if (st == 0) rdy = rt_ready(a, a.tasks[q][i]);
                         }
                         if (base == h) {
-                            const unsigned long long claimed = __ballot(i < nt && st != 0);
+                            const unsigned long long claimed = __ballot(i < end && st != 0);
                             const int lead = (~claimed == 0ull) ? 64 : (__ffsll((unsigned long long)~claimed) - 1);
                             if (lane == 0 && lead > 0) {
-                                unsigned long long expect = (unsigned long long)h;
-                                __hip_atomic_compare_exchange_strong(a.head + q, &expect, (unsigned long long)(h + lead), __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                unsigned long long expect = hraw;
+                                __hip_atomic_compare_exchange_strong(hp, &expect, (unsigned long long)(h + lead), __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                                      __HIP_MEMORY_SCOPE_AGENT);
                             }
                         }
@@ -965,10 +967,31 @@ __global__ __launch_bounds__(256, 3) void update_worker_kernel(RtArgs a)
                             }
                         }
                     }
-                }
+                };
+                if (got == -1) scan(0, a.head, 0, a.ntasks[0], 1 << 30);
+                // the bulk queue, segment by segment (the step that needs the tiles next): the front of a segment holds the
+                // entries whose operands exist, its end the ones that wait for sub-panels still to come
+                for (int d = 0; d < a.nseg && got == -1; ++d) scan(1, a.head + 1 + d, a.seg_begin[d], a.seg_begin[d + 1], 3);
                 if (got == -1 && finished) got = -2;
                 if (got != -1) break;
-                // nothing ready (and a head that just moved is looked at again at once)
+                // Nothing at the fronts.  While things are moving (the event count changes within ~30 us) look at the fronts
+                // again; only when the chip has gone quiet is every entry of every segment looked at -- that search is what
+                // guarantees progress (a ready entry may sit anywhere behind blocked ones), but it walks ~500 windows, and
+                // taken whenever the fronts were empty it cost every worker a millisecond at a time.
+                int quiet = 0;
+                if (lane == 0) {
+                    int spins = 0;
+                    while (rt_ld(a.ctl + 4) == ev0 && rt_ld(a.ctl + 2) < a.epoch && ++spins < 8) __builtin_amdgcn_s_sleep(127);
+                    quiet = (rt_ld(a.ctl + 4) == ev0) ? 1 : 0;
+                }
+                if (!__shfl(quiet, 0)) continue;
+                finished = true;
+                if (rt_ld(a.ctl + 2) >= a.epoch) got = -2;
+                if (got == -1) scan(0, a.head, 0, a.ntasks[0], 1 << 30);
+                for (int d = 0; d < a.nseg && got == -1; ++d) scan(1, a.head + 1 + d, a.seg_begin[d], a.seg_begin[d + 1], 1 << 30);
+                if (got == -1 && finished) got = -2;
+                if (got != -1) break;
+                // nothing ready anywhere: nap until something is published
                 int spins = 0, expired = 0;
                 if (lane == 0) {
                     while (rt_ld(a.ctl + 4) == ev0 && rt_ld(a.ctl + 2) < a.epoch && ++spins < RT_IDLE_LIMIT) __builtin_amdgcn_s_sleep(127);

@@ -88,7 +88,8 @@ struct RtArgs {
     double* A; int64_t lda; int M, N;
     const RtTask* tasks[2]; int ntasks[2];        // queue 0: what the pivot chain waits for next; queue 1: everything else
     int* state[2];                                // 0 = free, 1 = claimed
-    unsigned long long* head;                     // [2]
+    unsigned long long* head;                     // [0] urgent queue; [1 + d] bulk segment d: entries claimed from the segment's start
+    int nseg; int seg_begin[40];                  // bulk queue = nseg segments [seg_begin[d], seg_begin[d + 1])
     unsigned long long* cnt;                      // DONE (+= 1 per finished row block: panel kernels, type-1 tasks) | IN (+= 1 per
                                                   //   finished tile: type-0 tasks; panel kernels and type-1 tasks wait on it)
     unsigned long long* prog;
@@ -111,6 +112,7 @@ bool potrf_runtime_usable(gpirt_handle_t h, int64_t n, int64_t nr);
 int64_t potrf_runtime_scratch_row0(int64_t nr);     // first of the potrf_runtime_scratch_rows() identity rows a caller must provide
 int64_t potrf_runtime_scratch_rows();
 void potrf_runtime_reset(gpirt_handle_t h);
+int potrf_runtime_tasks(gpirt_handle_t h, RtTask* host_out, int max_tasks, int* n0, int* n1);
 void potrf_runtime_destroy(gpirt_handle_t h);
 int launch_panel_ll(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t K0, int64_t c1,
                     int64_t row_end = 0, unsigned long long* epoch_out = nullptr, const PanelLink* link = nullptr);

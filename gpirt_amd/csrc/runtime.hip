@@ -39,7 +39,9 @@ namespace {
 
 constexpr int RT_W = 1024, RT_H = 512;     // outer panel / sub-panel width this schedule is built for (the defaults)
 constexpr int RT_GB = RT_W / 64;           // row blocks per row group
-constexpr int RT_WINDOW_GROUPS = 3;        // row groups a sub-panel kernel sweeps (own outer panel + the next two)
+constexpr int RT_WINDOW_GROUPS = 2;        // row groups a sub-panel kernel sweeps: its own outer panel and the next (with three, the third
+                                           // group -- whose input comes two dependent tile products late -- kept every first sub-panel kernel
+                                           // alive 0.6-1.3 ms after its diagonal rows were done, and the next launch waits for the kernel to END)
 constexpr int RT_RESERVED = 64;            // compute units kept free for the sub-panel kernels (48 window + 8 identity row blocks): a multiple
                                            // of 32 -- work-groups are dealt round-robin to 8 XCCs x 4 shader engines, and only with 2 holders on
                                            // EVERY engine do 18 workers and 2 panel work-groups per engine always find their place (census: tools/rt_trace.py)
@@ -62,6 +64,8 @@ struct RtState {
     unsigned long long epoch = 0;
     int nworkers = 0, reserved = 0;
     double flops = 0.0;
+    int nseg = 0;                          // segments of the bulk queue (one per step that needs the tiles next)
+    std::vector<int> seg_begin;            // [nseg + 1]
     hipEvent_t ev_done = nullptr;
 };
 
@@ -76,7 +80,7 @@ __global__ void identity_rows_kernel(double* A, int64_t lda, int64_t row0, int64
 __global__ void fill_words_kernel(unsigned long long* p, unsigned long long v) { *p = v; }
 
 struct Unit { int kb, klen, cls; int sidK; };          // cls: 0 a, 1 b1, 2 b2, 3 c, 4 D
-struct Keyed { long long k[7]; RtTask t; };
+struct Keyed { long long k[7]; RtTask t; int queue; int prev; double est, dur; };
 
 int build(gpirt_handle_t h, RtState* rt, int64_t n, int64_t nr)
 {
@@ -107,7 +111,7 @@ int build(gpirt_handle_t h, RtState* rt, int64_t n, int64_t nr)
     };
     rt->in_need.assign((size_t)NS * NG, 0u);
     const int ntiles = nbr * (nbr + 1) / 2;
-    std::vector<Keyed> q[2];
+    std::vector<Keyed> q[2], all;
     double flops = 0.0;
     // ---- the products: per tile the units of potrf.hip's schedule, in its order
     for (int bj = 0; bj < ncb; ++bj) {
@@ -129,8 +133,11 @@ int build(gpirt_handle_t h, RtState* rt, int64_t n, int64_t nr)
             if (nu == 0) continue;
             const int gi = grp(bi);
             rt->in_need[(size_t)sid_c * NG + gi] += 1;
+            int prev_unit = -1;
             for (int k = 0; k < nu; ++k) {
                 Keyed e{};
+                e.prev = prev_unit; e.dur = 8.0 + 6.5 * u[k].klen;
+                prev_unit = (int)all.size();
                 RtTask& t = e.t;
                 t.bi = (uint16_t)bi; t.bj = (uint16_t)bj; t.kb = (uint16_t)u[k].kb; t.klen = (uint16_t)u[k].klen;
                 t.type = 0;
@@ -153,19 +160,20 @@ int build(gpirt_handle_t h, RtState* rt, int64_t n, int64_t nr)
                     // window, then the tiles that read those rows; what gates the next sub-panel kernel (a, b2) before the rest
                     const bool far_rows = gi > pk + RT_WINDOW_GROUPS - 1;
                     e.k[0] = sk; e.k[1] = far_rows ? 2 : 0; e.k[2] = (u[k].cls == 0 || u[k].cls == 2) ? 0 : 1; e.k[3] = gi; e.k[4] = bi; e.k[5] = bj;
-                    q[0].push_back(e);
-                } else if (u[k].cls == 4) {
-                    const int step = r - 2;
-                    // The rows the chain needs soonest -- the next-but-one outer panel's own rows and the group below, whose later
-                    // updates sit in the urgent queue and wait for these -- go first in their step, ahead of the far rows of the
-                    // step's other products; the rest of the block column behind those (its operands' far rows come from them).
-                    const bool soon = gi <= r + 1;
-                    const bool early = u[k].kb / RT_GB < r - 2;
-                    e.k[0] = step; e.k[1] = soon ? (early ? 0 : 1) : (early ? 4 : 5); e.k[2] = u[k].kb; e.k[3] = bi; e.k[4] = bj;
-                    q[1].push_back(e);
+                    e.queue = 0; all.push_back(e);
                 } else {
-                    e.k[0] = pk; e.k[1] = (sk & 1) ? 3 : 2; e.k[2] = gi; e.k[3] = 1; e.k[4] = u[k].cls; e.k[5] = bi; e.k[6] = bj;
-                    q[1].push_back(e);
+                    // The bulk queue, by DEADLINE.  What panel pk contributes to the rows of group g ("stage (pk, g)": X = A W^T
+                    // for its first sub-panel, the a / b1 tiles, X = A W^T for the second, b2 / c, then its trailing updates of
+                    // the later block columns) can only start when stage (pk - 1, g) is through, and stage (g - 2, g) is the
+                    // urgent one the next chain launch waits for -- a pipeline along every row group.  Ordered by step first
+                    // (every far row of panel p before anything of panel p + 1) the second far group of a panel came ~1 ms after
+                    // its sub-panels, and with it the FIRST far group of the next panel, which the chain does wait for.  So:
+                    // by the step that needs the tile next, then by row group (nearest first), then by panel, then in the
+                    // order of a stage.
+                    const int need_step = (u[k].cls == 4) ? r - 1 : (u[k].cls == 0 ? pk : pk + 1);
+                    const int in_stage = (u[k].cls == 4) ? 4 : ((sk & 1) ? 3 : 1);
+                    e.k[0] = need_step; e.k[1] = pk; e.k[2] = gi; e.k[3] = in_stage; e.k[4] = bi; e.k[5] = bj; e.k[6] = u[k].kb;
+                    e.queue = 1; all.push_back(e);
                 }
             }
         }
@@ -188,21 +196,37 @@ int build(gpirt_handle_t h, RtState* rt, int64_t n, int64_t nr)
                 t.tile = ntiles; t.prog_need = 0;
                 t.last = (uint8_t)wb; t.out_idx = cnt_done(sid, gi);
                 flops += 2.0 * 64 * 64 * 64.0 * (jb + 1);
+                e.prev = -1; e.dur = 14.0 + 6.5 * (jb + 1);
                 if (gi == s.p + RT_WINDOW_GROUPS) {
                     e.k[0] = sid; e.k[1] = 1; e.k[2] = 0; e.k[3] = bi; e.k[4] = jb;
-                    q[0].push_back(e);
+                    e.queue = 0; all.push_back(e);
                 } else {
-                    e.k[0] = s.p; e.k[1] = (sid & 1) ? 3 : 2; e.k[2] = gi; e.k[3] = 0; e.k[4] = 0; e.k[5] = bi; e.k[6] = jb;
-                    q[1].push_back(e);
+                    e.k[0] = s.p; e.k[1] = s.p; e.k[2] = gi; e.k[3] = (sid & 1) ? 2 : 0; e.k[4] = bi; e.k[5] = jb; e.k[6] = 0;
+                    e.queue = 1; all.push_back(e);
                 }
             }
         }
     }
+    // ---- order of the queues.  Urgent: the order the pivot chain releases and needs its tiles.  Bulk: by the step that
+    // needs the tile next, and within a step by operand panel -- so that in every step's SEGMENT of the queue the entries
+    // whose operands exist come first and the ones that wait for sub-panels still to be factored sit together at its end.
+    // A worker looks at the front of each segment in turn (gemm_f64.hip): scanning one queue in deadline order from its head,
+    // a dequeue walked over thousands of blocked entries (~85 us on average, half of every worker's time).
+    // (Measured and not kept: both queues sorted by the earliest start a host-side run of the dataflow gives each task --
+    // short scans, but every trailing update that CAN run early then DOES, in front of what the chain needs: 9.7 -> 10.4 ms.)
+    for (auto& e : all) q[e.queue].push_back(e);
     for (int z = 0; z < 2; ++z)
         std::stable_sort(q[z].begin(), q[z].end(), [](const Keyed& a, const Keyed& b) {
             for (int i = 0; i < 7; ++i) if (a.k[i] != b.k[i]) return a.k[i] < b.k[i];
             return false;
         });
+    rt->nseg = P + 1;
+    rt->seg_begin.assign((size_t)rt->nseg + 1, (int)q[1].size());
+    for (int i = (int)q[1].size() - 1; i >= 0; --i) {
+        const int d = (int)std::min<long long>(std::max<long long>(q[1][(size_t)i].k[0], 0), P);
+        rt->seg_begin[(size_t)d] = i;
+    }
+    for (int d = rt->nseg - 1; d >= 0; --d) rt->seg_begin[(size_t)d] = std::min(rt->seg_begin[(size_t)d], rt->seg_begin[(size_t)d + 1]);
     rt->flops = flops;
     // ---- device copies
     rt->ntasks[0] = (int)q[0].size(); rt->ntasks[1] = (int)q[1].size();
@@ -215,7 +239,7 @@ int build(gpirt_handle_t h, RtState* rt, int64_t n, int64_t nr)
     rt->off_prog = (size_t)2 * NS * NG;
     rt->off_strip = rt->off_prog + (size_t)ntiles + 1;
     rt->off_head = rt->off_strip + 2 * 4096;
-    rt->off_ctl = rt->off_head + 2;
+    rt->off_ctl = rt->off_head + 64;                       // heads: [0] urgent queue, [1 + d] segment d of the bulk queue
     rt->words = rt->off_ctl + 8;
     GP_HIP(hipMalloc(&rt->d_words, rt->words * sizeof(unsigned long long)));
     GP_HIP(hipMalloc(&rt->d_in_need, (size_t)NS * NG * sizeof(unsigned int)));
@@ -259,6 +283,16 @@ bool potrf_runtime_usable(gpirt_handle_t h, int64_t n, int64_t nr)
            (n % 64) == 0 && n > 2 * RT_W && nr >= n && h->n_cu > RT_RESERVED + 64 && nr / 64 < 4000;
 }
 
+// debug: the task lists as the update workers see them (urgent queue first); returns the number copied
+int potrf_runtime_tasks(gpirt_handle_t h, RtTask* host_out, int max_tasks, int* n0, int* n1)
+{
+    if (!h->rt) { *n0 = *n1 = 0; return 0; }
+    *n0 = h->rt->ntasks[0]; *n1 = h->rt->ntasks[1];
+    const int nt = std::min(max_tasks, *n0 + *n1);
+    GP_HIP(hipMemcpy(host_out, h->rt->d_tasks, (size_t)nt * sizeof(RtTask), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 void potrf_runtime_destroy(gpirt_handle_t h)
 {
     destroy(h->rt);
@@ -294,7 +328,7 @@ int potrf_runtime(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, in
     unsigned long long* W = rt->d_words;
     const size_t nt = (size_t)rt->ntasks[0] + (size_t)rt->ntasks[1];
     // per-factorisation words: queue heads and claim flags start at zero (the counters run on, scaled by the epoch)
-    GP_HIP(hipMemsetAsync(W + rt->off_head, 0, 2 * sizeof(unsigned long long), stream));
+    GP_HIP(hipMemsetAsync(W + rt->off_head, 0, 64 * sizeof(unsigned long long), stream));
     GP_HIP(hipMemsetAsync(W + rt->off_ctl, 0, sizeof(unsigned long long), stream));               // workers arrived
     GP_HIP(hipMemsetAsync(W + rt->off_ctl + 3, 0, sizeof(unsigned long long), stream));           // holders arrived
     GP_HIP(hipMemsetAsync(rt->d_state, 0, nt * sizeof(int), stream));
@@ -312,6 +346,8 @@ int potrf_runtime(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, in
     a.ntasks[0] = rt->ntasks[0]; a.ntasks[1] = rt->ntasks[1];
     a.state[0] = rt->d_state; a.state[1] = rt->d_state + rt->ntasks[0];
     a.head = W + rt->off_head;
+    a.nseg = rt->nseg;
+    for (int d = 0; d <= rt->nseg && d < 40; ++d) a.seg_begin[d] = rt->seg_begin[(size_t)d];
     a.cnt = W; a.prog = W + rt->off_prog; a.strip = W + rt->off_strip;
     a.stage = rt->d_stage; a.ld_stage = rt->nid; a.wt_row0 = rt->nid;
     a.epoch = E; a.prog_base = E * 64ull;

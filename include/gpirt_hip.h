@@ -90,6 +90,8 @@ int         gpirt_debug_last_mcmc_fallbacks(void);
  * otherwise copies out [2][4096][4] words {HW_ID, XCC_ID, arrival index, stayed} (update workers, then CU holders), then
  * [4096][8] 64-bit per-worker counters and [65536][2] 64-bit task start / end stamps (100 MHz): tools/rt_trace.py. */
 int         gpirt_debug_rt_census(gpirt_handle_t h, unsigned int* host_out);
+/* ... and the task lists the update workers work off (32-byte records: csrc/kernels.h RtTask), urgent queue first. */
+int         gpirt_debug_rt_tasks(gpirt_handle_t h, void* host_out, int max_tasks, int* n_urgent, int* n_bulk);
 /* Peak fp64 MFMA rate of this device measured by a back-to-back v_mfma_f64_16x16x4_f64 loop
  * (TFLOP/s); used to calibrate the roofline. */
 int         gpirt_calibrate_mfma_f64(gpirt_handle_t h, double* tflops);

@@ -38,7 +38,7 @@ def test_runtime_factor_equals_launch_ordered_factor(n, reps):
     b, fb = _factor(n, 2, reps)
     assert fb == 0, "the dependency-driven factorisation fell back to the launch-per-step panel"
     assert np.isfinite(b).all()
-    win = min(n, 3072)                                   # rows every sub-panel's own window covers from panel 0 on
+    win = min(n, 2048)                                   # rows every sub-panel kernel sweeps itself from panel 0 on
     assert np.array_equal(np.tril(a[:win, :]), np.tril(b[:win, :]))
     assert np.abs(np.tril(a[:n]) - np.tril(b[:n])).max() <= 1e-12
     assert np.abs(a[n:] - b[n:]).max() <= 1e-11         # the rows of the bordered layout: (L^-1 K(theta, c))^T, entries up to ~30

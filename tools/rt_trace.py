@@ -50,6 +50,45 @@ if ok.any():
         if sel.any():
             print(f"  tasks {lo:6d}..: start {((tt[sel, 0].min() - t0t) / 100.0):8.0f} .. {((tt[sel, 0].max() - t0t) / 100.0):8.0f}  mean dur {((tt[sel, 1] - tt[sel, 0]).mean() / 100.0):6.1f} us")
 st = st[(st[:, 3] > 0) & (st[:, 3] < 10**12)]
+# ---- the path behind one outer panel: when were the tile tasks of each kind, by row group, started / finished?
+P_SHOW = int(os.environ.get("PANEL", "2"))
+tdt = np.dtype([("bi", "<u2"), ("bj", "<u2"), ("kb", "<u2"), ("klen", "<u2"), ("dep0", "<i4"), ("dep1", "<i4"), ("need0", "<u4"), ("need1", "<u4"),
+                ("tile", "<i4"), ("prog", "<u2"), ("last", "u1"), ("type", "u1"), ("out", "<i4")])
+tasks = np.zeros(65536, dtype=tdt)
+n0, n1 = C.c_int(), C.c_int()
+check(h.lib.gpirt_debug_rt_tasks(h._h, C.c_void_p(tasks.ctypes.data), 65536, C.byref(n0), C.byref(n1)))
+nt = min(65536, n0.value + n1.value)
+ok2 = (tt[:nt, 0] > 0) & (tt[:nt, 1] > 0) & (tt[:nt, 0] < 2**62)
+if ok2.any():
+    T0 = tt[:nt][ok2, 0].min()
+    tk = tasks[:nt]
+    gi = tk["bi"] // 16
+    queue = np.where(np.arange(nt) < n0.value, 0, 1)
+    def show(name, sel):
+        sel = sel & ok2
+        if sel.any():
+            print(f"  {name:34s} n {int(sel.sum()):5d}  queue {sorted(set(queue[sel].tolist()))}  start {((tt[:nt][sel, 0].min() - T0) / 100.0):8.0f} .. end {((tt[:nt][sel, 1].max() - T0) / 100.0):8.0f}")
+    p = P_SHOW
+    print(f"tasks around outer panel {p} (us since the first task started):")
+    for g in range(p, p + 5):
+        show(f"X = A W^T, A({p}), rows g{g}", (tk["type"] == 1) & (tk["kb"] == 16 * p) & (gi == g))
+        show(f"a({p}): K = A({p}), rows g{g}", (tk["type"] == 0) & (tk["kb"] == 16 * p) & (tk["klen"] == 8) & (tk["bj"] // 16 == p) & (gi == g))
+        show(f"b1({p}): K = A({p}) -> col {p + 1}, rows g{g}", (tk["type"] == 0) & (tk["kb"] == 16 * p) & (tk["klen"] == 8) & (tk["bj"] // 16 == p + 1) & (gi == g))
+        show(f"X = A W^T, B({p}), rows g{g}", (tk["type"] == 1) & (tk["kb"] == 16 * p + 8) & (gi == g))
+        show(f"b2({p}): K = B({p}) -> col {p + 1}, rows g{g}", (tk["type"] == 0) & (tk["kb"] == 16 * p + 8) & (tk["klen"] == 8) & (gi == g))
+        show(f"c({p}): K = panel {p} -> col {p + 1}, rows g{g}", (tk["type"] == 0) & (tk["kb"] == 16 * p) & (tk["klen"] == 16) & (tk["bj"] // 16 == p + 1) & (gi == g))
+        show(f"D({p}) -> col {p + 2}, rows g{g}", (tk["type"] == 0) & (tk["kb"] == 16 * p) & (tk["klen"] == 16) & (tk["bj"] // 16 == p + 2) & (gi == g))
+    # ---- the path of ONE row group through every outer panel (ROWS=g): the chain of stages that feeds the sub-panel kernels
+    G = int(os.environ.get("ROWS", "-1"))
+    if G >= 0:
+        print(f"row group g{G} through the panels (us since the first task started):")
+        for p in range(0, G + 1):
+            show(f"X = A W^T, A({p})", (tk["type"] == 1) & (tk["kb"] == 16 * p) & (gi == G))
+            show(f"a({p})", (tk["type"] == 0) & (tk["kb"] == 16 * p) & (tk["klen"] == 8) & (tk["bj"] // 16 == p) & (gi == G))
+            show(f"X = A W^T, B({p})", (tk["type"] == 1) & (tk["kb"] == 16 * p + 8) & (gi == G))
+            for c in range(p + 1, G + 1):
+                show(f"   panel {p} -> col {c}: K = 512 halves", (tk["type"] == 0) & (tk["kb"] // 16 == p) & (tk["klen"] == 8) & (tk["bj"] // 16 == c) & (gi == G))
+                show(f"   panel {p} -> col {c}: K = 1024", (tk["type"] == 0) & (tk["kb"] == 16 * p) & (tk["klen"] == 16) & (tk["bj"] // 16 == c) & (gi == G))
 if len(st):
     us = lambda x: x / 100.0
     print(f"worker stats ({len(st)} workers): tasks per worker mean {st[:,0].mean():.1f} (urgent {st[:,4].mean():.1f}); per worker: in tasks {us(st[:,1].mean()):.0f} us, "
