@@ -743,16 +743,18 @@ int gpirt_rstream_from_state(gpirt_rstream_t* out, const uint32_t mt[624], int m
 int gpirt_rstream_get_state(gpirt_rstream_t r, uint32_t mt[624], int* mti)
 {
     GP_ARG(r && mt && mti);
+    rstream_sync(r);                 // a sampler replaying this stream runs ahead of the chain: back to the consumed position
     memcpy(mt, r->r.mt, sizeof(r->r.mt));
     *mti = r->r.mti;
     return 0;
 }
 
-int gpirt_rstream_destroy(gpirt_rstream_t r) { delete r; return 0; }
+int gpirt_rstream_destroy(gpirt_rstream_t r) { rstream_sync(r, true); delete r; return 0; }
 
 int gpirt_rstream_unif(gpirt_rstream_t r, double* h_out, int64_t n)
 {
     GP_ARG(r && (h_out || n == 0) && n >= 0);
+    rstream_sync(r);
     for (int64_t i = 0; i < n; ++i) h_out[i] = r->r.unif();
     return 0;
 }
@@ -760,6 +762,7 @@ int gpirt_rstream_unif(gpirt_rstream_t r, double* h_out, int64_t n)
 int gpirt_rstream_norm(gpirt_rstream_t r, double* h_out, int64_t n)
 {
     GP_ARG(r && (h_out || n == 0) && n >= 0);
+    rstream_sync(r);
     for (int64_t i = 0; i < n; ++i) h_out[i] = r->r.norm();
     return 0;
 }

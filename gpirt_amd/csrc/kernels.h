@@ -149,6 +149,36 @@ struct EssArgs {
     int ll_exact;         // 1: log(1 + exp(-a)) through the library's exp and log, as written (GPIRT_LL_EXACT)
 };
 int launch_ess(hipStream_t stream, const EssArgs& a);
+// R-stream replay, speculative form (sampler.hip, do_draw_f): item j's nu = L z is taken from RS_CAND candidate vectors
+// that were computed while item j - 1's slice loop was still running -- one per possible length of that loop.
+constexpr int RS_CAND = 32;          // candidates per item: rejection counts 0 .. 31 of the item before
+constexpr int RS_KC = 1024;          // columns of L per part of a candidate product
+constexpr int RS_ROWS = 32;          // rows of L per work-group of a candidate product
+constexpr int RS_SPEC_MIN_N = 64;    // below: item by item, four launches each
+constexpr int RS_ESS_WGS = 8;        // work-groups (of 256 threads, 1024 rows each) one item's slice loop is spread over
+struct RsSpecArgs {
+    const double* U; uint64_t cap;   // the window of stream uniforms
+    uint64_t* pos;                   // the cursor (start of the next unconsumed uniform)
+    uint64_t* posv;                  // [m + 1]: where item j's normals start
+    int* k_out;                      // [m]: rejection counts
+    int* miss;                       // != 0: item (miss - 1) found no candidate; every later kernel of the pass leaves at once
+    int* err;
+    int64_t n, ldl;
+    const double* L;
+    // slice sampler of item `ess_item` (< 0: none) on the candidate its predecessor's count picks (ess_first: candidate 0),
+    // spread over the first ess_wgs work-groups of the grid (<= RS_ESS_WGS): they meet once per likelihood pass through
+    // ess_cnt[ess_item] (zero when the pass over the items starts) and ess_partial[2][RS_ESS_WGS]
+    int ess_item, ess_first, ess_wgs;
+    unsigned long long* ess_cnt; double* ess_partial;
+    double* ess_part;                // [parts][RS_CAND][n] parts of that item's candidate products
+    double* f; const double* y; const double* mu;
+    // candidates of item `cand_item` (< 0: none): normals (rs_cand_normals) and products (the other work-groups of rs_item)
+    int cand_item, cand_first;       // cand_first: the item has no predecessor in this pass, its normals start at the cursor
+    double* cand_zc;                 // [n + 4][RS_CAND] candidate normals (k-major)
+    double* cand_part;
+};
+int launch_rs_cand_normals(hipStream_t stream, const RsSpecArgs& a);
+int launch_rs_item(hipStream_t stream, const RsSpecArgs& a);      // ONE grid: work-group 0 = the slice sampler, the rest = the products
 int launch_ll_term_probe(hipStream_t stream, const double* a, int64_t n, double* out, bool fast);
 int launch_ll_bar(hipStream_t stream, const double* f, const double* y, const double* mu, int64_t n,
                   int64_t m, double* out);

@@ -146,6 +146,280 @@ __global__ __launch_bounds__(256) void ess_kernel(EssArgs a)
     }
 }
 
+// ---- R-stream replay, speculative form --------------------------------------------------------------------------------
+// Item j's normals start where item j - 1's slice loop stopped consuming, so nu_j = L z_j cannot be STARTED before that
+// loop ends -- but it has few possible values: z_j starts at  posv[j - 1] + 2n + 2 + k  for the rejection count k of item
+// j - 1, and a pass over L (268 MB at n = 8192: HBM-bound) costs the same for 32 right-hand sides as for one.  So ONE grid
+// per item runs item j's slice loop in its first work-groups and  L z  for the 32 candidates of item j + 1 in all the
+// others; the slice loop of item j + 1 then picks column k_j.  A count >= 32 raises `miss`: every later kernel of the
+// pass leaves at once and the host redoes that item the plain way (do_draw_f).  Two launches per item on one stream (the
+// candidate normals, then this grid) instead of four dependent ones; no events.
+__global__ __launch_bounds__(256) void rs_cand_normals_kernel(RsSpecArgs a)
+{
+    if (*(volatile int*)a.miss != 0) return;
+    const uint64_t base = a.cand_first ? *a.pos : a.posv[a.cand_item - 1] + 2ull * (uint64_t)a.n + 2ull;
+    if (a.cand_first && blockIdx.x == 0 && threadIdx.x == 0) a.posv[a.cand_item] = base;
+    const int64_t total = a.n * RS_CAND;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = g / RS_CAND; const int c = (int)(g - i * RS_CAND);
+        const uint64_t q = base + (uint64_t)c + 2ull * (uint64_t)i;
+        a.cand_zc[g] = (q + 1 < a.cap) ? rnorm_from_two(a.U[q], a.U[q + 1]) : 0.0;     // (past the window: the slice loop reports it)
+    }
+}
+
+// part[s][c][row] = sum over columns [s KC, (s + 1) KC) of L[row][k] zc[k][c] for RS_ROWS = 32 rows: fp64 MFMA 16x16x4 with
+// A = 16 rows x 4 columns of L -- one 16-byte load per lane brings two rows (tiles t = 0, 1) -- and B = 4 x 16 candidates.
+// The four waves of a work-group take a quarter of the part's columns each (a wave's loads are a dependent chain of ~2.5 us
+// round trips: short chains and many waves are what fills the memory system -- 128 rows x 1024 columns per wave ran at
+// 3 TB/s; 64 rows per wave with 32-byte loads, half as many waves, at 3.1), eight steps' loads in flight; the quarters meet
+// in LDS and are added in order.  The strict upper triangle of L holds zeros (gpirt_sampler_create).
+__device__ __forceinline__ void rs_product_block(const RsSpecArgs& a, const int bx, const int by, double* red /* 16 x 64 doubles */)
+{
+    const int lane = threadIdx.x & 63, kq = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+    const int64_t n = a.n, ldl = a.ldl;
+    const int64_t r0 = (int64_t)bx * RS_ROWS;
+    const int64_t kall = (r0 + RS_ROWS < n) ? r0 + RS_ROWS : n;       // columns that can be non-zero in these rows
+    if ((int64_t)by * RS_KC >= kall) return;                  // (uniform over the work-group)
+    const int64_t k_beg = (int64_t)by * RS_KC + (int64_t)kq * (RS_KC / 4);
+    int64_t k_end = k_beg + RS_KC / 4;
+    if (k_end > kall) k_end = kall;
+    // The instruction returns row (g + 4 r) of the 16-row tile in element r of lane (i, g): A-lane i carries row pair
+    // pi(i) = 4 (i & 3) + (i >> 2), so that a lane ends up with EIGHT CONSECUTIVE rows, r0 + 8 g + 2 r + t (solve64.h uses the
+    // same permutation).  Clamped past the matrix: n is even, rows >= n are not stored.
+    int64_t rp = r0 + 2 * (4 * (i & 3) + (i >> 2));
+    if (rp > n - 2) rp = n - 2;
+    const double* Lp = a.L + rp;
+    const double* Zp = a.cand_zc + i;
+    d4 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[t][ct] = d4{ 0.0, 0.0, 0.0, 0.0 };
+    auto step = [&](const double2& av, const double b0, const double b1) {
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, b0, acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, b0, acc[1][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, b1, acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, b1, acc[1][1], 0, 0, 0);
+    };
+    int64_t k = k_beg;
+    for (; k + 32 <= k_end; k += 32) {
+        double2 av[8]; double b0[8], b1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t kk = k + 4 * u + g;
+            av[u] = *reinterpret_cast<const double2*>(Lp + kk * ldl);
+            b0[u] = Zp[kk * RS_CAND]; b1[u] = Zp[kk * RS_CAND + 16];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) step(av[u], b0[u], b1[u]);
+    }
+    for (; k < k_end; k += 4) {
+        const int64_t kk = k + g;
+        const bool in = kk < n;                               // (columns past the matrix: zc has four zero rows of padding, L has none)
+        double2 av = *reinterpret_cast<const double2*>(Lp + (in ? kk : n - 1) * ldl);
+        if (!in) { av.x = 0.0; av.y = 0.0; }
+        step(av, Zp[kk * RS_CAND], Zp[kk * RS_CAND + 16]);
+    }
+    // quarters 1, 2, 3 are added to quarter 0 in that order, one at a time through LDS
+    double* mine = red + lane;
+    for (int q = 1; q < 4; ++q) {
+        __syncthreads();
+        if (kq == q) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mine[((t * 2 + ct) * 4 + r) * 64] = acc[t][ct][r];
+        }
+        __syncthreads();
+        if (kq == 0) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[t][ct][r] += mine[((t * 2 + ct) * 4 + r) * 64];
+        }
+    }
+    if (kq != 0) return;
+    // lane (i, g): acc[t][ct][r] = row r0 + 2 pi(g + 4 r) + t = r0 + 8 g + 2 r + t, candidate 16 ct + i
+    double* out = a.cand_part + ((int64_t)by * RS_CAND) * n;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        double* oc = out + (int64_t)(16 * ct + i) * n + r0 + 8 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int64_t row = r0 + 8 * g + 2 * r + t;
+                if (row < n) oc[2 * r + t] = acc[t][ct][r];
+            }
+    }
+}
+
+// Sum of one value per thread over ALL the work-groups of the slice loop (pass = how many such sums came before): a block
+// sum, then the work-groups' sums meet in memory and every work-group adds them in the same order -- so all of them see
+// the same bits and take the same branches.  One lane publishes (agent-scope atomic store, then an add on the
+// counter) and polls; the poll is bounded like every in-kernel wait of this library (flagsync.h): on expiry the pass is
+// abandoned with GPIRT_E_HIP (as the panel kernel's guard is).  The work-groups are the FIRST of their grid on an otherwise idle stream: dispatched
+// together, before any of the product work-groups.  Returns false when the wait expired (uniform).
+__device__ __forceinline__ bool rs_sum_all(const RsSpecArgs& a, const int w, const int E, const int pass, const double v,
+                                           double* red, double& out)
+{
+    const double bs = block_sum_256(v, red);
+    if (E == 1) { out = bs; return true; }
+    double* slot = a.ess_partial + (pass & 1) * RS_ESS_WGS;
+    if (threadIdx.x == 0) {
+        // flagsync.h's form: the value is stored write-through at agent scope, the store is waited for, then the counter;
+        // the readers poll and read with agent-scope loads (served past the L1 and this XCD's L2) -- no release (it would
+        // write back every dirty line the product work-groups of this XCD have produced) and no acquire per poll
+        __hip_atomic_store(slot + w, bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(a.ess_cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long need = (unsigned long long)E * (unsigned long long)(pass + 1);
+        int spins = 0;
+        unsigned long long seen = __hip_atomic_load(a.ess_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (seen < need && ++spins < (1 << 22)) {
+            __builtin_amdgcn_s_sleep(1);
+            seen = __hip_atomic_load(a.ess_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        red[8] = (seen >= need) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    const bool ok = red[8] != 0.0;
+    double r = 0.0;
+    for (int q = 0; q < E; ++q) r += __hip_atomic_load(slot + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();                                          // (red is reused by the next block sum)
+    out = r;
+    return ok;
+}
+
+// ess() of ONE item (src/draw-f.cpp:21-60) on the candidate its predecessor's count selects, the formula as written (no
+// ll_fast: an R-stream replay keeps the reference's arithmetic).  On one compute unit the 2 + k likelihood passes over
+// 8192 rows take ~85 us -- as long as the products beside them -- so the rows are spread over E work-groups (1024 each, four
+// per thread, in registers) that meet once per pass (rs_sum_all).
+__device__ __forceinline__ void rs_ess_block(const RsSpecArgs& a, const int w, double* red)
+{
+    const int64_t n = a.n;
+    const int j = a.ess_item, E = a.ess_wgs;
+    const int kprev = a.ess_first ? 0 : a.k_out[j - 1];
+    if (kprev >= RS_CAND) {
+        if (w == 0 && threadIdx.x == 0) *a.miss = j + 1;
+        return;
+    }
+    double* fj = a.f; const double* yj = a.y; const double* mj = a.mu;
+    const uint64_t p0 = a.posv[j] + 2ull * (uint64_t)n;                                // behind the n normals
+    const int64_t per = ((n + E - 1) / E + 255) / 256 * 256;                           // rows per work-group
+    const int64_t i0 = (int64_t)w * per, i1 = (i0 + per < n) ? i0 + per : n;
+    const bool in_regs = per <= 4 * 256;
+    // nu = the parts of candidate kprev, added in part order; kept in the first part's column (nobody else reads it)
+    double* nj = a.ess_part + (int64_t)kprev * n;
+    double F[4], V[4], M[4], Y[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { F[e] = 0.0; V[e] = 0.0; M[e] = 0.0; Y[e] = __builtin_nan(""); }
+    for (int64_t i = i0 + threadIdx.x, e = 0; i < i1; i += 256, e = (e + 1) & 3) {
+        const int64_t grp = (i / RS_ROWS) * RS_ROWS;
+        const int64_t kall = (grp + RS_ROWS < n) ? grp + RS_ROWS : n;
+        const int parts = (int)((kall + RS_KC - 1) / RS_KC);
+        double v = nj[i];
+        for (int q = 1; q < parts; ++q) v += a.ess_part[((int64_t)q * RS_CAND + kprev) * n + i];
+        if (in_regs) {
+#pragma unroll
+            for (int ee = 0; ee < 4; ++ee) if (ee == e) { V[ee] = v; F[ee] = fj[i]; M[ee] = mj[i]; Y[ee] = yj[i]; }
+        } else nj[i] = v;                                     // (own rows only: re-read by this work-group alone)
+    }
+    if (!in_regs) __syncthreads();
+    uint32_t uidx = 0;
+    int pass = 0;
+    bool overflow = false, nan_state = false, expired = false;
+    auto next_u = [&]() -> double {
+        const uint64_t q = p0 + uidx;
+        double u;
+        if (q >= a.cap) { overflow = true; u = 0.5; } else u = a.U[q];
+        ++uidx;
+        return u;
+    };
+    // log_y = ll_bar(f, y, mu) + log(u)                                   draw-f.cpp:28-29
+    double acc = 0.0, ll0, llp = 0.0;
+    if (in_regs) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (Y[e] == Y[e]) acc += ll_term(Y[e] * (F[e] + M[e]));
+    } else {
+        for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+            const double yy = yj[i];
+            if (yy != yy) continue;
+            acc += ll_term(yy * (fj[i] + mj[i]));
+        }
+    }
+    if (!rs_sum_all(a, w, E, pass++, acc, red, ll0)) expired = true;
+    ll0 = -ll0;
+    const double u = next_u();
+    const double log_y = ll0 + log(u);
+    double eps_min = 0.0, eps_max = GP_2PI;                                // :33-34
+    double eps = eps_min + (eps_max - eps_min) * next_u();                 // :35
+    eps_min = eps - GP_2PI;                                                // :36
+    int k = 0;
+    double c = 1.0, s = 0.0;
+    while (!expired) {
+        c = cos(eps);
+        s = sin(eps);
+        acc = 0.0;
+        if (in_regs) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (Y[e] == Y[e]) acc += ll_term(Y[e] * ((F[e] * c + V[e] * s) + M[e]));     // :43
+        } else {
+            for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+                const double yy = yj[i];
+                if (yy != yy) continue;
+                acc += ll_term(yy * ((fj[i] * c + nj[i] * s) + mj[i]));
+            }
+        }
+        if (!rs_sum_all(a, w, E, pass++, acc, red, llp)) { expired = true; break; }
+        llp = -llp;
+        if (llp > log_y) break;                                            // :45-47
+        if (llp != llp) { nan_state = true; break; }                       // NaN state: never accepts
+        if (eps < 0.0) eps_min = eps; else eps_max = eps;                  // :50-55
+        if (eps_min == eps_max) eps = eps_min;                             // R::runif(a,a) = a
+        else eps = eps_min + (eps_max - eps_min) * next_u();               // :56
+        ++k;
+        if (k >= ESS_MAX_TRIALS || overflow) { overflow = true; break; }
+    }
+    if (expired) {
+        if (threadIdx.x == 0 && a.err) atomicCAS(a.err, 0, (int)GPIRT_E_HIP);          // (reported like the panel kernel's guard)
+        return;
+    }
+    if (in_regs) {
+        for (int64_t i = i0 + threadIdx.x, e = 0; i < i1; i += 256, e = (e + 1) & 3) {
+#pragma unroll
+            for (int ee = 0; ee < 4; ++ee) if (ee == e) fj[i] = F[ee] * c + V[ee] * s;
+        }
+    } else {
+        for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) fj[i] = fj[i] * c + nj[i] * s;
+    }
+    if (w == 0 && threadIdx.x == 0) {
+        a.k_out[j] = k;
+        if (nan_state && a.err) atomicCAS(a.err, 0, (int)GPIRT_E_NUMERIC);
+        else if (overflow && a.err) atomicCAS(a.err, 0, (int)GPIRT_E_RNG);
+        a.posv[j + 1] = p0 + uidx;
+        *a.pos = p0 + uidx;
+    }
+}
+
+// (forcing five work-groups per CU -- 96 registers, every wave of a pass at n = 8192 resident at once -- changed nothing at
+// n = 8192 and cost the slice loop spills at small n)
+__global__ __launch_bounds__(256) void rs_item_kernel(RsSpecArgs a)
+{
+    __shared__ double red[16 * 64];
+    if (*(volatile int*)a.miss != 0) return;
+    const int E = a.ess_item >= 0 ? a.ess_wgs : 0;
+    if ((int)blockIdx.x < E) { rs_ess_block(a, (int)blockIdx.x, red); return; }
+    if (a.cand_item < 0) return;
+    const int nbx = (int)((a.n + RS_ROWS - 1) / RS_ROWS);
+    const int id = (int)blockIdx.x - E;
+    rs_product_block(a, id % nbx, id / nbx, red);
+}
+
 // Register-resident variant for n <= NTH * EPT: each lane keeps its EPT entries of f, nu, mu and y in
 // registers, so the (2 + k) likelihood passes of a column touch memory once; arithmetic is identical
 // to ess_kernel (same per-element expression, same reduction tree).
@@ -266,6 +540,25 @@ int launch_ess(hipStream_t stream, const EssArgs& a)
         if (fast) hipLaunchKernelGGL(ess_kernel<true>, dim3((unsigned)a.m), dim3(256), 0, stream, a);
         else      hipLaunchKernelGGL(ess_kernel<false>, dim3((unsigned)a.m), dim3(256), 0, stream, a);
     }
+    GP_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_rs_cand_normals(hipStream_t stream, const RsSpecArgs& a)
+{
+    int64_t blocks = (a.n * RS_CAND + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(rs_cand_normals_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    GP_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_rs_item(hipStream_t stream, const RsSpecArgs& a)
+{
+    const unsigned nbx = (unsigned)((a.n + RS_ROWS - 1) / RS_ROWS), parts = (unsigned)((a.n + RS_KC - 1) / RS_KC);
+    const unsigned grid = (a.ess_item >= 0 ? (unsigned)a.ess_wgs : 0u) + (a.cand_item >= 0 ? nbx * parts : 0u);
+    if (grid == 0) return 0;
+    hipLaunchKernelGGL(rs_item_kernel, dim3(grid), dim3(256), 0, stream, a);
     GP_HIP(hipGetLastError());
     return 0;
 }

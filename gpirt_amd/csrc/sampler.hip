@@ -87,6 +87,25 @@ struct gpirt_sampler_s {
     uint64_t beta_total = 0;
     RStream saved{};
     bool stream_open = false;
+    // The host generator runs AHEAD of the chain (stream_begin / stream_end): while the device works off an iteration the
+    // host tops up a FIFO of fresh uniforms (hA, uploaded to S on cs), and the next window is put together on the device
+    // from the unconsumed tail of this one + the FIFO's head -- no 65 ms rewind and no 73 ms generation between two
+    // iterations (they were half of the default contract's 286 ms at 8192 x 1024).  ahead_gen / ahead_used: draws generated /
+    // consumed since the generator was attached; snaps: its state every 2^16 draws, so that the state at the consumed
+    // position -- what the caller's RStream must hold whenever anybody looks (rstream_sync) -- is one copy + a short skip.
+    gpirt_rstream_s* rs_obj = nullptr;
+    bool ahead_attached = false;
+    uint64_t ahead_gen = 0, ahead_used = 0, a_len = 0;
+    std::vector<std::pair<uint64_t, RStream>> snaps;
+    double *hA = nullptr, *S = nullptr, *U2 = nullptr;
+    hipStream_t cs = nullptr;
+    hipEvent_t ev_up = nullptr, ev_asm = nullptr;
+    // speculative draw_f of the replay (rng_ess.hip): one grid per item = its slice loop + the NEXT item's candidate products
+    bool spec_ok = false;
+    uint64_t* posv = nullptr;
+    int *miss = nullptr, *h_miss = nullptr;
+    unsigned long long* ess_cnt = nullptr; double* ess_partial = nullptr;
+    double *zc[2] = { nullptr, nullptr }, *cpart[2] = { nullptr, nullptr };
     // bookkeeping
     int iter = 0;                     // completed iterations
     bool initialised = false;
@@ -122,38 +141,106 @@ inline bool stream_mode(const gpirt_sampler_s* s) { return s->opt.rng_kind == GP
 
 int report_degenerate_theta(gpirt_sampler_s* s, int count);
 
-// ---- R-stream window: generate `count` uniforms ahead, upload, reset the device cursor -------
+// ---- R-stream window ---------------------------------------------------------------------------
+// draws [ahead_gen, ahead_gen + count) of the attached generator into dst, a state snapshot every 2^16 draws
+void ahead_generate(gpirt_sampler_s* s, double* dst, uint64_t count)
+{
+    constexpr uint64_t EVERY = 1ull << 16;
+    while (count) {
+        const uint64_t c = count < EVERY ? count : EVERY;
+        s->snaps.emplace_back(s->ahead_gen, *s->rs);
+        s->rs->fill_unif(dst, c);
+        s->ahead_gen += c; dst += c; count -= c;
+    }
+}
+
+// puts the caller's generator back to exactly the consumed position and forgets everything generated ahead
+// (gone: the RStream object itself is being destroyed -- the sampler must not touch it again)
+void ahead_resolve(void* owner, bool gone)
+{
+    gpirt_sampler_s* s = static_cast<gpirt_sampler_s*>(owner);
+    if (s->ahead_attached) {
+        if (s->ev_up) hipEventSynchronize(s->ev_up);          // (an upload may still be reading hA)
+        size_t best = 0;
+        for (size_t q = 0; q < s->snaps.size(); ++q) if (s->snaps[q].first <= s->ahead_used) best = q;
+        *s->rs = s->snaps[best].second;
+        s->rs->skip(s->ahead_used - s->snaps[best].first);
+    }
+    s->ahead_attached = false;
+    s->snaps.clear();
+    s->ahead_gen = s->ahead_used = s->a_len = 0;
+    if (s->rs_obj) { s->rs_obj->owner = nullptr; s->rs_obj->resolve = nullptr; }
+    if (gone) { s->rs_obj = nullptr; s->rs = nullptr; }
+}
+
 int stream_begin(gpirt_sampler_s* s, uint64_t count)
 {
     if (count > s->U_cap) { set_error("R-stream window %llu exceeds capacity %llu", (unsigned long long)count, (unsigned long long)s->U_cap); return GPIRT_E_RNG; }
-    s->saved = *s->rs;
-    for (uint64_t i = 0; i < count; ++i) s->hU[i] = s->rs->unif();
+    if (!s->rs) { set_error("the R stream of this sampler has been destroyed"); return GPIRT_E_ARG; }
     hipStream_t st = s->h->stream;
-    GP_HIP(hipMemcpyAsync(s->U, s->hU, count * sizeof(double), hipMemcpyHostToDevice, st));
+    if (!s->ahead_attached) {
+        // the first window after creation (or after somebody looked at the generator): generate, upload
+        s->snaps.clear();
+        s->ahead_gen = s->ahead_used = s->a_len = 0;
+        ahead_generate(s, s->hU, count);
+        GP_HIP(hipMemcpyAsync(s->U, s->hU, count * sizeof(double), hipMemcpyHostToDevice, st));
+        GP_HIP(hipEventRecord(s->ev_asm, st));
+        s->ahead_attached = true;
+        s->rs_obj->owner = s; s->rs_obj->resolve = ahead_resolve;
+    }                                                         // (otherwise stream_end has already put the window together)
     GP_HIP(hipMemsetAsync(s->pos, 0, sizeof(uint64_t), st));
     s->stream_open = true;
     return 0;
 }
 
-// read back the cursor, rewind the host generator to exactly the consumed position
-int stream_end(gpirt_sampler_s* s)
+// tops up the FIFO while the device works, reads back the cursor, builds the next window on the device
+int stream_end(gpirt_sampler_s* s, uint64_t count)
 {
     hipStream_t st = s->h->stream;
     GP_HIP(hipMemcpyAsync(s->h_pos, s->pos, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     GP_HIP(hipMemcpyAsync(s->h_flags, s->flags, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    if (s->a_len < count) {
+        const uint64_t need = count - s->a_len;
+        GP_HIP(hipEventSynchronize(s->ev_up));                // the previous upload has left hA
+        ahead_generate(s, s->hA + s->a_len, need);
+        GP_HIP(hipStreamWaitEvent(s->cs, s->ev_asm, 0));      // the last assembly has finished moving S's leftover
+        GP_HIP(hipMemcpyAsync(s->S + s->a_len, s->hA + s->a_len, need * sizeof(double), hipMemcpyHostToDevice, s->cs));
+        GP_HIP(hipEventRecord(s->ev_up, s->cs));
+        s->a_len = count;
+    }
     GP_HIP(hipStreamSynchronize(st));
     s->stream_open = false;
+    const uint64_t used = *s->h_pos <= count ? *s->h_pos : count;
+    s->ahead_used += used;
+    if (s->h_flags[0] != 0 || s->h_flags[1] != 0) ahead_resolve(s, false);       // the chain stops here: hand the generator back
     if (s->h_flags[0] != 0) {
         set_error(s->h_flags[0] == GPIRT_E_RNG ? "R-stream replay ran out of pre-generated uniforms"
-                                               : "sampler state is not finite (elliptical slice sampler met a NaN log-likelihood or did not terminate)");
+                  : s->h_flags[0] == GPIRT_E_HIP ? "slice sampler: the work-groups of one item did not meet within the spin bound (device hang guard)"
+                  : "sampler state is not finite (elliptical slice sampler met a NaN log-likelihood or did not terminate)");
         return s->h_flags[0];
     }
     // draw_theta as written underflows to 0/0 for some respondents (quirk Q5: the reference then reads theta_star[N] out
     // of bounds): reported at the iteration it happens in, not as whatever the NaN theta breaks next
     if (s->h_flags[1] != 0) return report_degenerate_theta(s, s->h_flags[1]);
-    const uint64_t used = *s->h_pos;
-    *s->rs = s->saved;
-    for (uint64_t i = 0; i < used; ++i) (void)s->rs->next32();
+    // next window = this one's unconsumed tail + the FIFO's first `used` draws; the FIFO's leftover moves to its front
+    // (through the old window buffer: the ranges overlap)
+    const uint64_t tail = count - used, rem = s->a_len - used;
+    GP_HIP(hipStreamWaitEvent(st, s->ev_up, 0));
+    if (tail) GP_HIP(hipMemcpyAsync(s->U2, s->U + used, tail * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (used) GP_HIP(hipMemcpyAsync(s->U2 + tail, s->S, used * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (rem) {
+        GP_HIP(hipMemcpyAsync(s->U, s->S + used, rem * sizeof(double), hipMemcpyDeviceToDevice, st));
+        GP_HIP(hipMemcpyAsync(s->S, s->U, rem * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    GP_HIP(hipEventRecord(s->ev_asm, st));
+    std::swap(s->U, s->U2);
+    GP_HIP(hipEventSynchronize(s->ev_up));
+    if (rem) memmove(s->hA, s->hA + used, rem * sizeof(double));
+    s->a_len = rem;
+    // snapshots below the consumed position are never needed again (all but the last of them)
+    size_t keep = 0;
+    for (size_t q = 0; q < s->snaps.size(); ++q) if (s->snaps[q].first <= s->ahead_used) keep = q;
+    if (keep) s->snaps.erase(s->snaps.begin(), s->snaps.begin() + (std::ptrdiff_t)keep);
     return 0;
 }
 
@@ -284,14 +371,48 @@ int do_draw_f(gpirt_sampler_s* s)
         return 0;
     }
     // exact R order: item j draws its n normals, then u, eps0 and one uniform per rejection
-    for (int64_t j = 0; j < m; ++j) {
+    auto plain_item = [&](int64_t j) -> int {
         GP_TRY(launch_rstream_normals(st, s->U, s->pos, 0, n, 1, s->Z));
         GP_TRY(launch_trmv_lower(st, s->L, n, s->ldl, s->Z, s->NU + n, s->NU));        // (the parts go behind NU's first column)
         EssArgs a{};
         a.f = s->f + j * n; a.nu = s->NU; a.y = s->y + j * n; a.mu = s->mu + j * n; a.n = n; a.m = 1;
         a.k_out = s->ess_k + j; a.err = s->flags; a.item0 = (uint32_t)j;
         a.U = s->U; a.pos = s->pos; a.cap = s->U_cap;
-        GP_TRY(launch_ess(st, a));
+        return launch_ess(st, a);
+    };
+    const bool spec = s->spec_ok && (s->ldl % 2 == 0) && (((uintptr_t)s->L & 15) == 0);      // (16-byte loads of two rows)
+    if (!spec) {
+        for (int64_t j = 0; j < m; ++j) GP_TRY(plain_item(j));
+        return 0;
+    }
+    // Speculative form (rng_ess.hip): the grid that runs item j's slice loop also computes L z for the 32 places item j + 1's
+    // normals can start at.  A slice loop longer than 31 rejections finds no candidate: the pass stops there (every later
+    // kernel leaves at once), the host redoes that one item the plain way and starts the pipeline again behind it.
+    int64_t j0 = 0;
+    while (j0 < m) {
+        RsSpecArgs a{};
+        a.U = s->U; a.cap = s->U_cap; a.pos = s->pos; a.posv = s->posv; a.k_out = s->ess_k; a.miss = s->miss; a.err = s->flags;
+        a.n = n; a.ldl = s->ldl; a.L = s->L;
+        a.ess_wgs = (int)((n + 1023) / 1024 < RS_ESS_WGS ? (n + 1023) / 1024 : RS_ESS_WGS); a.ess_partial = s->ess_partial;
+        GP_HIP(hipMemsetAsync(s->ess_cnt, 0, sizeof(unsigned long long) * (size_t)m, st));
+        for (int64_t j = j0 - 1; j < m; ++j) {                // (j0 - 1: the first item's candidates alone)
+            RsSpecArgs g = a;
+            g.ess_item = (j >= j0) ? (int)j : -1; g.ess_first = (j == j0) ? 1 : 0;
+            g.cand_item = (j + 1 < m) ? (int)(j + 1) : -1; g.cand_first = (j + 1 == j0) ? 1 : 0;
+            if (g.ess_item >= 0) { g.ess_cnt = s->ess_cnt + j; g.ess_part = s->cpart[j & 1]; g.f = s->f + j * n; g.y = s->y + j * n; g.mu = s->mu + j * n; }
+            if (g.cand_item >= 0) {
+                g.cand_zc = s->zc[(j + 1) & 1]; g.cand_part = s->cpart[(j + 1) & 1];
+                GP_TRY(launch_rs_cand_normals(st, g));        // (reads posv[j]: item j - 1's slice loop wrote it in the grid before)
+            }
+            GP_TRY(launch_rs_item(st, g));
+        }
+        GP_HIP(hipMemcpyAsync(s->h_miss, s->miss, sizeof(int), hipMemcpyDeviceToHost, st));
+        GP_HIP(hipStreamSynchronize(st));
+        if (*s->h_miss == 0) break;
+        const int64_t jm = (int64_t)*s->h_miss - 1;           // items < jm are done, the cursor stands at item jm's normals
+        GP_HIP(hipMemsetAsync(s->miss, 0, sizeof(int), st));
+        GP_TRY(plain_item(jm));
+        j0 = jm + 1;
     }
     return 0;
 }
@@ -642,7 +763,8 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
         if (s->opt.item0 != 0 || s->opt.m_total != m) {
             set_error("R-stream replay is sequential over items and cannot be sharded"); delete s; return GPIRT_E_ARG;
         }
-        s->rs = &rs->r;
+        rstream_sync(rs);            // (another sampler may be running ahead on this stream: it hands it back first)
+        s->rs = &rs->r; s->rs_obj = rs;
     }
     const int64_t N = s->N;
     hipStream_t st = h->stream;
@@ -699,12 +821,29 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
         s->U_cap = stream_window(s);
         const uint64_t init_need = (uint64_t)m * 2 * (uint64_t)n + 4 * (uint64_t)m + 2 * (uint64_t)N * m + 64;
         if (init_need > s->U_cap) s->U_cap = init_need;
-        GP_A(s->U, s->U_cap);
+        GP_A(s->U, s->U_cap);       GP_A(s->U2, s->U_cap);      GP_A(s->S, s->U_cap);
         GP_A(s->pos, 2);
+        // speculative draw_f: two sets of candidate buffers (items alternate)
+        s->spec_ok = (n % 2 == 0) && n >= RS_SPEC_MIN_N;
+        if (s->spec_ok) {
+            const size_t parts = (size_t)((n + RS_KC - 1) / RS_KC);
+            GP_A(s->posv, m + 1);    GP_A(s->miss, 2);    GP_A(s->ess_cnt, m);    GP_A(s->ess_partial, 2 * RS_ESS_WGS);
+            for (int q = 0; q < 2; ++q) {
+                GP_A(s->zc[q], (size_t)(n + 4) * RS_CAND);
+                GP_A(s->cpart[q], parts * RS_CAND * (size_t)n);
+                hipMemsetAsync(s->zc[q], 0, sizeof(double) * (size_t)(n + 4) * RS_CAND, st);
+            }
+            hipMemsetAsync(s->miss, 0, 2 * sizeof(int), st);
+        }
         GP_A(s->beta_off, m);
         GP_A(s->fstar_off, N + 8);
         if (hipHostMalloc(&s->hU, s->U_cap * sizeof(double), hipHostMallocDefault) != hipSuccess ||
-            hipHostMalloc(&s->h_pos, 2 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
+            hipHostMalloc(&s->hA, s->U_cap * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc(&s->h_pos, 2 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess ||
+            hipStreamCreateWithFlags(&s->cs, hipStreamNonBlocking) != hipSuccess ||
+            hipHostMalloc(&s->h_miss, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&s->ev_up, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s->ev_asm, hipEventDisableTiming) != hipSuccess) {
             set_error("pinned allocation for the R-stream window failed");
             gpirt_sampler_destroy(s);
             return GPIRT_E_ALLOC;
@@ -798,6 +937,12 @@ int gpirt_sampler_destroy(gpirt_sampler_t s)
 {
     if (!s) return 0;
     if (s->h) hipStreamSynchronize(s->h->stream);
+    if (s->rs_obj && s->rs_obj->owner == s) ahead_resolve(s, false);     // the caller's generator goes back to the consumed position
+    if (s->cs) { hipStreamSynchronize(s->cs); hipStreamDestroy(s->cs); }
+    if (s->h_miss) hipHostFree(s->h_miss);
+    if (s->ev_up) hipEventDestroy(s->ev_up);
+    if (s->ev_asm) hipEventDestroy(s->ev_asm);
+    if (s->hA) hipHostFree(s->hA);
     if (s->haux) {
         hipStreamSynchronize(s->haux->stream);       // (the side handle belongs to the main handle: not destroyed here)
         if (s->haux->trsm_winv_L == s->L) s->haux->trsm_winv_L = nullptr;
@@ -831,6 +976,10 @@ int gpirt_sampler_init(gpirt_sampler_t s)
     hipStream_t st = h->stream;
     const int64_t n = s->n, m = s->m, N = s->N;
     GP_TRY(aux_join(s));                  // (a repeated init: nothing of the previous chain may still be in flight)
+    if (stream_mode(s)) {
+        if (!s->rs) { set_error("the R stream of this sampler has been destroyed"); return GPIRT_E_ARG; }
+        rstream_sync(s->rs_obj);          // init draws from the generator directly: from the consumed position
+    }
     s->in_init = true;
     const int rc_f = do_factor(s);                                                // :15-17
     s->in_init = false;
@@ -860,7 +1009,7 @@ int gpirt_sampler_init(gpirt_sampler_t s)
         const uint64_t nf = (uint64_t)m * 2 * (uint64_t)n;
         // beta consumes on the host, directly behind the f-init block
         s->saved = *s->rs;
-        for (uint64_t i = 0; i < nf; ++i) s->hU[i] = s->rs->unif();
+        s->rs->fill_unif(s->hU, nf);
         std::vector<double> b((size_t)(2 * m));
         const double* pm = s->host_tmp.data();
         const double* ps = pm + 2 * m;
@@ -875,7 +1024,7 @@ int gpirt_sampler_init(gpirt_sampler_t s)
                 b[(size_t)(p + 2 * j)] = v;
             }
         const uint64_t nfs = 2 * (uint64_t)N * (uint64_t)m;
-        for (uint64_t i = 0; i < nfs; ++i) s->hU[nf + i] = s->rs->unif();
+        s->rs->fill_unif(s->hU + nf, nfs);
         (void)nb;
         GP_HIP(hipMemcpyAsync(s->U, s->hU, (nf + nfs) * sizeof(double), hipMemcpyHostToDevice, st));
         GP_HIP(hipMemsetAsync(s->pos, 0, sizeof(uint64_t), st));
@@ -896,7 +1045,7 @@ int gpirt_sampler_init(gpirt_sampler_t s)
         const uint64_t used_fstar = *s->h_pos - nf;
         // host state currently sits after [f][beta][2Nm]; recompute: after [f][beta] + used_fstar
         RStream r = s->saved;
-        for (uint64_t i = 0; i < nf; ++i) (void)r.next32();
+        r.skip(nf);
         const double* pm = s->host_tmp.data();
         const double* ps = pm + 2 * m;
         for (int64_t j = 0; j < m; ++j)
@@ -906,7 +1055,7 @@ int gpirt_sampler_init(gpirt_sampler_t s)
                     (void)r.next32(); (void)r.next32();
                 }
             }
-        for (uint64_t i = 0; i < used_fstar; ++i) (void)r.next32();
+        r.skip(used_fstar);
         *s->rs = r;
     }
     s->iter = 0;
@@ -1006,7 +1155,7 @@ int gpirt_sampler_step(gpirt_sampler_t s)
     GP_TRY(do_draw_beta(s));         mark(s, 5);
     GP_TRY(do_factor(s));            mark(s, 6);
     s->iter += 1;
-    if (stream_mode(s)) GP_TRY(stream_end(s));
+    if (stream_mode(s)) GP_TRY(stream_end(s, stream_window(s)));
     if (s->timing) {
         GP_HIP(hipEventSynchronize(s->ev[ST_COUNT]));
         for (int i = 0; i < ST_COUNT; ++i) {

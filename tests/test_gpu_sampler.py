@@ -479,3 +479,46 @@ def test_side_chain_beside_the_product_changes_nothing(handle):
             s.close()
     for name in outs[0]:
         assert np.array_equal(outs[0][name], outs[1][name]), name
+
+
+def test_r_stream_generator_runs_ahead_and_is_handed_back_exactly(handle, oracle):
+    """Under the R-stream contract the host generator runs AHEAD of the chain between iterations (the next window's uniforms
+    are generated while the device works; sampler.hip, stream_end).  Whoever looks at the RStream -- its state, a draw from
+    it -- must find it at exactly the consumed position, and the chain must go on from there as if nobody had looked:
+    A steps 4 times; B steps twice, reads the state, steps, draws 3 uniforms (which the chain then does not get), steps;
+    C is the oracle's whole call for the first three iterations' consumption."""
+    from gpirt_amd import Sampler
+    from gpirt_amd.ops import RStream
+    from gpirt_amd.synthetic import make_responses
+    n, m = 300, 12
+    y, th0 = make_responses(n, m, seed=5)
+    ra = RStream(77)
+    a = Sampler(handle, y, th0, rng="reference", rstream=ra)
+    a.init()
+    for _ in range(3):
+        a.step()
+    a.check()
+    fa3, tha3 = a.get("f"), a.get("theta")
+    state3 = ra.state()                                   # (hands the generator back; A re-attaches at its next step)
+    a.step(); a.check()
+    fa4 = a.get("f")
+    rb = RStream(77)
+    b = Sampler(handle, y, th0, rng="reference", rstream=rb)
+    b.init()
+    b.step(); b.step()
+    rb.state()
+    b.step(); b.check()
+    assert np.array_equal(b.get("f"), fa3) and np.array_equal(b.get("theta"), tha3)
+    sb = rb.state()
+    assert sb[1] == state3[1] and np.array_equal(sb[0], state3[0])
+    # the oracle's generator after init + 3 iterations sits at the same place
+    r = oracle.RStream(77)
+    oracle.gpirt_mcmc(r, y, th0, 3, 0)
+    mt_ref, mti_ref = r.mt_state()
+    assert sb[1] == mti_ref and np.array_equal(sb[0], mt_ref)
+    # a draw taken from the stream in between belongs to the caller, not to the chain
+    taken = rb.runif(3)
+    assert np.array_equal(taken, r.runif(3))
+    b.step(); b.check()
+    assert not np.array_equal(b.get("f"), fa4)            # (the chain went on with the uniforms BEHIND the three taken)
+    a.close(); b.close()
