@@ -415,6 +415,15 @@ int gpirt_guard_fallbacks(gpirt_handle_t h, int* count)
 // guard word raised, result unfinished -- so the fallback can be tested without spinning a kernel to its bound.
 // h == NULL arms the NEXT handle gpirt_mcmc creates for itself.
 static long long g_trip_next_mcmc = 0;
+// Tests only: the replay's speculative draw_f (rng_ess.hip) finds a candidate for rejection counts < limit only (0: all 32),
+// so that the redo-one-item-the-plain-way path, which a real chain takes once in many thousand items, runs every few items.
+int gpirt_debug_rs_cand_limit(gpirt_handle_t h, int limit)
+{
+    GP_ARG(h != nullptr && limit >= 0);
+    h->rs_cand_limit = limit;
+    return 0;
+}
+
 int gpirt_debug_trip_guard(gpirt_handle_t h, int nth)
 {
     GP_ARG(nth >= 0);

@@ -162,6 +162,7 @@ struct RsSpecArgs {
     uint64_t* posv;                  // [m + 1]: where item j's normals start
     int* k_out;                      // [m]: rejection counts
     int* miss;                       // != 0: item (miss - 1) found no candidate; every later kernel of the pass leaves at once
+    int cand_limit;                  // counts >= this find no candidate (RS_CAND; smaller only through gpirt_debug_rs_cand_limit)
     int* err;
     int64_t n, ldl;
     const double* L;

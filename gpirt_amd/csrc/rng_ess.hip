@@ -304,7 +304,7 @@ __device__ __forceinline__ void rs_ess_block(const RsSpecArgs& a, const int w, d
     const int64_t n = a.n;
     const int j = a.ess_item, E = a.ess_wgs;
     const int kprev = a.ess_first ? 0 : a.k_out[j - 1];
-    if (kprev >= RS_CAND) {
+    if (kprev >= a.cand_limit) {
         if (w == 0 && threadIdx.x == 0) *a.miss = j + 1;
         return;
     }

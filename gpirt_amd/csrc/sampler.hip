@@ -393,6 +393,7 @@ int do_draw_f(gpirt_sampler_s* s)
         RsSpecArgs a{};
         a.U = s->U; a.cap = s->U_cap; a.pos = s->pos; a.posv = s->posv; a.k_out = s->ess_k; a.miss = s->miss; a.err = s->flags;
         a.n = n; a.ldl = s->ldl; a.L = s->L;
+        a.cand_limit = (h->rs_cand_limit > 0 && h->rs_cand_limit < RS_CAND) ? h->rs_cand_limit : RS_CAND;
         a.ess_wgs = (int)((n + 1023) / 1024 < RS_ESS_WGS ? (n + 1023) / 1024 : RS_ESS_WGS); a.ess_partial = s->ess_partial;
         GP_HIP(hipMemsetAsync(s->ess_cnt, 0, sizeof(unsigned long long) * (size_t)m, st));
         for (int64_t j = j0 - 1; j < m; ++j) {                // (j0 - 1: the first item's candidates alone)

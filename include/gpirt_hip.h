@@ -85,6 +85,9 @@ int         gpirt_guard_fallbacks(gpirt_handle_t h, int* count);
  * word raised, result unfinished -- without spinning any kernel.  h == NULL arms the handle the NEXT gpirt_mcmc call
  * creates for itself (that call reports its fallbacks through gpirt_debug_last_mcmc_fallbacks). */
 int         gpirt_debug_trip_guard(gpirt_handle_t h, int nth);
+/* Tests only: the R-stream replay's speculative draw_f uses candidates for rejection counts < limit only (0: all 32; see
+ * DESIGN.md section 2), so the fallback of an item whose predecessor's slice loop ran longer is exercised. */
+int         gpirt_debug_rs_cand_limit(gpirt_handle_t h, int limit);
 int         gpirt_debug_last_mcmc_fallbacks(void);
 /* Debug (GPIRT_RUNTIME=2): where the work-groups of the dependency-driven factorisation land.  host_out == NULL arms it;
  * otherwise copies out [2][4096][4] words {HW_ID, XCC_ID, arrival index, stayed} (update workers, then CU holders), then

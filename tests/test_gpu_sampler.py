@@ -522,3 +522,37 @@ def test_r_stream_generator_runs_ahead_and_is_handed_back_exactly(handle, oracle
     b.step(); b.check()
     assert not np.array_equal(b.get("f"), fa4)            # (the chain went on with the uniforms BEHIND the three taken)
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("n,m,limit", [(100, 17, 2), (512, 9, 1), (1030, 6, 3), (2048, 5, 2)])
+def test_r_stream_draw_f_redoes_an_item_whose_candidates_ran_out(handle, oracle, n, m, limit):
+    """The replay's draw_f takes item j's nu = L z from 32 candidates computed beside item j - 1's slice loop, one per possible
+    rejection count of that loop (rng_ess.hip); a longer loop leaves item j without a candidate and the host redoes it the
+    plain way.  With the limit lowered to 1-3 that happens every few items: every draw must still be the oracle's."""
+    from gpirt_amd import Sampler, _lib
+    from gpirt_amd.ops import RStream
+    from gpirt_amd.synthetic import make_responses
+    lib = _lib.load()
+    y, th0 = make_responses(n, m, seed=n + m)
+    _lib.check(lib.gpirt_debug_rs_cand_limit(handle._h, limit))
+    try:
+        rs = RStream(4242)
+        s = Sampler(handle, y, th0, rng="reference", rstream=rs)
+        s.init()
+        for _ in range(2):
+            s.step()
+        s.check()
+        got = {k: s.get(k) for k in ("theta", "f", "beta")}
+        ks = s.get("ess_k")
+        state = rs.state()
+        s.close()
+    finally:
+        _lib.check(lib.gpirt_debug_rs_cand_limit(handle._h, 0))
+    assert (ks >= limit).any()                            # (the path under test did run)
+    r = oracle.RStream(4242)
+    ref = oracle.gpirt_mcmc(r, y, th0, 2, 0)
+    assert np.array_equal(got["theta"], ref["theta"][2])
+    assert np.abs(got["f"] - ref["f"][:, :, 2]).max() <= 1e-9
+    assert np.abs(got["beta"] - ref["beta"][:, :, 2]).max() <= 1e-9
+    mt_ref, mti_ref = r.mt_state()
+    assert state[1] == mti_ref and np.array_equal(state[0], mt_ref)
