@@ -193,21 +193,29 @@ int stream_begin(gpirt_sampler_s* s, uint64_t count)
     return 0;
 }
 
-// tops up the FIFO while the device works, reads back the cursor, builds the next window on the device
+// Fills the FIFO of fresh uniforms up to one window and uploads the new part on the copy stream: host work for the time the
+// device is busy.  Called with the items of draw_f enqueued (80 % of an iteration's device time is still ahead), and again
+// from stream_end for whoever did not come through there.
+int ahead_topup(gpirt_sampler_s* s, uint64_t count)
+{
+    if (!s->ahead_attached || s->a_len >= count) return 0;
+    const uint64_t need = count - s->a_len;
+    GP_HIP(hipEventSynchronize(s->ev_up));                    // the previous upload has left hA
+    ahead_generate(s, s->hA + s->a_len, need);
+    GP_HIP(hipStreamWaitEvent(s->cs, s->ev_asm, 0));          // the last assembly has finished moving S's leftover
+    GP_HIP(hipMemcpyAsync(s->S + s->a_len, s->hA + s->a_len, need * sizeof(double), hipMemcpyHostToDevice, s->cs));
+    GP_HIP(hipEventRecord(s->ev_up, s->cs));
+    s->a_len = count;
+    return 0;
+}
+
+// reads back the cursor, builds the next window on the device
 int stream_end(gpirt_sampler_s* s, uint64_t count)
 {
     hipStream_t st = s->h->stream;
     GP_HIP(hipMemcpyAsync(s->h_pos, s->pos, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     GP_HIP(hipMemcpyAsync(s->h_flags, s->flags, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-    if (s->a_len < count) {
-        const uint64_t need = count - s->a_len;
-        GP_HIP(hipEventSynchronize(s->ev_up));                // the previous upload has left hA
-        ahead_generate(s, s->hA + s->a_len, need);
-        GP_HIP(hipStreamWaitEvent(s->cs, s->ev_asm, 0));      // the last assembly has finished moving S's leftover
-        GP_HIP(hipMemcpyAsync(s->S + s->a_len, s->hA + s->a_len, need * sizeof(double), hipMemcpyHostToDevice, s->cs));
-        GP_HIP(hipEventRecord(s->ev_up, s->cs));
-        s->a_len = count;
-    }
+    GP_TRY(ahead_topup(s, count));                            // (normally done already, beside draw_f)
     GP_HIP(hipStreamSynchronize(st));
     s->stream_open = false;
     const uint64_t used = *s->h_pos <= count ? *s->h_pos : count;
@@ -408,6 +416,7 @@ int do_draw_f(gpirt_sampler_s* s)
             GP_TRY(launch_rs_item(st, g));
         }
         GP_HIP(hipMemcpyAsync(s->h_miss, s->miss, sizeof(int), hipMemcpyDeviceToHost, st));
+        if (s->stream_open) GP_TRY(ahead_topup(s, stream_window(s)));     // the next window's uniforms, while the items run
         GP_HIP(hipStreamSynchronize(st));
         if (*s->h_miss == 0) break;
         const int64_t jm = (int64_t)*s->h_miss - 1;           // items < jm are done, the cursor stands at item jm's normals

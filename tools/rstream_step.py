@@ -12,8 +12,12 @@ y, th0 = make_responses(n, m, seed=20240)
 h = Handle()
 s = Sampler(h, y, th0, rng="reference", rstream=RStream(20240), theta_stabilise=True, fstar_fused=False)
 s.init(); s.check(); s.step(); s.check()
+s.enable_timing(True)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(3):
     s.step()
 s.check(); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+import time as _t
+t1 = _t.perf_counter(); s.step(); t2 = _t.perf_counter()
+print("stage ms:", {k: round(v, 2) for k, v in s.stage_times().items()}, f"; wall of that step {1e3 * (t2 - t1):.1f} ms")
 print(f"{n} x {m}: {dt * 1e3:.2f} ms per iteration = {dt / m * 1e6:.1f} us per item all told; mean k {s.get('ess_k').mean():.2f}")
