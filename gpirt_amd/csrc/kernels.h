@@ -151,7 +151,8 @@ struct EssArgs {
 int launch_ess(hipStream_t stream, const EssArgs& a);
 // R-stream replay, speculative form (sampler.hip, do_draw_f): item j's nu = L z is taken from RS_CAND candidate vectors
 // that were computed while item j - 1's slice loop was still running -- one per possible length of that loop.
-constexpr int RS_CAND = 32;          // candidates per item: rejection counts 0 .. 31 of the item before
+constexpr int RS_CAND_MAX = 32;      // candidates per item: rejection counts 0 .. 31 of the item before (16 below n = 6144: the
+                                     // product is then bound by the candidates' own traffic, and a redone item costs little)
 constexpr int RS_KC = 1024;          // columns of L per part of a candidate product
 constexpr int RS_ROWS = 32;          // rows of L per work-group of a candidate product
 constexpr int RS_SPEC_MIN_N = 64;    // below: item by item, four launches each
@@ -162,7 +163,8 @@ struct RsSpecArgs {
     uint64_t* posv;                  // [m + 1]: where item j's normals start
     int* k_out;                      // [m]: rejection counts
     int* miss;                       // != 0: item (miss - 1) found no candidate; every later kernel of the pass leaves at once
-    int cand_limit;                  // counts >= this find no candidate (RS_CAND; smaller only through gpirt_debug_rs_cand_limit)
+    int cand;                        // 16 or RS_CAND_MAX: candidates per item in this round
+    int cand_limit;                  // counts >= this find no candidate (cand; smaller only through gpirt_debug_rs_cand_limit)
     int* err;
     int64_t n, ldl;
     const double* L;
@@ -171,11 +173,11 @@ struct RsSpecArgs {
     // ess_cnt[ess_item] (zero when the pass over the items starts) and ess_partial[2][RS_ESS_WGS]
     int ess_item, ess_first, ess_wgs;
     unsigned long long* ess_cnt; double* ess_partial;
-    double* ess_part;                // [parts][RS_CAND][n] parts of that item's candidate products
+    double* ess_part;                // [parts][cand][n] parts of that item's candidate products
     double* f; const double* y; const double* mu;
     // candidates of item `cand_item` (< 0: none): normals (rs_cand_normals) and products (the other work-groups of rs_item)
     int cand_item, cand_first;       // cand_first: the item has no predecessor in this pass, its normals start at the cursor
-    double* cand_zc;                 // [n + 4][RS_CAND] candidate normals (k-major)
+    double* cand_zc;                 // [n + 4][cand] candidate normals (k-major)
     double* cand_part;
 };
 int launch_rs_cand_normals(hipStream_t stream, const RsSpecArgs& a);

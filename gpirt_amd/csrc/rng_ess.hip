@@ -154,6 +154,7 @@ __global__ __launch_bounds__(256) void ess_kernel(EssArgs a)
 // others; the slice loop of item j + 1 then picks column k_j.  A count >= 32 raises `miss`: every later kernel of the
 // pass leaves at once and the host redoes that item the plain way (do_draw_f).  Two launches per item on one stream (the
 // candidate normals, then this grid) instead of four dependent ones; no events.
+template <int RS_CAND>
 __global__ __launch_bounds__(256) void rs_cand_normals_kernel(RsSpecArgs a)
 {
     if (*(volatile int*)a.miss != 0) return;
@@ -173,6 +174,7 @@ __global__ __launch_bounds__(256) void rs_cand_normals_kernel(RsSpecArgs a)
 // round trips: short chains and many waves are what fills the memory system -- 128 rows x 1024 columns per wave ran at
 // 3 TB/s; 64 rows per wave with 32-byte loads, half as many waves, at 3.1), eight steps' loads in flight; the quarters meet
 // in LDS and are added in order.  The strict upper triangle of L holds zeros (gpirt_sampler_create).
+template <int RS_CAND>
 __device__ __forceinline__ void rs_product_block(const RsSpecArgs& a, const int bx, const int by, double* red /* 16 x 64 doubles */)
 {
     const int lane = threadIdx.x & 63, kq = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
@@ -190,35 +192,41 @@ __device__ __forceinline__ void rs_product_block(const RsSpecArgs& a, const int 
     if (rp > n - 2) rp = n - 2;
     const double* Lp = a.L + rp;
     const double* Zp = a.cand_zc + i;
-    d4 acc[2][2];
+    constexpr int CT = RS_CAND / 16;                          // tiles of 16 candidates
+    d4 acc[2][CT];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) acc[t][ct] = d4{ 0.0, 0.0, 0.0, 0.0 };
-    auto step = [&](const double2& av, const double b0, const double b1) {
-        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, b0, acc[0][0], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, b0, acc[1][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, b1, acc[0][1], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, b1, acc[1][1], 0, 0, 0);
-    };
+        for (int ct = 0; ct < CT; ++ct) acc[t][ct] = d4{ 0.0, 0.0, 0.0, 0.0 };
     int64_t k = k_beg;
     for (; k + 32 <= k_end; k += 32) {
-        double2 av[8]; double b0[8], b1[8];
+        double2 av[8]; double b[8][CT];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int64_t kk = k + 4 * u + g;
             av[u] = *reinterpret_cast<const double2*>(Lp + kk * ldl);
-            b0[u] = Zp[kk * RS_CAND]; b1[u] = Zp[kk * RS_CAND + 16];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) b[u][ct] = Zp[kk * RS_CAND + 16 * ct];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) step(av[u], b0[u], b1[u]);
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                acc[0][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u].x, b[u][ct], acc[0][ct], 0, 0, 0);
+                acc[1][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u].y, b[u][ct], acc[1][ct], 0, 0, 0);
+            }
     }
     for (; k < k_end; k += 4) {
         const int64_t kk = k + g;
         const bool in = kk < n;                               // (columns past the matrix: zc has four zero rows of padding, L has none)
         double2 av = *reinterpret_cast<const double2*>(Lp + (in ? kk : n - 1) * ldl);
         if (!in) { av.x = 0.0; av.y = 0.0; }
-        step(av, Zp[kk * RS_CAND], Zp[kk * RS_CAND + 16]);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const double bb = Zp[kk * RS_CAND + 16 * ct];
+            acc[0][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, bb, acc[0][ct], 0, 0, 0);
+            acc[1][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, bb, acc[1][ct], 0, 0, 0);
+        }
     }
     // quarters 1, 2, 3 are added to quarter 0 in that order, one at a time through LDS
     double* mine = red + lane;
@@ -228,25 +236,25 @@ __device__ __forceinline__ void rs_product_block(const RsSpecArgs& a, const int 
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
+                for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) mine[((t * 2 + ct) * 4 + r) * 64] = acc[t][ct][r];
+                    for (int r = 0; r < 4; ++r) mine[((t * CT + ct) * 4 + r) * 64] = acc[t][ct][r];
         }
         __syncthreads();
         if (kq == 0) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
+                for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[t][ct][r] += mine[((t * 2 + ct) * 4 + r) * 64];
+                    for (int r = 0; r < 4; ++r) acc[t][ct][r] += mine[((t * CT + ct) * 4 + r) * 64];
         }
     }
     if (kq != 0) return;
     // lane (i, g): acc[t][ct][r] = row r0 + 2 pi(g + 4 r) + t = r0 + 8 g + 2 r + t, candidate 16 ct + i
     double* out = a.cand_part + ((int64_t)by * RS_CAND) * n;
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
+    for (int ct = 0; ct < CT; ++ct) {
         double* oc = out + (int64_t)(16 * ct + i) * n + r0 + 8 * g;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -299,6 +307,7 @@ __device__ __forceinline__ bool rs_sum_all(const RsSpecArgs& a, const int w, con
 // ll_fast: an R-stream replay keeps the reference's arithmetic).  On one compute unit the 2 + k likelihood passes over
 // 8192 rows take ~85 us -- as long as the products beside them -- so the rows are spread over E work-groups (1024 each, four
 // per thread, in registers) that meet once per pass (rs_sum_all).
+template <int RS_CAND>
 __device__ __forceinline__ void rs_ess_block(const RsSpecArgs& a, const int w, double* red)
 {
     const int64_t n = a.n;
@@ -408,16 +417,17 @@ __device__ __forceinline__ void rs_ess_block(const RsSpecArgs& a, const int w, d
 
 // (forcing five work-groups per CU -- 96 registers, every wave of a pass at n = 8192 resident at once -- changed nothing at
 // n = 8192 and cost the slice loop spills at small n)
+template <int RS_CAND>
 __global__ __launch_bounds__(256) void rs_item_kernel(RsSpecArgs a)
 {
     __shared__ double red[16 * 64];
     if (*(volatile int*)a.miss != 0) return;
     const int E = a.ess_item >= 0 ? a.ess_wgs : 0;
-    if ((int)blockIdx.x < E) { rs_ess_block(a, (int)blockIdx.x, red); return; }
+    if ((int)blockIdx.x < E) { rs_ess_block<RS_CAND>(a, (int)blockIdx.x, red); return; }
     if (a.cand_item < 0) return;
     const int nbx = (int)((a.n + RS_ROWS - 1) / RS_ROWS);
     const int id = (int)blockIdx.x - E;
-    rs_product_block(a, id % nbx, id / nbx, red);
+    rs_product_block<RS_CAND>(a, id % nbx, id / nbx, red);
 }
 
 // Register-resident variant for n <= NTH * EPT: each lane keeps its EPT entries of f, nu, mu and y in
@@ -546,9 +556,10 @@ int launch_ess(hipStream_t stream, const EssArgs& a)
 
 int launch_rs_cand_normals(hipStream_t stream, const RsSpecArgs& a)
 {
-    int64_t blocks = (a.n * RS_CAND + 255) / 256;
+    int64_t blocks = (a.n * a.cand + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(rs_cand_normals_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    if (a.cand == 16) hipLaunchKernelGGL(rs_cand_normals_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    else              hipLaunchKernelGGL(rs_cand_normals_kernel<RS_CAND_MAX>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     GP_HIP(hipGetLastError());
     return 0;
 }
@@ -558,7 +569,8 @@ int launch_rs_item(hipStream_t stream, const RsSpecArgs& a)
     const unsigned nbx = (unsigned)((a.n + RS_ROWS - 1) / RS_ROWS), parts = (unsigned)((a.n + RS_KC - 1) / RS_KC);
     const unsigned grid = (a.ess_item >= 0 ? (unsigned)a.ess_wgs : 0u) + (a.cand_item >= 0 ? nbx * parts : 0u);
     if (grid == 0) return 0;
-    hipLaunchKernelGGL(rs_item_kernel, dim3(grid), dim3(256), 0, stream, a);
+    if (a.cand == 16) hipLaunchKernelGGL(rs_item_kernel<16>, dim3(grid), dim3(256), 0, stream, a);
+    else              hipLaunchKernelGGL(rs_item_kernel<RS_CAND_MAX>, dim3(grid), dim3(256), 0, stream, a);
     GP_HIP(hipGetLastError());
     return 0;
 }

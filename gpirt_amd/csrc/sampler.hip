@@ -401,7 +401,8 @@ int do_draw_f(gpirt_sampler_s* s)
         RsSpecArgs a{};
         a.U = s->U; a.cap = s->U_cap; a.pos = s->pos; a.posv = s->posv; a.k_out = s->ess_k; a.miss = s->miss; a.err = s->flags;
         a.n = n; a.ldl = s->ldl; a.L = s->L;
-        a.cand_limit = (h->rs_cand_limit > 0 && h->rs_cand_limit < RS_CAND) ? h->rs_cand_limit : RS_CAND;
+        a.cand = (n >= 6144) ? RS_CAND_MAX : 16;
+        a.cand_limit = (h->rs_cand_limit > 0 && h->rs_cand_limit < a.cand) ? h->rs_cand_limit : a.cand;
         a.ess_wgs = (int)((n + 1023) / 1024 < RS_ESS_WGS ? (n + 1023) / 1024 : RS_ESS_WGS); a.ess_partial = s->ess_partial;
         GP_HIP(hipMemsetAsync(s->ess_cnt, 0, sizeof(unsigned long long) * (size_t)m, st));
         for (int64_t j = j0 - 1; j < m; ++j) {                // (j0 - 1: the first item's candidates alone)
@@ -839,9 +840,9 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
             const size_t parts = (size_t)((n + RS_KC - 1) / RS_KC);
             GP_A(s->posv, m + 1);    GP_A(s->miss, 2);    GP_A(s->ess_cnt, m);    GP_A(s->ess_partial, 2 * RS_ESS_WGS);
             for (int q = 0; q < 2; ++q) {
-                GP_A(s->zc[q], (size_t)(n + 4) * RS_CAND);
-                GP_A(s->cpart[q], parts * RS_CAND * (size_t)n);
-                hipMemsetAsync(s->zc[q], 0, sizeof(double) * (size_t)(n + 4) * RS_CAND, st);
+                GP_A(s->zc[q], (size_t)(n + 4) * RS_CAND_MAX);
+                GP_A(s->cpart[q], parts * RS_CAND_MAX * (size_t)n);
+                hipMemsetAsync(s->zc[q], 0, sizeof(double) * (size_t)(n + 4) * RS_CAND_MAX, st);
             }
             hipMemsetAsync(s->miss, 0, 2 * sizeof(int), st);
         }

@@ -19,5 +19,7 @@ for _ in range(3):
 s.check(); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
 import time as _t
 t1 = _t.perf_counter(); s.step(); t2 = _t.perf_counter()
+import numpy as _np
+_k = s.get("ess_k"); print("rejection counts: max", int(_k.max()), "histogram", _np.bincount(_k.astype(int), minlength=12)[:24].tolist())
 print("stage ms:", {k: round(v, 2) for k, v in s.stage_times().items()}, f"; wall of that step {1e3 * (t2 - t1):.1f} ms")
 print(f"{n} x {m}: {dt * 1e3:.2f} ms per iteration = {dt / m * 1e6:.1f} us per item all told; mean k {s.get('ess_k').mean():.2f}")
