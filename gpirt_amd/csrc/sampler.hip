@@ -180,6 +180,7 @@ int stream_begin(gpirt_sampler_s* s, uint64_t count)
     hipStream_t st = s->h->stream;
     if (!s->ahead_attached) {
         // the first window after creation (or after somebody looked at the generator): generate, upload
+        if (s->rs_obj->owner && s->rs_obj->owner != s) rstream_sync(s->rs_obj);     // another sampler runs ahead on this stream
         s->snaps.clear();
         s->ahead_gen = s->ahead_used = s->a_len = 0;
         ahead_generate(s, s->hU, count);

@@ -556,3 +556,35 @@ def test_r_stream_draw_f_redoes_an_item_whose_candidates_ran_out(handle, oracle,
     assert np.abs(got["beta"] - ref["beta"][:, :, 2]).max() <= 1e-9
     mt_ref, mti_ref = r.mt_state()
     assert state[1] == mti_ref and np.array_equal(state[0], mt_ref)
+
+
+def test_two_samplers_alternating_on_one_r_stream(handle, oracle):
+    """Two chains drawing from ONE R stream in turns (each step continues where the other's left the generator): each
+    sampler runs ahead of its own chain between ITS steps, so every step of the other must first get the generator back
+    at the consumed position.  Reference: the same interleaving done with a hand-over of the state after every step."""
+    from gpirt_amd import Sampler
+    from gpirt_amd.ops import RStream
+    from gpirt_amd.synthetic import make_responses
+    n, m = 200, 8
+    ya, tha = make_responses(n, m, seed=11)
+    yb, thb = make_responses(n, m, seed=12)
+
+    def run(peek):
+        rs = RStream(5)
+        a = Sampler(handle, ya, tha, rng="reference", rstream=rs)
+        b = Sampler(handle, yb, thb, rng="reference", rstream=rs)
+        a.init(); b.init()
+        for _ in range(3):
+            a.step()
+            if peek: rs.state()
+            b.step()
+            if peek: rs.state()
+        a.check(); b.check()
+        out = (a.get("f"), a.get("theta"), b.get("f"), b.get("theta"), rs.state())
+        a.close(); b.close()
+        return out
+
+    x, y = run(False), run(True)
+    for u, v in zip(x[:4], y[:4]):
+        assert np.array_equal(u, v)
+    assert x[4][1] == y[4][1] and np.array_equal(x[4][0], y[4][0])
