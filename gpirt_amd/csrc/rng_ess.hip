@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256) void ess_kernel(EssArgs a)
 // loop ends -- but it has few possible values: z_j starts at  posv[j - 1] + 2n + 2 + k  for the rejection count k of item
 // j - 1, and a pass over L (268 MB at n = 8192: HBM-bound) costs the same for 32 right-hand sides as for one.  So ONE grid
 // per item runs item j's slice loop in its first work-groups and  L z  for the 32 candidates of item j + 1 in all the
-// others; the slice loop of item j + 1 then picks column k_j.  A count >= 32 raises `miss`: every later kernel of the
+// others (16 below n = 6144, kernels.h); the slice loop of item j + 1 then picks column k_j.  A count beyond the candidates raises
+// `miss`: every later kernel of the
 // pass leaves at once and the host redoes that item the plain way (do_draw_f).  Two launches per item on one stream (the
 // candidate normals, then this grid) instead of four dependent ones; no events.
 template <int RS_CAND>
