@@ -167,7 +167,7 @@ struct RsSpecArgs {
     int cand_limit;                  // counts >= this find no candidate (cand; smaller only through gpirt_debug_rs_cand_limit)
     int* err;
     int64_t n, ldl;
-    const double* L;
+    const double* Lt; int64_t nkb;   // L in 1 KiB tiles of 32 rows x 4 columns (launch_rs_tiles), nkb = rs_tile_quads(n) tiles per row group
     // slice sampler of item `ess_item` (< 0: none) on the candidate its predecessor's count picks (ess_first: candidate 0),
     // spread over the first ess_wgs work-groups of the grid (<= RS_ESS_WGS): they meet once per likelihood pass through
     // ess_cnt[ess_item] (zero when the pass over the items starts) and ess_partial[2][RS_ESS_WGS]
@@ -180,6 +180,9 @@ struct RsSpecArgs {
     double* cand_zc;                 // [n + 4][cand] candidate normals (k-major)
     double* cand_part;
 };
+inline int64_t rs_tile_quads(int64_t n) { return (n + 3) / 4 + 1; }
+inline size_t rs_tile_doubles(int64_t n) { return (size_t)((n + RS_ROWS - 1) / RS_ROWS) * (size_t)rs_tile_quads(n) * 128; }
+int launch_rs_tiles(hipStream_t stream, const double* L, int64_t n, int64_t ldl, double* Lt);
 int launch_rs_cand_normals(hipStream_t stream, const RsSpecArgs& a);
 int launch_rs_item(hipStream_t stream, const RsSpecArgs& a);      // ONE grid: work-group 0 = the slice sampler, the rest = the products
 int launch_ll_term_probe(hipStream_t stream, const double* a, int64_t n, double* out, bool fast);

@@ -169,6 +169,30 @@ __global__ __launch_bounds__(256) void rs_cand_normals_kernel(RsSpecArgs a)
     }
 }
 
+// L in the order the candidate products read it: tile (row group rg of 32 rows, column quad kb) = 1 KiB, lane l's two rows of
+// column 4 kb + (l >> 4) at doubles 2 l, 2 l + 1 -- the MFMA A operand of one step, so a wave's step is ONE contiguous
+// kilobyte and its steps follow each other in memory.  From column-major L the same step touches four 256-byte pieces
+// 64 KiB apart (a quarter of a DRAM page each): 3.55 TB/s.  Built once per iteration (a pass over the triangle: ~0.2 ms
+// against 1024 passes that read it); rows and columns past the matrix are zeros; only the tiles a product reads exist.
+__global__ __launch_bounds__(256) void rs_tile_kernel(const double* __restrict__ L, int64_t n, int64_t ldl, int64_t nkb, double* __restrict__ Lt)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+    const int64_t rg = blockIdx.y;
+    const int64_t r0 = rg * RS_ROWS;
+    const int64_t kall = (r0 + RS_ROWS < n) ? r0 + RS_ROWS : n;
+    const int64_t kb_end = (kall + 3) / 4;
+    const int64_t rp = r0 + 2 * (4 * (i & 3) + (i >> 2));
+    for (int64_t kb = (int64_t)blockIdx.x * 4 + wave; kb < kb_end; kb += (int64_t)gridDim.x * 4) {
+        const int64_t k = 4 * kb + g;
+        double2 v; v.x = 0.0; v.y = 0.0;
+        if (k < n) {
+            if (rp < n) v.x = L[rp + k * ldl];
+            if (rp + 1 < n) v.y = L[rp + 1 + k * ldl];
+        }
+        *reinterpret_cast<double2*>(Lt + (rg * nkb + kb) * 128 + 2 * lane) = v;
+    }
+}
+
 // part[s][c][row] = sum over columns [s KC, (s + 1) KC) of L[row][k] zc[k][c] for RS_ROWS = 32 rows: fp64 MFMA 16x16x4 with
 // A = 16 rows x 4 columns of L -- one 16-byte load per lane brings two rows (tiles t = 0, 1) -- and B = 4 x 16 candidates.
 // The four waves of a work-group take a quarter of the part's columns each (a wave's loads are a dependent chain of ~2.5 us
@@ -179,7 +203,7 @@ template <int RS_CAND>
 __device__ __forceinline__ void rs_product_block(const RsSpecArgs& a, const int bx, const int by, double* red /* 16 x 64 doubles */)
 {
     const int lane = threadIdx.x & 63, kq = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
-    const int64_t n = a.n, ldl = a.ldl;
+    const int64_t n = a.n;
     const int64_t r0 = (int64_t)bx * RS_ROWS;
     const int64_t kall = (r0 + RS_ROWS < n) ? r0 + RS_ROWS : n;       // columns that can be non-zero in these rows
     if ((int64_t)by * RS_KC >= kall) return;                  // (uniform over the work-group)
@@ -187,11 +211,9 @@ __device__ __forceinline__ void rs_product_block(const RsSpecArgs& a, const int 
     int64_t k_end = k_beg + RS_KC / 4;
     if (k_end > kall) k_end = kall;
     // The instruction returns row (g + 4 r) of the 16-row tile in element r of lane (i, g): A-lane i carries row pair
-    // pi(i) = 4 (i & 3) + (i >> 2), so that a lane ends up with EIGHT CONSECUTIVE rows, r0 + 8 g + 2 r + t (solve64.h uses the
-    // same permutation).  Clamped past the matrix: n is even, rows >= n are not stored.
-    int64_t rp = r0 + 2 * (4 * (i & 3) + (i >> 2));
-    if (rp > n - 2) rp = n - 2;
-    const double* Lp = a.L + rp;
+    // pi(i) = 4 (i & 3) + (i >> 2) (rs_tile_kernel), so that a lane ends up with EIGHT CONSECUTIVE rows, r0 + 8 g + 2 r + t
+    // (solve64.h uses the same permutation).  Rows >= n are zeros in the tiles and are not stored.
+    const double* Lp = a.Lt + ((int64_t)bx * a.nkb) * 128 + 2 * lane;      // tile (bx, kb) at + 128 kb (rs_tile_kernel)
     const double* Zp = a.cand_zc + i;
     constexpr int CT = RS_CAND / 16;                          // tiles of 16 candidates
     d4 acc[2][CT];
@@ -205,7 +227,7 @@ __device__ __forceinline__ void rs_product_block(const RsSpecArgs& a, const int 
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int64_t kk = k + 4 * u + g;
-            av[u] = *reinterpret_cast<const double2*>(Lp + kk * ldl);
+            av[u] = *reinterpret_cast<const double2*>(Lp + ((k >> 2) + u) * 128);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) b[u][ct] = Zp[kk * RS_CAND + 16 * ct];
         }
@@ -219,9 +241,7 @@ __device__ __forceinline__ void rs_product_block(const RsSpecArgs& a, const int 
     }
     for (; k < k_end; k += 4) {
         const int64_t kk = k + g;
-        const bool in = kk < n;                               // (columns past the matrix: zc has four zero rows of padding, L has none)
-        double2 av = *reinterpret_cast<const double2*>(Lp + (in ? kk : n - 1) * ldl);
-        if (!in) { av.x = 0.0; av.y = 0.0; }
+        const double2 av = *reinterpret_cast<const double2*>(Lp + (k >> 2) * 128);      // (past the matrix: zeros in the tile and in zc)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const double bb = Zp[kk * RS_CAND + 16 * ct];
@@ -551,6 +571,14 @@ int launch_ess(hipStream_t stream, const EssArgs& a)
         if (fast) hipLaunchKernelGGL(ess_kernel<true>, dim3((unsigned)a.m), dim3(256), 0, stream, a);
         else      hipLaunchKernelGGL(ess_kernel<false>, dim3((unsigned)a.m), dim3(256), 0, stream, a);
     }
+    GP_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_rs_tiles(hipStream_t stream, const double* L, int64_t n, int64_t ldl, double* Lt)
+{
+    const int64_t nrg = (n + RS_ROWS - 1) / RS_ROWS, nkb = rs_tile_quads(n);
+    hipLaunchKernelGGL(rs_tile_kernel, dim3(8, (unsigned)nrg), dim3(256), 0, stream, L, n, ldl, nkb, Lt);
     GP_HIP(hipGetLastError());
     return 0;
 }

@@ -105,6 +105,7 @@ struct gpirt_sampler_s {
     uint64_t* posv = nullptr;
     int *miss = nullptr, *h_miss = nullptr;
     unsigned long long* ess_cnt = nullptr; double* ess_partial = nullptr;
+    double* Lt = nullptr;             // L in the candidate products' tile order (rebuilt at the start of every draw_f)
     double *zc[2] = { nullptr, nullptr }, *cpart[2] = { nullptr, nullptr };
     // bookkeeping
     int iter = 0;                     // completed iterations
@@ -389,7 +390,7 @@ int do_draw_f(gpirt_sampler_s* s)
         a.U = s->U; a.pos = s->pos; a.cap = s->U_cap;
         return launch_ess(st, a);
     };
-    const bool spec = s->spec_ok && (s->ldl % 2 == 0) && (((uintptr_t)s->L & 15) == 0);      // (16-byte loads of two rows)
+    const bool spec = s->spec_ok;
     if (!spec) {
         for (int64_t j = 0; j < m; ++j) GP_TRY(plain_item(j));
         return 0;
@@ -397,11 +398,12 @@ int do_draw_f(gpirt_sampler_s* s)
     // Speculative form (rng_ess.hip): the grid that runs item j's slice loop also computes L z for the 32 places item j + 1's
     // normals can start at.  A slice loop longer than 31 rejections finds no candidate: the pass stops there (every later
     // kernel leaves at once), the host redoes that one item the plain way and starts the pipeline again behind it.
+    GP_TRY(launch_rs_tiles(st, s->L, n, s->ldl, s->Lt));
     int64_t j0 = 0;
     while (j0 < m) {
         RsSpecArgs a{};
         a.U = s->U; a.cap = s->U_cap; a.pos = s->pos; a.posv = s->posv; a.k_out = s->ess_k; a.miss = s->miss; a.err = s->flags;
-        a.n = n; a.ldl = s->ldl; a.L = s->L;
+        a.n = n; a.ldl = s->ldl; a.Lt = s->Lt; a.nkb = rs_tile_quads(n);
         a.cand = (n >= 6144) ? RS_CAND_MAX : 16;
         a.cand_limit = (h->rs_cand_limit > 0 && h->rs_cand_limit < a.cand) ? h->rs_cand_limit : a.cand;
         a.ess_wgs = (int)((n + 1023) / 1024 < RS_ESS_WGS ? (n + 1023) / 1024 : RS_ESS_WGS); a.ess_partial = s->ess_partial;
@@ -839,6 +841,7 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
         s->spec_ok = (n % 2 == 0) && n >= RS_SPEC_MIN_N;
         if (s->spec_ok) {
             const size_t parts = (size_t)((n + RS_KC - 1) / RS_KC);
+            GP_A(s->Lt, rs_tile_doubles(n));
             GP_A(s->posv, m + 1);    GP_A(s->miss, 2);    GP_A(s->ess_cnt, m);    GP_A(s->ess_partial, 2 * RS_ESS_WGS);
             for (int q = 0; q < 2; ++q) {
                 GP_A(s->zc[q], (size_t)(n + 4) * RS_CAND_MAX);
