@@ -149,42 +149,43 @@ struct EssArgs {
     int ll_exact;         // 1: log(1 + exp(-a)) through the library's exp and log, as written (GPIRT_LL_EXACT)
 };
 int launch_ess(hipStream_t stream, const EssArgs& a);
-// R-stream replay, speculative form (sampler.hip, do_draw_f): item j's nu = L z is taken from RS_CAND candidate vectors
-// that were computed while item j - 1's slice loop was still running -- one per possible length of that loop.
-constexpr int RS_CAND_MAX = 32;      // candidates per item: rejection counts 0 .. 31 of the item before (16 below n = 6144: the
-                                     // product is then bound by the candidates' own traffic, and a redone item costs little)
+// R-stream replay of draw_f, three items per pass over L (rng_ess.hip; sampler.hip, do_draw_f)
 constexpr int RS_KC = 1024;          // columns of L per part of a candidate product
 constexpr int RS_ROWS = 32;          // rows of L per work-group of a candidate product
 constexpr int RS_SPEC_MIN_N = 64;    // below: item by item, four launches each
-constexpr int RS_ESS_WGS = 8;        // work-groups (of 256 threads, 1024 rows each) one item's slice loop is spread over
-struct RsSpecArgs {
+constexpr int RS3_SLOTS = 3;         // items a pass can resolve
+constexpr int RS3_C1 = 15;           // slot 1: the item before consumed 0 .. 14 uniforms behind its first two
+constexpr int RS3_C2 = 32;           // slot 2: the two items before consumed 0 .. 31 together
+constexpr int RS3_CAND = 48;         // columns of a pass: [slot 0 | slot 1 x 15 | slot 2 x 32] = three 16-wide MFMA tiles
+constexpr int RS3_TRIALS = 8;        // trial points of a slice loop evaluated per meeting of the work-groups
+constexpr int RS3_MAX_WGS = 64;      // work-groups of the slice kernel (256 rows each, up to 4 rows per thread)
+constexpr int64_t RS3_MAX_N = (int64_t)RS3_MAX_WGS * 1024;
+struct Rs3Args {
     const double* U; uint64_t cap;   // the window of stream uniforms
+    double* Nrm;                     // Nrm[r] = rnorm(U[r], U[r + 1]) for r in [cursor at the start of draw_f, *nrm_end)
+    uint64_t* nrm_end;
     uint64_t* pos;                   // the cursor (start of the next unconsumed uniform)
     uint64_t* posv;                  // [m + 1]: where item j's normals start
     int* k_out;                      // [m]: rejection counts
-    int* miss;                       // != 0: item (miss - 1) found no candidate; every later kernel of the pass leaves at once
-    int cand;                        // 16 or RS_CAND_MAX: candidates per item in this round
-    int cand_limit;                  // counts >= this find no candidate (cand; smaller only through gpirt_debug_rs_cand_limit)
-    int* err;
-    int64_t n, ldl;
+    int* next_item;                  // the first item no pass has resolved yet (the next pass's anchor)
+    int* err;                        // != 0: every later kernel of the draw leaves at once
+    int64_t n, m;
     const double* Lt; int64_t nkb;   // L in 1 KiB tiles of 32 rows x 4 columns (launch_rs_tiles), nkb = rs_tile_quads(n) tiles per row group
-    // slice sampler of item `ess_item` (< 0: none) on the candidate its predecessor's count picks (ess_first: candidate 0),
-    // spread over the first ess_wgs work-groups of the grid (<= RS_ESS_WGS): they meet once per likelihood pass through
-    // ess_cnt[ess_item] (zero when the pass over the items starts) and ess_partial[2][RS_ESS_WGS]
-    int ess_item, ess_first, ess_wgs;
-    unsigned long long* ess_cnt; double* ess_partial;
-    double* ess_part;                // [parts][cand][n] parts of that item's candidate products
-    double* f; const double* y; const double* mu;
-    // candidates of item `cand_item` (< 0: none): normals (rs_cand_normals) and products (the other work-groups of rs_item)
-    int cand_item, cand_first;       // cand_first: the item has no predecessor in this pass, its normals start at the cursor
-    double* cand_zc;                 // [n + 4][cand] candidate normals (k-major)
-    double* cand_part;
+    double* part;                    // [parts][RS3_CAND][n] parts of the pass's candidate products
+    int lim1, lim2;                  // slots 1 / 2 take counts below these (RS3_C1 / RS3_C2; smaller only through gpirt_debug_rs_cand_limit)
+    double* f; const double* y; const double* mu;      // n x m
+    int wgs;                         // work-groups of the slice kernel: they meet through cnt (one word per pass, zero when the
+    unsigned long long* cnt;         //   draw starts) and partial[2][RS3_MAX_WGS][RS3_TRIALS + 1]
+    double* partial;
 };
 inline int64_t rs_tile_quads(int64_t n) { return (n + 3) / 4 + 1; }
 inline size_t rs_tile_doubles(int64_t n) { return (size_t)((n + RS_ROWS - 1) / RS_ROWS) * (size_t)rs_tile_quads(n) * 128; }
 int launch_rs_tiles(hipStream_t stream, const double* L, int64_t n, int64_t ldl, double* Lt);
-int launch_rs_cand_normals(hipStream_t stream, const RsSpecArgs& a);
-int launch_rs_item(hipStream_t stream, const RsSpecArgs& a);      // ONE grid: work-group 0 = the slice sampler, the rest = the products
+int launch_rs_unpack(hipStream_t stream, const uint32_t* raw, int64_t count, double* out);   // MT words -> unif_rand() values
+int launch_rs3_begin(hipStream_t stream, const Rs3Args& a, uint64_t span);   // Nrm over [cursor, cursor + span), anchor 0
+int launch_rs3_products(hipStream_t stream, const Rs3Args& a);
+int rs3_slice_wgs(int64_t n);
+int launch_rs3_slice(hipStream_t stream, const Rs3Args& a);
 int launch_ll_term_probe(hipStream_t stream, const double* a, int64_t n, double* out, bool fast);
 int launch_ll_bar(hipStream_t stream, const double* f, const double* y, const double* mu, int64_t n,
                   int64_t m, double* out);

@@ -146,27 +146,56 @@ __global__ __launch_bounds__(256) void ess_kernel(EssArgs a)
     }
 }
 
-// ---- R-stream replay, speculative form --------------------------------------------------------------------------------
-// Item j's normals start where item j - 1's slice loop stopped consuming, so nu_j = L z_j cannot be STARTED before that
-// loop ends -- but it has few possible values: z_j starts at  posv[j - 1] + 2n + 2 + k  for the rejection count k of item
-// j - 1, and a pass over L (268 MB at n = 8192: HBM-bound) costs the same for 32 right-hand sides as for one.  So ONE grid
-// per item runs item j's slice loop in its first work-groups and  L z  for the 32 candidates of item j + 1 in all the
-// others (16 below n = 6144, kernels.h); the slice loop of item j + 1 then picks column k_j.  A count beyond the candidates raises
-// `miss`: every later kernel of the
-// pass leaves at once and the host redoes that item the plain way (do_draw_f).  Two launches per item on one stream (the
-// candidate normals, then this grid) instead of four dependent ones; no events.
-template <int RS_CAND>
-__global__ __launch_bounds__(256) void rs_cand_normals_kernel(RsSpecArgs a)
+// ---- R-stream replay: three items per pass over L ---------------------------------------------------------------------
+// Item j's normals start where item j - 1's slice loop stopped consuming (src/draw-f.cpp:26,56), so nu_j = L z_j cannot be
+// STARTED before that loop ends -- but it has few possible values, and a pass over L (268 MB at n = 8192: HBM-bound) costs
+// nearly the same for 48 right-hand sides as for one.  R's inversion normal takes two consecutive uniforms
+// (src/mvnormal.h:8), so with  Nrm[r] = rnorm(U[r], U[r + 1])  computed ONCE per iteration for every position r of the
+// window (rs3_begin_kernel), the normals of an item that starts at position p are simply Nrm[p + 2 i]: every candidate is a
+// strided window of one array, nothing per candidate is ever materialised.
+// A pass is anchored at an item a whose start posv[a] is known exactly and serves THREE items (kernels.h, RS3_*):
+//   slot 0  item a          1 candidate            start  posv[a]
+//   slot 1  item a + 1     15 candidates  c = used(a) in 0..14            start  posv[a] + (2n + 2) + c
+//   slot 2  item a + 2     32 candidates  c = used(a) + used(a+1) in 0..31   start  posv[a] + 2 (2n + 2) + c
+// (used = uniforms the slice loop consumed behind its first two = its rejection count, src/draw-f.cpp:56): 48 columns = three
+// 16-wide MFMA tiles per step of L.  rs3_products_kernel computes the 48 products, rs3_slice_kernel then runs the three
+// slice loops one after the other, each on the column its predecessors' counts select, and leaves the next anchor.  A count
+// beyond a slot's candidates just ends the pass early -- the next pass is anchored at the first unresolved item -- so there is
+// no host round trip and no other path: the host enqueues ceil(m / 3) passes + a few spare ones (a pass that finds every
+// item done leaves at once) and looks at the item counter once at the end.
+//
+// The slice loop itself is evaluated RS3_TRIALS points at a time: a rejected point only moves the bracket end of its own
+// sign (src/draw-f.cpp:50-55), so the sequence of trial points is a function of the stream alone, not of the data -- the
+// likelihoods of the next eight points are one pass over the rows and ONE meeting of the work-groups instead of eight.
+
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y)
 {
-    if (*(volatile int*)a.miss != 0) return;
-    const uint64_t base = a.cand_first ? *a.pos : a.posv[a.cand_item - 1] + 2ull * (uint64_t)a.n + 2ull;
-    if (a.cand_first && blockIdx.x == 0 && threadIdx.x == 0) a.posv[a.cand_item] = base;
-    const int64_t total = a.n * RS_CAND;
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t i = g / RS_CAND; const int c = (int)(g - i * RS_CAND);
-        const uint64_t q = base + (uint64_t)c + 2ull * (uint64_t)i;
-        a.cand_zc[g] = (q + 1 < a.cap) ? rnorm_from_two(a.U[q], a.U[q + 1]) : 0.0;     // (past the window: the slice loop reports it)
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+// raw Mersenne-Twister words -> unif_rand() values (R's MT_genrand + fixup, RNG.c): the host only runs the recurrence
+__global__ void rs_unpack_kernel(const uint32_t* __restrict__ raw, int64_t count, double* __restrict__ out)
+{
+    const double i2_32m1 = 2.328306437080797e-10;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < count; g += (int64_t)gridDim.x * blockDim.x) {
+        const double v = (double)mt_temper(raw[g]) * 2.3283064365386963e-10;
+        out[g] = v <= 0.0 ? 0.5 * i2_32m1 : ((1.0 - v) <= 0.0 ? 1.0 - 0.5 * i2_32m1 : v);
     }
+}
+
+// Nrm[r] for the positions draw_f can reach from the cursor, the first anchor, the item counter
+__global__ __launch_bounds__(256) void rs3_begin_kernel(Rs3Args a, uint64_t span)
+{
+    const uint64_t p = *a.pos;
+    uint64_t end = p + span;
+    if (end + 1 > a.cap) end = a.cap > 0 ? a.cap - 1 : 0;      // Nrm[r] needs U[r + 1]
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *a.next_item = 0; a.posv[0] = p; *a.nrm_end = end; }
+    for (uint64_t r = p + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < end; r += (uint64_t)gridDim.x * blockDim.x)
+        a.Nrm[r] = rnorm_from_two(a.U[r], a.U[r + 1]);
 }
 
 // L in the order the candidate products read it: tile (row group rg of 32 rows, column quad kb) = 1 KiB, lane l's two rows of
@@ -193,14 +222,15 @@ __global__ __launch_bounds__(256) void rs_tile_kernel(const double* __restrict__
     }
 }
 
-// part[s][c][row] = sum over columns [s KC, (s + 1) KC) of L[row][k] zc[k][c] for RS_ROWS = 32 rows: fp64 MFMA 16x16x4 with
-// A = 16 rows x 4 columns of L -- one 16-byte load per lane brings two rows (tiles t = 0, 1) -- and B = 4 x 16 candidates.
-// The four waves of a work-group take a quarter of the part's columns each (a wave's loads are a dependent chain of ~2.5 us
-// round trips: short chains and many waves are what fills the memory system -- 128 rows x 1024 columns per wave ran at
-// 3 TB/s; 64 rows per wave with 32-byte loads, half as many waves, at 3.1), eight steps' loads in flight; the quarters meet
-// in LDS and are added in order.  The strict upper triangle of L holds zeros (gpirt_sampler_create).
-template <int RS_CAND>
-__device__ __forceinline__ void rs_product_block(const RsSpecArgs& a, const int bx, const int by, double* red /* 16 x 64 doubles */)
+// part[by][c][row] = sum over columns [by KC, (by + 1) KC) of L[row][k] z_c[k] for RS_ROWS = 32 rows and the pass's candidate
+// columns c (NT tiles of 16): fp64 MFMA 16x16x4 with A = 16 rows x 4 columns of L -- one 16-byte load per lane brings two
+// rows (tiles t = 0, 1) -- and B = 4 x 16 candidate normals, lane (i, g) reading  Nrm[start_c + 2 (k + g)]  for its
+// candidate c = 16 ct + i: the lanes of a tile touch ~22 consecutive doubles per step, all of them L2 / L1 hits (a pass reads
+// 3 (2n + 32) distinct normals).  The four waves of a work-group take a quarter of the part's columns each (a wave's loads are
+// a dependent chain of round trips: short chains and many waves are what fills the memory system), eight steps' loads in
+// flight; the quarters meet in LDS and are added in order.  The strict upper triangle of L holds zeros (gpirt_sampler_create).
+template <int NT>
+__device__ __forceinline__ void rs3_product_block(const Rs3Args& a, const uint64_t base, const int bx, const int by, double* red /* 8 NT x 64 doubles */)
 {
     const int lane = threadIdx.x & 63, kq = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     const int64_t n = a.n;
@@ -214,37 +244,40 @@ __device__ __forceinline__ void rs_product_block(const RsSpecArgs& a, const int 
     // pi(i) = 4 (i & 3) + (i >> 2) (rs_tile_kernel), so that a lane ends up with EIGHT CONSECUTIVE rows, r0 + 8 g + 2 r + t
     // (solve64.h uses the same permutation).  Rows >= n are zeros in the tiles and are not stored.
     const double* Lp = a.Lt + ((int64_t)bx * a.nkb) * 128 + 2 * lane;      // tile (bx, kb) at + 128 kb (rs_tile_kernel)
-    const double* Zp = a.cand_zc + i;
-    constexpr int CT = RS_CAND / 16;                          // tiles of 16 candidates
-    d4 acc[2][CT];
+    const uint64_t item_step = 2ull * (uint64_t)n + 2ull;
+    const double* Zp[NT];
+    Zp[0] = a.Nrm + (i == 0 ? base : base + item_step + (uint64_t)(i - 1)) + 2 * g;
+    if (NT > 1) {
+#pragma unroll
+        for (int ct = 1; ct < NT; ++ct) Zp[ct] = a.Nrm + base + 2ull * item_step + (uint64_t)(16 * (ct - 1) + i) + 2 * g;
+    }
+    d4 acc[2][NT];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) acc[t][ct] = d4{ 0.0, 0.0, 0.0, 0.0 };
+        for (int ct = 0; ct < NT; ++ct) acc[t][ct] = d4{ 0.0, 0.0, 0.0, 0.0 };
     int64_t k = k_beg;
     for (; k + 32 <= k_end; k += 32) {
-        double2 av[8]; double b[8][CT];
+        double2 av[8]; double b[8][NT];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int64_t kk = k + 4 * u + g;
             av[u] = *reinterpret_cast<const double2*>(Lp + ((k >> 2) + u) * 128);
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) b[u][ct] = Zp[kk * RS_CAND + 16 * ct];
+            for (int ct = 0; ct < NT; ++ct) b[u][ct] = Zp[ct][2 * (k + 4 * u)];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u)
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
+            for (int ct = 0; ct < NT; ++ct) {
                 acc[0][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u].x, b[u][ct], acc[0][ct], 0, 0, 0);
                 acc[1][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u].y, b[u][ct], acc[1][ct], 0, 0, 0);
             }
     }
     for (; k < k_end; k += 4) {
-        const int64_t kk = k + g;
-        const double2 av = *reinterpret_cast<const double2*>(Lp + (k >> 2) * 128);      // (past the matrix: zeros in the tile and in zc)
+        const double2 av = *reinterpret_cast<const double2*>(Lp + (k >> 2) * 128);      // (past the matrix: zeros in the tile)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            const double bb = Zp[kk * RS_CAND + 16 * ct];
+        for (int ct = 0; ct < NT; ++ct) {
+            const double bb = Zp[ct][2 * k];
             acc[0][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, bb, acc[0][ct], 0, 0, 0);
             acc[1][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, bb, acc[1][ct], 0, 0, 0);
         }
@@ -257,25 +290,25 @@ __device__ __forceinline__ void rs_product_block(const RsSpecArgs& a, const int 
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
+                for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) mine[((t * CT + ct) * 4 + r) * 64] = acc[t][ct][r];
+                    for (int r = 0; r < 4; ++r) mine[((t * NT + ct) * 4 + r) * 64] = acc[t][ct][r];
         }
         __syncthreads();
         if (kq == 0) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
+                for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[t][ct][r] += mine[((t * CT + ct) * 4 + r) * 64];
+                    for (int r = 0; r < 4; ++r) acc[t][ct][r] += mine[((t * NT + ct) * 4 + r) * 64];
         }
     }
     if (kq != 0) return;
     // lane (i, g): acc[t][ct][r] = row r0 + 2 pi(g + 4 r) + t = r0 + 8 g + 2 r + t, candidate 16 ct + i
-    double* out = a.cand_part + ((int64_t)by * RS_CAND) * n;
+    double* out = a.part + ((int64_t)by * RS3_CAND) * n;
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
+    for (int ct = 0; ct < NT; ++ct) {
         double* oc = out + (int64_t)(16 * ct + i) * n + r0 + 8 * g;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -287,168 +320,202 @@ __device__ __forceinline__ void rs_product_block(const RsSpecArgs& a, const int 
     }
 }
 
-// Sum of one value per thread over ALL the work-groups of the slice loop (pass = how many such sums came before): a block
-// sum, then the work-groups' sums meet in memory and every work-group adds them in the same order -- so all of them see
-// the same bits and take the same branches.  One lane publishes (agent-scope atomic store, then an add on the
-// counter) and polls; the poll is bounded like every in-kernel wait of this library (flagsync.h): on expiry the pass is
-// abandoned with GPIRT_E_HIP (as the panel kernel's guard is).  The work-groups are the FIRST of their grid on an otherwise idle stream: dispatched
-// together, before any of the product work-groups.  Returns false when the wait expired (uniform).
-__device__ __forceinline__ bool rs_sum_all(const RsSpecArgs& a, const int w, const int E, const int pass, const double v,
-                                           double* red, double& out)
+__global__ __launch_bounds__(256) void rs3_products_kernel(Rs3Args a)
 {
-    const double bs = block_sum_256(v, red);
-    if (E == 1) { out = bs; return true; }
-    double* slot = a.ess_partial + (pass & 1) * RS_ESS_WGS;
-    if (threadIdx.x == 0) {
-        // flagsync.h's form: the value is stored write-through at agent scope, the store is waited for, then the counter;
-        // the readers poll and read with agent-scope loads (served past the L1 and this XCD's L2) -- no release (it would
-        // write back every dirty line the product work-groups of this XCD have produced) and no acquire per poll
-        __hip_atomic_store(slot + w, bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(a.ess_cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long need = (unsigned long long)E * (unsigned long long)(pass + 1);
-        int spins = 0;
-        unsigned long long seen = __hip_atomic_load(a.ess_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (seen < need && ++spins < (1 << 22)) {
-            __builtin_amdgcn_s_sleep(1);
-            seen = __hip_atomic_load(a.ess_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        red[8] = (seen >= need) ? 1.0 : 0.0;
+    __shared__ double red[8 * 3 * 64];
+    if (*(volatile int*)a.err != 0) return;
+    const int item0 = *(volatile int*)a.next_item;
+    if (item0 >= (int)a.m) return;                            // every item is done: a spare pass
+    const uint64_t base = a.posv[item0];
+    const int nbx = (int)((a.n + RS_ROWS - 1) / RS_ROWS);
+    const int bx = (int)blockIdx.x % nbx, by = (int)blockIdx.x / nbx;
+    if ((int)a.m - item0 >= 3 && a.lim2 > 0) rs3_product_block<3>(a, base, bx, by, red);
+    else                                     rs3_product_block<1>(a, base, bx, by, red);     // the last items: slots 0 and 1 alone
+}
+
+// Sums of V values per thread over ALL the work-groups of the slice kernel (sync = how many such meetings came before in
+// this launch): wave sums, block sums, then the work-groups' sums meet in memory and every work-group adds them in the same
+// order -- so all of them see the same bits and take the same branches.  flagsync.h's form: the values are stored
+// write-through at agent scope by lanes of ONE wave, that wave waits for its stores, one lane adds to the counter and polls
+// it; readers use agent-scope loads (no release: nothing else of this kernel is shared, and no acquire per poll).  The poll is
+// bounded like every in-kernel wait of this library; the work-groups are the whole grid of a launch on an otherwise idle
+// stream, <= RS3_MAX_WGS of them, so they are resident together.  Returns false when the wait expired (uniform per block).
+template <int V>
+__device__ __forceinline__ bool rs3_sum_all(const Rs3Args& a, const int w, const int E, const int sync, const double* acc,
+                                            double* sh /* 5 V + 1 doubles */, double* tot)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();                                          // (sh is still being read from the meeting before)
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        double x = acc[v];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if (lane == 0) sh[wv * V + v] = x;
     }
     __syncthreads();
-    const bool ok = red[8] != 0.0;
-    double r = 0.0;
-    for (int q = 0; q < E; ++q) r += __hip_atomic_load(slot + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();                                          // (red is reused by the next block sum)
-    out = r;
-    return ok;
-}
-
-// ess() of ONE item (src/draw-f.cpp:21-60) on the candidate its predecessor's count selects, the formula as written (no
-// ll_fast: an R-stream replay keeps the reference's arithmetic).  On one compute unit the 2 + k likelihood passes over
-// 8192 rows take ~85 us -- as long as the products beside them -- so the rows are spread over E work-groups (1024 each, four
-// per thread, in registers) that meet once per pass (rs_sum_all).
-template <int RS_CAND>
-__device__ __forceinline__ void rs_ess_block(const RsSpecArgs& a, const int w, double* red)
-{
-    const int64_t n = a.n;
-    const int j = a.ess_item, E = a.ess_wgs;
-    const int kprev = a.ess_first ? 0 : a.k_out[j - 1];
-    if (kprev >= a.cand_limit) {
-        if (w == 0 && threadIdx.x == 0) *a.miss = j + 1;
-        return;
-    }
-    double* fj = a.f; const double* yj = a.y; const double* mj = a.mu;
-    const uint64_t p0 = a.posv[j] + 2ull * (uint64_t)n;                                // behind the n normals
-    const int64_t per = ((n + E - 1) / E + 255) / 256 * 256;                           // rows per work-group
-    const int64_t i0 = (int64_t)w * per, i1 = (i0 + per < n) ? i0 + per : n;
-    const bool in_regs = per <= 4 * 256;
-    // nu = the parts of candidate kprev, added in part order; kept in the first part's column (nobody else reads it)
-    double* nj = a.ess_part + (int64_t)kprev * n;
-    double F[4], V[4], M[4], Y[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { F[e] = 0.0; V[e] = 0.0; M[e] = 0.0; Y[e] = __builtin_nan(""); }
-    for (int64_t i = i0 + threadIdx.x, e = 0; i < i1; i += 256, e = (e + 1) & 3) {
-        const int64_t grp = (i / RS_ROWS) * RS_ROWS;
-        const int64_t kall = (grp + RS_ROWS < n) ? grp + RS_ROWS : n;
-        const int parts = (int)((kall + RS_KC - 1) / RS_KC);
-        double v = nj[i];
-        for (int q = 1; q < parts; ++q) v += a.ess_part[((int64_t)q * RS_CAND + kprev) * n + i];
-        if (in_regs) {
-#pragma unroll
-            for (int ee = 0; ee < 4; ++ee) if (ee == e) { V[ee] = v; F[ee] = fj[i]; M[ee] = mj[i]; Y[ee] = yj[i]; }
-        } else nj[i] = v;                                     // (own rows only: re-read by this work-group alone)
-    }
-    if (!in_regs) __syncthreads();
-    uint32_t uidx = 0;
-    int pass = 0;
-    bool overflow = false, nan_state = false, expired = false;
-    auto next_u = [&]() -> double {
-        const uint64_t q = p0 + uidx;
-        double u;
-        if (q >= a.cap) { overflow = true; u = 0.5; } else u = a.U[q];
-        ++uidx;
-        return u;
-    };
-    // log_y = ll_bar(f, y, mu) + log(u)                                   draw-f.cpp:28-29
-    double acc = 0.0, ll0, llp = 0.0;
-    if (in_regs) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) if (Y[e] == Y[e]) acc += ll_term(Y[e] * (F[e] + M[e]));
+    double bs = 0.0;
+    if (threadIdx.x < V) bs = (sh[threadIdx.x] + sh[V + threadIdx.x]) + (sh[2 * V + threadIdx.x] + sh[3 * V + threadIdx.x]);
+    if (E == 1) {
+        if (threadIdx.x < V) sh[4 * V + threadIdx.x] = bs;
+        if (threadIdx.x == 0) sh[5 * V] = 1.0;
+        __syncthreads();
     } else {
-        for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
-            const double yy = yj[i];
-            if (yy != yy) continue;
-            acc += ll_term(yy * (fj[i] + mj[i]));
-        }
-    }
-    if (!rs_sum_all(a, w, E, pass++, acc, red, ll0)) expired = true;
-    ll0 = -ll0;
-    const double u = next_u();
-    const double log_y = ll0 + log(u);
-    double eps_min = 0.0, eps_max = GP_2PI;                                // :33-34
-    double eps = eps_min + (eps_max - eps_min) * next_u();                 // :35
-    eps_min = eps - GP_2PI;                                                // :36
-    int k = 0;
-    double c = 1.0, s = 0.0;
-    while (!expired) {
-        c = cos(eps);
-        s = sin(eps);
-        acc = 0.0;
-        if (in_regs) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (Y[e] == Y[e]) acc += ll_term(Y[e] * ((F[e] * c + V[e] * s) + M[e]));     // :43
-        } else {
-            for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
-                const double yy = yj[i];
-                if (yy != yy) continue;
-                acc += ll_term(yy * ((fj[i] * c + nj[i] * s) + mj[i]));
+        double* slot = a.partial + (size_t)(sync & 1) * RS3_MAX_WGS * V;
+        if (wv == 0) {
+            if (lane < V) __hip_atomic_store(slot + w * V + lane, bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) {
+                __hip_atomic_fetch_add(a.cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long need = (unsigned long long)E * (unsigned long long)(sync + 1);
+                int spins = 0;
+                unsigned long long seen = __hip_atomic_load(a.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while (seen < need && ++spins < (1 << 22)) {
+                    __builtin_amdgcn_s_sleep(1);
+                    seen = __hip_atomic_load(a.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                sh[5 * V] = (seen >= need) ? 1.0 : 0.0;
             }
         }
-        if (!rs_sum_all(a, w, E, pass++, acc, red, llp)) { expired = true; break; }
-        llp = -llp;
-        if (llp > log_y) break;                                            // :45-47
-        if (llp != llp) { nan_state = true; break; }                       // NaN state: never accepts
-        if (eps < 0.0) eps_min = eps; else eps_max = eps;                  // :50-55
-        if (eps_min == eps_max) eps = eps_min;                             // R::runif(a,a) = a
-        else eps = eps_min + (eps_max - eps_min) * next_u();               // :56
-        ++k;
-        if (k >= ESS_MAX_TRIALS || overflow) { overflow = true; break; }
-    }
-    if (expired) {
-        if (threadIdx.x == 0 && a.err) atomicCAS(a.err, 0, (int)GPIRT_E_HIP);          // (reported like the panel kernel's guard)
-        return;
-    }
-    if (in_regs) {
-        for (int64_t i = i0 + threadIdx.x, e = 0; i < i1; i += 256, e = (e + 1) & 3) {
-#pragma unroll
-            for (int ee = 0; ee < 4; ++ee) if (ee == e) fj[i] = F[ee] * c + V[ee] * s;
+        __syncthreads();
+        if (threadIdx.x < V && sh[5 * V] != 0.0) {
+            double r = 0.0;
+            for (int q = 0; q < E; ++q) r += __hip_atomic_load(slot + q * V + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh[4 * V + threadIdx.x] = r;
         }
-    } else {
-        for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) fj[i] = fj[i] * c + nj[i] * s;
+        __syncthreads();
     }
-    if (w == 0 && threadIdx.x == 0) {
-        a.k_out[j] = k;
-        if (nan_state && a.err) atomicCAS(a.err, 0, (int)GPIRT_E_NUMERIC);
-        else if (overflow && a.err) atomicCAS(a.err, 0, (int)GPIRT_E_RNG);
-        a.posv[j + 1] = p0 + uidx;
-        *a.pos = p0 + uidx;
-    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) tot[v] = sh[4 * V + v];
+    return sh[5 * V] != 0.0;
 }
 
-// (forcing five work-groups per CU -- 96 registers, every wave of a pass at n = 8192 resident at once -- changed nothing at
-// n = 8192 and cost the slice loop spills at small n)
-template <int RS_CAND>
-__global__ __launch_bounds__(256) void rs_item_kernel(RsSpecArgs a)
+// ess() (src/draw-f.cpp:21-60) for the items of a pass, one after the other, the formula as written (no ll_fast: an R-stream
+// replay keeps the reference's arithmetic).  The rows are spread over the E work-groups of the launch, R per thread, in
+// registers; every work-group carries the same bracket state and takes the same branches.
+template <int R>
+__global__ __launch_bounds__(256) void rs3_slice_kernel(Rs3Args a)
 {
-    __shared__ double red[16 * 64];
-    if (*(volatile int*)a.miss != 0) return;
-    const int E = a.ess_item >= 0 ? a.ess_wgs : 0;
-    if ((int)blockIdx.x < E) { rs_ess_block<RS_CAND>(a, (int)blockIdx.x, red); return; }
-    if (a.cand_item < 0) return;
-    const int nbx = (int)((a.n + RS_ROWS - 1) / RS_ROWS);
-    const int id = (int)blockIdx.x - E;
-    rs_product_block<RS_CAND>(a, id % nbx, id / nbx, red);
+    constexpr int T = RS3_TRIALS, V = T + 1;
+    __shared__ double sh[5 * V + 1];
+    __shared__ double cs[2 * T];
+    const int tid = threadIdx.x, w = blockIdx.x, E = a.wgs;
+    const int64_t n = a.n;
+    if (*(volatile int*)a.err != 0) return;
+    const int item0 = *(volatile int*)a.next_item;
+    if (item0 >= (int)a.m) return;
+    const int ns = ((int)a.m - item0 < RS3_SLOTS) ? (int)a.m - item0 : RS3_SLOTS;
+    const uint64_t nrm_end = *a.nrm_end;
+    uint64_t start = a.posv[item0];
+    const int64_t i0 = (int64_t)w * (R * 256) + tid;
+    int usum = 0, resolved = 0, sync = 0, fail = 0;
+    for (int g = 0; g < ns; ++g) {
+        int col = 0;
+        if (g == 1) { if (usum >= a.lim1) break; col = 1 + usum; }
+        if (g == 2) { if (usum >= a.lim2) break; col = 16 + usum; }
+        const int64_t j = item0 + g;
+        // the item's 2n uniforms (all its normals were built) and its first two slice uniforms lie inside the window
+        if (start + 2ull * (uint64_t)n + 2ull > a.cap || start + 2ull * (uint64_t)(n - 1) >= nrm_end) { fail = GPIRT_E_RNG; break; }
+        double* fj = a.f + j * n; const double* yj = a.y + j * n; const double* mj = a.mu + j * n;
+        double F[R], Vn[R], M[R], Y[R];
+#pragma unroll
+        for (int e = 0; e < R; ++e) {
+            const int64_t i = i0 + 256 * e;
+            F[e] = 0.0; Vn[e] = 0.0; M[e] = 0.0; Y[e] = __builtin_nan("");      // NaN = skipped, like a missing response
+            if (i < n) {
+                // nu = the parts of column `col`, added in part order
+                const int64_t grp = (i / RS_ROWS) * RS_ROWS;
+                const int64_t kall = (grp + RS_ROWS < n) ? grp + RS_ROWS : n;
+                const int parts = (int)((kall + RS_KC - 1) / RS_KC);
+                double v = a.part[(int64_t)col * n + i];
+                for (int q = 1; q < parts; ++q) v += a.part[((int64_t)q * RS3_CAND + col) * n + i];
+                Vn[e] = v; F[e] = fj[i]; M[e] = mj[i]; Y[e] = yj[i];
+            }
+        }
+        const uint64_t p0 = start + 2ull * (uint64_t)n;                       // behind the n normals
+        uint32_t uidx = 0;
+        bool bad_u = false;
+        auto next_u = [&]() -> double {
+            const uint64_t q = p0 + uidx;
+            ++uidx;
+            if (q >= a.cap) { bad_u = true; return 0.5; }
+            return a.U[q];
+        };
+        const double u = next_u();                                             // draw-f.cpp:28
+        double eps_min = 0.0, eps_max = GP_2PI;                                // :33-34
+        double eps = eps_min + (eps_max - eps_min) * next_u();                 // :35
+        eps_min = eps - GP_2PI;                                                // :36
+        int k = 0;
+        double log_y = 0.0, c = 1.0, s = 0.0;
+        uint32_t uacc = 0;
+        bool first = true, done = false;
+        while (!done) {
+            // the next T trial points: each is what :50-56 makes of the one before, were it rejected
+            uint32_t Ut[T]; bool Bt[T];
+            double my_eps = 0.0;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                if (tid == t) my_eps = eps;
+                Ut[t] = uidx; Bt[t] = bad_u;
+                if (eps < 0.0) eps_min = eps; else eps_max = eps;              // :50-55
+                if (eps_min == eps_max) eps = eps_min;                         // R::runif(a, a) = a, nothing consumed
+                else eps = eps_min + (eps_max - eps_min) * next_u();           // :56
+            }
+            __syncthreads();                                                   // (cs is still being read from the round before)
+            if (tid < T) { cs[tid] = cos(my_eps); cs[T + tid] = sin(my_eps); }
+            __syncthreads();
+            double acc[V], tot[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[v] = 0.0;
+            if (first) {
+#pragma unroll
+                for (int e = 0; e < R; ++e) if (Y[e] == Y[e]) acc[0] += ll_term(Y[e] * (F[e] + M[e]));          // :29
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const double ct = cs[t], st = cs[T + t];
+#pragma unroll
+                for (int e = 0; e < R; ++e) if (Y[e] == Y[e]) acc[1 + t] += ll_term(Y[e] * ((F[e] * ct + Vn[e] * st) + M[e]));   // :43
+            }
+            if (!rs3_sum_all<V>(a, w, E, sync++, acc, sh, tot)) { fail = GPIRT_E_HIP; break; }
+            if (first) { log_y = -tot[0] + log(u); first = false; }            // :29
+            int hit = -1;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                if (hit < 0 && fail == 0) {
+                    const double llp = -tot[1 + t];
+                    if (llp > log_y) hit = t;                                  // :45-47
+                    else if (llp != llp) fail = GPIRT_E_NUMERIC;               // NaN state: never accepts
+                }
+            }
+            if (fail) break;
+            if (hit >= 0) {
+                bool bad = false;
+#pragma unroll
+                for (int t = 0; t < T; ++t) if (t == hit) { c = cs[t]; s = cs[T + t]; uacc = Ut[t]; bad = Bt[t]; }
+                if (bad) { fail = GPIRT_E_RNG; break; }
+                k += hit; done = true;
+            } else {
+                k += T;
+                if (bad_u) { fail = GPIRT_E_RNG; break; }
+                if (k >= ESS_MAX_TRIALS) { fail = GPIRT_E_NUMERIC; break; }
+            }
+        }
+        if (fail) break;
+#pragma unroll
+        for (int e = 0; e < R; ++e) {
+            const int64_t i = i0 + 256 * e;
+            if (i < n) fj[i] = F[e] * c + Vn[e] * s;
+        }
+        start = p0 + uacc;
+        usum += (int)uacc - 2;
+        ++resolved;
+        if (w == 0 && tid == 0) { a.k_out[j] = k; a.posv[j + 1] = start; }
+    }
+    if (tid == 0) {
+        if (fail) atomicCAS(a.err, 0, fail);                  // every later kernel of the pass leaves at once
+        else if (w == 0) { *a.next_item = item0 + resolved; *a.pos = start; }
+    }
 }
 
 // Register-resident variant for n <= NTH * EPT: each lane keeps its EPT entries of f, nu, mu and y in
@@ -583,23 +650,43 @@ int launch_rs_tiles(hipStream_t stream, const double* L, int64_t n, int64_t ldl,
     return 0;
 }
 
-int launch_rs_cand_normals(hipStream_t stream, const RsSpecArgs& a)
+int launch_rs_unpack(hipStream_t stream, const uint32_t* raw, int64_t count, double* out)
 {
-    int64_t blocks = (a.n * a.cand + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    if (a.cand == 16) hipLaunchKernelGGL(rs_cand_normals_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
-    else              hipLaunchKernelGGL(rs_cand_normals_kernel<RS_CAND_MAX>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    if (count <= 0) return 0;
+    int64_t blocks = (count + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(rs_unpack_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, raw, count, out);
     GP_HIP(hipGetLastError());
     return 0;
 }
 
-int launch_rs_item(hipStream_t stream, const RsSpecArgs& a)
+int launch_rs3_begin(hipStream_t stream, const Rs3Args& a, uint64_t span)
+{
+    hipLaunchKernelGGL(rs3_begin_kernel, dim3(2048), dim3(256), 0, stream, a, span);
+    GP_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_rs3_products(hipStream_t stream, const Rs3Args& a)
 {
     const unsigned nbx = (unsigned)((a.n + RS_ROWS - 1) / RS_ROWS), parts = (unsigned)((a.n + RS_KC - 1) / RS_KC);
-    const unsigned grid = (a.ess_item >= 0 ? (unsigned)a.ess_wgs : 0u) + (a.cand_item >= 0 ? nbx * parts : 0u);
-    if (grid == 0) return 0;
-    if (a.cand == 16) hipLaunchKernelGGL(rs_item_kernel<16>, dim3(grid), dim3(256), 0, stream, a);
-    else              hipLaunchKernelGGL(rs_item_kernel<RS_CAND_MAX>, dim3(grid), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(rs3_products_kernel, dim3(nbx * parts), dim3(256), 0, stream, a);
+    GP_HIP(hipGetLastError());
+    return 0;
+}
+
+int rs3_slice_wgs(int64_t n) { const int64_t e = (n + 255) / 256; return (int)(e < RS3_MAX_WGS ? e : RS3_MAX_WGS); }
+
+int launch_rs3_slice(hipStream_t stream, const Rs3Args& a)
+{
+    const int rows = (int)((a.n + (int64_t)a.wgs * 256 - 1) / ((int64_t)a.wgs * 256));     // per thread
+    switch (rows) {
+    case 1: hipLaunchKernelGGL(rs3_slice_kernel<1>, dim3((unsigned)a.wgs), dim3(256), 0, stream, a); break;
+    case 2: hipLaunchKernelGGL(rs3_slice_kernel<2>, dim3((unsigned)a.wgs), dim3(256), 0, stream, a); break;
+    case 3: hipLaunchKernelGGL(rs3_slice_kernel<3>, dim3((unsigned)a.wgs), dim3(256), 0, stream, a); break;
+    case 4: hipLaunchKernelGGL(rs3_slice_kernel<4>, dim3((unsigned)a.wgs), dim3(256), 0, stream, a); break;
+    default: set_error("R-stream replay: n = %lld is beyond the slice kernel's %d rows", (long long)a.n, RS3_MAX_WGS * 1024); return GPIRT_E_ARG;
+    }
     GP_HIP(hipGetLastError());
     return 0;
 }

@@ -59,6 +59,17 @@ struct RStream {
             mti += take; dst += take; count -= (uint64_t)take;
         }
     }
+    // the same draws as raw state words: unif() = fixup(temper(word)), left to the consumer (the device, rs_unpack_kernel)
+    void fill_raw(uint32_t* dst, uint64_t count)
+    {
+        while (count) {
+            if (mti >= 624) refresh();
+            const uint64_t left = (uint64_t)(624 - mti);
+            const uint64_t take = left < count ? left : count;
+            memcpy(dst, mt + mti, (size_t)take * sizeof(uint32_t));
+            mti += (int)take; dst += take; count -= take;
+        }
+    }
     // the state `count` draws further on, without producing them
     void skip(uint64_t count)
     {

@@ -97,16 +97,19 @@ struct gpirt_sampler_s {
     bool ahead_attached = false;
     uint64_t ahead_gen = 0, ahead_used = 0, a_len = 0;
     std::vector<std::pair<uint64_t, RStream>> snaps;
-    double *hA = nullptr, *S = nullptr, *U2 = nullptr;
+    uint32_t *hA = nullptr, *Sraw = nullptr;      // the FIFO as the host produces it: raw Mersenne-Twister words (pinned / device)
+    double *S = nullptr, *U2 = nullptr;
     hipStream_t cs = nullptr;
     hipEvent_t ev_up = nullptr, ev_asm = nullptr;
-    // speculative draw_f of the replay (rng_ess.hip): one grid per item = its slice loop + the NEXT item's candidate products
+    // draw_f of the replay, three items per pass over L (rng_ess.hip): Nrm = the normal that starts at every position of the
+    // window, rs_part = the parts of a pass's 48 candidate products, next_item = the first item no pass has resolved yet
     bool spec_ok = false;
-    uint64_t* posv = nullptr;
-    int *miss = nullptr, *h_miss = nullptr;
-    unsigned long long* ess_cnt = nullptr; double* ess_partial = nullptr;
+    uint64_t *posv = nullptr, *nrm_end = nullptr;
+    int *next_item = nullptr, *h_next = nullptr;
+    unsigned long long* rs_cnt = nullptr; double* rs_partial = nullptr;
     double* Lt = nullptr;             // L in the candidate products' tile order (rebuilt at the start of every draw_f)
-    double *zc[2] = { nullptr, nullptr }, *cpart[2] = { nullptr, nullptr };
+    double *Nrm = nullptr, *rs_part = nullptr;
+    int64_t rs_passes_cap = 0;        // words of rs_cnt (one per pass of a draw)
     // bookkeeping
     int iter = 0;                     // completed iterations
     bool initialised = false;
@@ -143,14 +146,17 @@ inline bool stream_mode(const gpirt_sampler_s* s) { return s->opt.rng_kind == GP
 int report_degenerate_theta(gpirt_sampler_s* s, int count);
 
 // ---- R-stream window ---------------------------------------------------------------------------
-// draws [ahead_gen, ahead_gen + count) of the attached generator into dst, a state snapshot every 2^16 draws
-void ahead_generate(gpirt_sampler_s* s, double* dst, uint64_t count)
+// draws [ahead_gen, ahead_gen + count) of the attached generator into dst, a state snapshot every 2^16 draws.  The host
+// only runs the Mersenne-Twister recurrence (0.85 ns per word on one core: 16 ms for the 18.8 M draws of an iteration at
+// 8192 x 1024); tempering and the conversion to unif_rand()'s double happen on the device (rs_unpack_kernel) -- done on the
+// host they were three quarters of the 70 ms this took, more than the device needs for the whole iteration.
+void ahead_generate(gpirt_sampler_s* s, uint32_t* dst, uint64_t count)
 {
     constexpr uint64_t EVERY = 1ull << 16;
     while (count) {
         const uint64_t c = count < EVERY ? count : EVERY;
         s->snaps.emplace_back(s->ahead_gen, *s->rs);
-        s->rs->fill_unif(dst, c);
+        s->rs->fill_raw(dst, c);
         s->ahead_gen += c; dst += c; count -= c;
     }
 }
@@ -184,9 +190,13 @@ int stream_begin(gpirt_sampler_s* s, uint64_t count)
         if (s->rs_obj->owner && s->rs_obj->owner != s) rstream_sync(s->rs_obj);     // another sampler runs ahead on this stream
         s->snaps.clear();
         s->ahead_gen = s->ahead_used = s->a_len = 0;
-        ahead_generate(s, s->hU, count);
-        GP_HIP(hipMemcpyAsync(s->U, s->hU, count * sizeof(double), hipMemcpyHostToDevice, st));
+        GP_HIP(hipEventSynchronize(s->ev_up));                // (an earlier upload may still be reading hA)
+        ahead_generate(s, s->hA, count);
+        GP_HIP(hipStreamWaitEvent(st, s->ev_up, 0));          // (... or unpacking Sraw on the copy stream)
+        GP_HIP(hipMemcpyAsync(s->Sraw, s->hA, count * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        GP_TRY(launch_rs_unpack(st, s->Sraw, (int64_t)count, s->U));
         GP_HIP(hipEventRecord(s->ev_asm, st));
+        GP_HIP(hipEventRecord(s->ev_up, st));                 // (hA and Sraw are free again when this has run)
         s->ahead_attached = true;
         s->rs_obj->owner = s; s->rs_obj->resolve = ahead_resolve;
     }                                                         // (otherwise stream_end has already put the window together)
@@ -205,7 +215,8 @@ int ahead_topup(gpirt_sampler_s* s, uint64_t count)
     GP_HIP(hipEventSynchronize(s->ev_up));                    // the previous upload has left hA
     ahead_generate(s, s->hA + s->a_len, need);
     GP_HIP(hipStreamWaitEvent(s->cs, s->ev_asm, 0));          // the last assembly has finished moving S's leftover
-    GP_HIP(hipMemcpyAsync(s->S + s->a_len, s->hA + s->a_len, need * sizeof(double), hipMemcpyHostToDevice, s->cs));
+    GP_HIP(hipMemcpyAsync(s->Sraw + s->a_len, s->hA + s->a_len, need * sizeof(uint32_t), hipMemcpyHostToDevice, s->cs));
+    GP_TRY(launch_rs_unpack(s->cs, s->Sraw + s->a_len, (int64_t)need, s->S + s->a_len));
     GP_HIP(hipEventRecord(s->ev_up, s->cs));
     s->a_len = count;
     return 0;
@@ -245,8 +256,7 @@ int stream_end(gpirt_sampler_s* s, uint64_t count)
     GP_HIP(hipEventRecord(s->ev_asm, st));
     std::swap(s->U, s->U2);
     GP_HIP(hipEventSynchronize(s->ev_up));
-    if (rem) memmove(s->hA, s->hA + used, rem * sizeof(double));
-    s->a_len = rem;
+    s->a_len = rem;                                           // (the host copy of the FIFO is never read again: nothing to move)
     // snapshots below the consumed position are never needed again (all but the last of them)
     size_t keep = 0;
     for (size_t q = 0; q < s->snaps.size(); ++q) if (s->snaps[q].first <= s->ahead_used) keep = q;
@@ -395,38 +405,43 @@ int do_draw_f(gpirt_sampler_s* s)
         for (int64_t j = 0; j < m; ++j) GP_TRY(plain_item(j));
         return 0;
     }
-    // Speculative form (rng_ess.hip): the grid that runs item j's slice loop also computes L z for the 32 places item j + 1's
-    // normals can start at.  A slice loop longer than 31 rejections finds no candidate: the pass stops there (every later
-    // kernel leaves at once), the host redoes that one item the plain way and starts the pipeline again behind it.
+    // Three items per pass over L (rng_ess.hip): a pass is anchored at the first item whose start is known, computes L z for
+    // the one place its normals start at and for the 15 + 32 places the next two items' normals can start at, and runs the
+    // three slice loops; a slice loop that ran longer than its successors' candidates reach just ends the pass early.  All of
+    // it is device-side state (next_item, posv): the host enqueues ceil(m / 3) passes and a few spare ones -- a pass that finds
+    // every item done leaves at once -- and reads the item counter back once.
     GP_TRY(launch_rs_tiles(st, s->L, n, s->ldl, s->Lt));
-    int64_t j0 = 0;
-    while (j0 < m) {
-        RsSpecArgs a{};
-        a.U = s->U; a.cap = s->U_cap; a.pos = s->pos; a.posv = s->posv; a.k_out = s->ess_k; a.miss = s->miss; a.err = s->flags;
-        a.n = n; a.ldl = s->ldl; a.Lt = s->Lt; a.nkb = rs_tile_quads(n);
-        a.cand = (n >= 6144) ? RS_CAND_MAX : 16;
-        a.cand_limit = (h->rs_cand_limit > 0 && h->rs_cand_limit < a.cand) ? h->rs_cand_limit : a.cand;
-        a.ess_wgs = (int)((n + 1023) / 1024 < RS_ESS_WGS ? (n + 1023) / 1024 : RS_ESS_WGS); a.ess_partial = s->ess_partial;
-        GP_HIP(hipMemsetAsync(s->ess_cnt, 0, sizeof(unsigned long long) * (size_t)m, st));
-        for (int64_t j = j0 - 1; j < m; ++j) {                // (j0 - 1: the first item's candidates alone)
-            RsSpecArgs g = a;
-            g.ess_item = (j >= j0) ? (int)j : -1; g.ess_first = (j == j0) ? 1 : 0;
-            g.cand_item = (j + 1 < m) ? (int)(j + 1) : -1; g.cand_first = (j + 1 == j0) ? 1 : 0;
-            if (g.ess_item >= 0) { g.ess_cnt = s->ess_cnt + j; g.ess_part = s->cpart[j & 1]; g.f = s->f + j * n; g.y = s->y + j * n; g.mu = s->mu + j * n; }
-            if (g.cand_item >= 0) {
-                g.cand_zc = s->zc[(j + 1) & 1]; g.cand_part = s->cpart[(j + 1) & 1];
-                GP_TRY(launch_rs_cand_normals(st, g));        // (reads posv[j]: item j - 1's slice loop wrote it in the grid before)
-            }
-            GP_TRY(launch_rs_item(st, g));
+    Rs3Args a{};
+    a.U = s->U; a.cap = s->U_cap; a.Nrm = s->Nrm; a.nrm_end = s->nrm_end; a.pos = s->pos; a.posv = s->posv; a.k_out = s->ess_k;
+    a.next_item = s->next_item; a.err = s->flags; a.n = n; a.m = m; a.Lt = s->Lt; a.nkb = rs_tile_quads(n); a.part = s->rs_part;
+    a.lim1 = RS3_C1; a.lim2 = RS3_C2;
+    if (h->rs_cand_limit > 0) {
+        if (h->rs_cand_limit < a.lim1) a.lim1 = h->rs_cand_limit;
+        if (h->rs_cand_limit < a.lim2) a.lim2 = h->rs_cand_limit;
+    }
+    a.f = s->f; a.y = s->y; a.mu = s->mu; a.wgs = rs3_slice_wgs(n); a.partial = s->rs_partial;
+    GP_HIP(hipMemsetAsync(s->rs_cnt, 0, sizeof(unsigned long long) * (size_t)s->rs_passes_cap, st));
+    // the normals draw_f can reach: m items of 2n + 2 uniforms + their rejections (the window's own slack, stream_window)
+    GP_TRY(launch_rs3_begin(st, a, (uint64_t)m * (2ull * (uint64_t)n + 2ull) + 512ull * (uint64_t)m + 4096ull));
+    int64_t pass = 0, done = 0;
+    bool topped = false;
+    while (done < m) {
+        const int64_t left = m - done;
+        int64_t count = (left + RS3_SLOTS - 1) / RS3_SLOTS + left / 40 + 2;
+        if (pass + count > s->rs_passes_cap) count = s->rs_passes_cap - pass;
+        if (count <= 0) { set_error("R-stream replay: draw_f made no progress"); return GPIRT_E_NUMERIC; }   // (a pass resolves >= 1 item)
+        for (int64_t q = 0; q < count; ++q, ++pass) {
+            a.cnt = s->rs_cnt + pass;
+            GP_TRY(launch_rs3_products(st, a));
+            GP_TRY(launch_rs3_slice(st, a));
         }
-        GP_HIP(hipMemcpyAsync(s->h_miss, s->miss, sizeof(int), hipMemcpyDeviceToHost, st));
-        if (s->stream_open) GP_TRY(ahead_topup(s, stream_window(s)));     // the next window's uniforms, while the items run
+        GP_HIP(hipMemcpyAsync(s->h_next, s->next_item, sizeof(int), hipMemcpyDeviceToHost, st));
+        GP_HIP(hipMemcpyAsync(s->h_next + 1, s->flags, sizeof(int), hipMemcpyDeviceToHost, st));
+        if (s->stream_open && !topped) { GP_TRY(ahead_topup(s, stream_window(s))); topped = true; }     // the next window's uniforms, while the items run
         GP_HIP(hipStreamSynchronize(st));
-        if (*s->h_miss == 0) break;
-        const int64_t jm = (int64_t)*s->h_miss - 1;           // items < jm are done, the cursor stands at item jm's normals
-        GP_HIP(hipMemsetAsync(s->miss, 0, sizeof(int), st));
-        GP_TRY(plain_item(jm));
-        j0 = jm + 1;
+        if (s->h_next[1] != 0) break;                         // (an error flag: stream_end / check report it)
+        if (s->h_next[0] <= done) { set_error("R-stream replay: draw_f made no progress"); return GPIRT_E_NUMERIC; }
+        done = s->h_next[0];
     }
     return 0;
 }
@@ -835,28 +850,29 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
         s->U_cap = stream_window(s);
         const uint64_t init_need = (uint64_t)m * 2 * (uint64_t)n + 4 * (uint64_t)m + 2 * (uint64_t)N * m + 64;
         if (init_need > s->U_cap) s->U_cap = init_need;
-        GP_A(s->U, s->U_cap);       GP_A(s->U2, s->U_cap);      GP_A(s->S, s->U_cap);
+        GP_A(s->U, s->U_cap);       GP_A(s->U2, s->U_cap);      GP_A(s->S, s->U_cap);      GP_A(s->Sraw, s->U_cap);
         GP_A(s->pos, 2);
-        // speculative draw_f: two sets of candidate buffers (items alternate)
-        s->spec_ok = (n % 2 == 0) && n >= RS_SPEC_MIN_N;
+        // draw_f, three items per pass (rng_ess.hip)
+        s->spec_ok = n >= RS_SPEC_MIN_N && n <= RS3_MAX_N;
         if (s->spec_ok) {
             const size_t parts = (size_t)((n + RS_KC - 1) / RS_KC);
+            const size_t nrm = (size_t)s->U_cap + 6 * (size_t)n + 128;        // (the products read up to 6n + 39 past an anchor)
+            s->rs_passes_cap = m + 64;
             GP_A(s->Lt, rs_tile_doubles(n));
-            GP_A(s->posv, m + 1);    GP_A(s->miss, 2);    GP_A(s->ess_cnt, m);    GP_A(s->ess_partial, 2 * RS_ESS_WGS);
-            for (int q = 0; q < 2; ++q) {
-                GP_A(s->zc[q], (size_t)(n + 4) * RS_CAND_MAX);
-                GP_A(s->cpart[q], parts * RS_CAND_MAX * (size_t)n);
-                hipMemsetAsync(s->zc[q], 0, sizeof(double) * (size_t)(n + 4) * RS_CAND_MAX, st);
-            }
-            hipMemsetAsync(s->miss, 0, 2 * sizeof(int), st);
+            GP_A(s->posv, m + 1);    GP_A(s->next_item, 2);    GP_A(s->nrm_end, 2);
+            GP_A(s->rs_cnt, s->rs_passes_cap);    GP_A(s->rs_partial, 2 * RS3_MAX_WGS * (RS3_TRIALS + 1));
+            GP_A(s->Nrm, nrm);       GP_A(s->rs_part, parts * RS3_CAND * (size_t)n);
+            hipMemsetAsync(s->Nrm, 0, sizeof(double) * nrm, st);              // (positions no draw has filled are read, never used)
+            hipMemsetAsync(s->rs_part, 0, sizeof(double) * parts * RS3_CAND * (size_t)n, st);
+            hipMemsetAsync(s->next_item, 0, 2 * sizeof(int), st);
         }
         GP_A(s->beta_off, m);
         GP_A(s->fstar_off, N + 8);
         if (hipHostMalloc(&s->hU, s->U_cap * sizeof(double), hipHostMallocDefault) != hipSuccess ||
-            hipHostMalloc(&s->hA, s->U_cap * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc(&s->hA, s->U_cap * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
             hipHostMalloc(&s->h_pos, 2 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess ||
             hipStreamCreateWithFlags(&s->cs, hipStreamNonBlocking) != hipSuccess ||
-            hipHostMalloc(&s->h_miss, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc(&s->h_next, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
             hipEventCreateWithFlags(&s->ev_up, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s->ev_asm, hipEventDisableTiming) != hipSuccess) {
             set_error("pinned allocation for the R-stream window failed");
@@ -954,7 +970,7 @@ int gpirt_sampler_destroy(gpirt_sampler_t s)
     if (s->h) hipStreamSynchronize(s->h->stream);
     if (s->rs_obj && s->rs_obj->owner == s) ahead_resolve(s, false);     // the caller's generator goes back to the consumed position
     if (s->cs) { hipStreamSynchronize(s->cs); hipStreamDestroy(s->cs); }
-    if (s->h_miss) hipHostFree(s->h_miss);
+    if (s->h_next) hipHostFree(s->h_next);
     if (s->ev_up) hipEventDestroy(s->ev_up);
     if (s->ev_asm) hipEventDestroy(s->ev_asm);
     if (s->hA) hipHostFree(s->hA);
