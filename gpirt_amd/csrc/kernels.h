@@ -150,7 +150,7 @@ struct EssArgs {
 };
 int launch_ess(hipStream_t stream, const EssArgs& a);
 // R-stream replay of draw_f, three items per pass over L (rng_ess.hip; sampler.hip, do_draw_f)
-constexpr int RS_KC = 1024;          // columns of L per part of a candidate product
+constexpr int RS_KC = 512;           // columns of L per part of a candidate product (one work-group: four waves x 128 columns)
 constexpr int RS_ROWS = 32;          // rows of L per work-group of a candidate product
 constexpr int RS_SPEC_MIN_N = 64;    // below: item by item, four launches each
 constexpr int RS3_SLOTS = 3;         // items a pass can resolve
@@ -158,25 +158,30 @@ constexpr int RS3_C1 = 15;           // slot 1: the item before consumed 0 .. 14
 constexpr int RS3_C2 = 32;           // slot 2: the two items before consumed 0 .. 31 together
 constexpr int RS3_CAND = 48;         // columns of a pass: [slot 0 | slot 1 x 15 | slot 2 x 32] = three 16-wide MFMA tiles
 constexpr int RS3_TRIALS = 8;        // trial points of a slice loop evaluated per meeting of the work-groups
-constexpr int RS3_MAX_WGS = 64;      // work-groups of the slice kernel (256 rows each, up to 4 rows per thread)
-constexpr int64_t RS3_MAX_N = (int64_t)RS3_MAX_WGS * 1024;
+constexpr int RS3_MAX_WGS = 256;     // work-groups of the slice kernel (32 R rows each, R <= 8 rows per thread)
+constexpr int64_t RS3_MAX_N = (int64_t)RS3_MAX_WGS * 256;
+constexpr int RS3_LDS_DOUBLES = 3 * 8 * 3 * 64;     // products: the three Nrm windows of a part (5 RS_KC + 48), then three waves' accumulators
+static_assert(5 * RS_KC + 48 <= RS3_LDS_DOUBLES, "the windows must fit");
 struct Rs3Args {
     const double* U; uint64_t cap;   // the window of stream uniforms
     double* Nrm;                     // Nrm[r] = rnorm(U[r], U[r + 1]) for r in [cursor at the start of draw_f, *nrm_end)
-    uint64_t* nrm_end;
+    uint64_t* anchor;                // [0] the first item no pass has resolved yet (m: all done, or the draw has failed)  [1] where
+                                     //   its normals start  [2] the end of Nrm -- one 32-byte record, read once per work-group
     uint64_t* pos;                   // the cursor (start of the next unconsumed uniform)
     uint64_t* posv;                  // [m + 1]: where item j's normals start
     int* k_out;                      // [m]: rejection counts
-    int* next_item;                  // the first item no pass has resolved yet (the next pass's anchor)
-    int* err;                        // != 0: every later kernel of the draw leaves at once
+    int* err;                        // the draw's error flag (the failing kernel also closes the anchor)
     int64_t n, m;
     const double* Lt; int64_t nkb;   // L in 1 KiB tiles of 32 rows x 4 columns (launch_rs_tiles), nkb = rs_tile_quads(n) tiles per row group
     double* part;                    // [parts][RS3_CAND][n] parts of the pass's candidate products
+    const uint32_t* units;           // the products' work-groups: (row group bx) | (part by) << 16, the nfull full parts first
+    int nunits, nfull;
     int lim1, lim2;                  // slots 1 / 2 take counts below these (RS3_C1 / RS3_C2; smaller only through gpirt_debug_rs_cand_limit)
     double* f; const double* y; const double* mu;      // n x m
-    int wgs;                         // work-groups of the slice kernel: they meet through cnt (one word per pass, zero when the
-    unsigned long long* cnt;         //   draw starts) and partial[2][RS3_MAX_WGS][RS3_TRIALS + 1]
-    double* partial;
+    // the slice kernel's work-groups meet through partial[2][RS3_MAX_WGS][RS3_TRIALS + 1] and flags[2][RS3_MAX_WGS]: a
+    // work-group raises its flag to the meeting's tag = tag + (meetings before it in this launch); the host hands every
+    // launch a range of 2^20 tags above all earlier ones, so nothing is ever reset
+    double* partial; unsigned long long* flags; uint64_t tag;
 };
 inline int64_t rs_tile_quads(int64_t n) { return (n + 3) / 4 + 1; }
 inline size_t rs_tile_doubles(int64_t n) { return (size_t)((n + RS_ROWS - 1) / RS_ROWS) * (size_t)rs_tile_quads(n) * 128; }
@@ -184,7 +189,9 @@ int launch_rs_tiles(hipStream_t stream, const double* L, int64_t n, int64_t ldl,
 int launch_rs_unpack(hipStream_t stream, const uint32_t* raw, int64_t count, double* out);   // MT words -> unif_rand() values
 int launch_rs3_begin(hipStream_t stream, const Rs3Args& a, uint64_t span);   // Nrm over [cursor, cursor + span), anchor 0
 int launch_rs3_products(hipStream_t stream, const Rs3Args& a);
+void rs3_unit_table(int64_t n, std::vector<uint32_t>& units, int* nfull);
 int rs3_slice_wgs(int64_t n);
+int rs3_slice_rows(int64_t n);
 int launch_rs3_slice(hipStream_t stream, const Rs3Args& a);
 int launch_ll_term_probe(hipStream_t stream, const double* a, int64_t n, double* out, bool fast);
 int launch_ll_bar(hipStream_t stream, const double* f, const double* y, const double* mu, int64_t n,

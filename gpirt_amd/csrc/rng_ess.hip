@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void rs3_begin_kernel(Rs3Args a, uint64_t span
     const uint64_t p = *a.pos;
     uint64_t end = p + span;
     if (end + 1 > a.cap) end = a.cap > 0 ? a.cap - 1 : 0;      // Nrm[r] needs U[r + 1]
-    if (blockIdx.x == 0 && threadIdx.x == 0) { *a.next_item = 0; a.posv[0] = p; *a.nrm_end = end; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { a.anchor[0] = 0; a.anchor[1] = p; a.anchor[2] = end; a.posv[0] = p; }
     for (uint64_t r = p + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < end; r += (uint64_t)gridDim.x * blockDim.x)
         a.Nrm[r] = rnorm_from_two(a.U[r], a.U[r + 1]);
 }
@@ -257,16 +257,16 @@ __device__ __forceinline__ void rs3_product_block(const Rs3Args& a, const uint64
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) acc[t][ct] = d4{ 0.0, 0.0, 0.0, 0.0 };
     int64_t k = k_beg;
-    for (; k + 32 <= k_end; k += 32) {
-        double2 av[8]; double b[8][NT];
+    for (; k + 16 <= k_end; k += 16) {
+        double2 av[4]; double b[4][NT];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 4; ++u) {
             av[u] = *reinterpret_cast<const double2*>(Lp + ((k >> 2) + u) * 128);
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) b[u][ct] = Zp[ct][2 * (k + 4 * u)];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) {
                 acc[0][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u].x, b[u][ct], acc[0][ct], 0, 0, 0);
@@ -320,95 +320,195 @@ __device__ __forceinline__ void rs3_product_block(const Rs3Args& a, const uint64
     }
 }
 
-__global__ __launch_bounds__(256) void rs3_products_kernel(Rs3Args a)
+// The same product for a FULL part (every wave has RS_KC / 16 steps), the form 9 of 10 work-groups run.  The candidates'
+// normals come from LDS: the part's columns need three windows of Nrm -- slot 0: every other normal from the anchor on,
+// slots 1 / 2: 2 RS_KC + 14 / + 31 consecutive normals -- which the work-group stages once (21 KB); the B operand of a step is
+// then three conflict-free ds_read_b64 (the lanes of a tile touch 22 consecutive doubles) instead of three gathers through
+// the vector memory path that had to be held in 48 registers a batch ahead.  That leaves the registers to L: a ring of
+// RS3_RING steps (1 KiB each) per wave, refilled as it is consumed -- every load address is known up front, nothing is
+// conditional, so the compiler's vmcnt bookkeeping lets step s start the moment ITS kilobyte has arrived while 15 more are in
+// flight behind it (v1 issued eight, waited for all, and only then computed).
+constexpr int RS3_RING = 16;
+template <int NT>
+__device__ __forceinline__ void rs3_product_full(const Rs3Args& a, const uint64_t base, const int bx, const int by, double* lds,
+                                                 const double* Lp, double2 (&av)[RS3_RING])
 {
-    __shared__ double red[8 * 3 * 64];
-    if (*(volatile int*)a.err != 0) return;
-    const int item0 = *(volatile int*)a.next_item;
-    if (item0 >= (int)a.m) return;                            // every item is done: a spare pass
-    const uint64_t base = a.posv[item0];
-    const int nbx = (int)((a.n + RS_ROWS - 1) / RS_ROWS);
-    const int bx = (int)blockIdx.x % nbx, by = (int)blockIdx.x / nbx;
-    if ((int)a.m - item0 >= 3 && a.lim2 > 0) rs3_product_block<3>(a, base, bx, by, red);
-    else                                     rs3_product_block<1>(a, base, bx, by, red);     // the last items: slots 0 and 1 alone
-}
-
-// Sums of V values per thread over ALL the work-groups of the slice kernel (sync = how many such meetings came before in
-// this launch): wave sums, block sums, then the work-groups' sums meet in memory and every work-group adds them in the same
-// order -- so all of them see the same bits and take the same branches.  flagsync.h's form: the values are stored
-// write-through at agent scope by lanes of ONE wave, that wave waits for its stores, one lane adds to the counter and polls
-// it; readers use agent-scope loads (no release: nothing else of this kernel is shared, and no acquire per poll).  The poll is
-// bounded like every in-kernel wait of this library; the work-groups are the whole grid of a launch on an otherwise idle
-// stream, <= RS3_MAX_WGS of them, so they are resident together.  Returns false when the wait expired (uniform per block).
-template <int V>
-__device__ __forceinline__ bool rs3_sum_all(const Rs3Args& a, const int w, const int E, const int sync, const double* acc,
-                                            double* sh /* 5 V + 1 doubles */, double* tot)
-{
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    __syncthreads();                                          // (sh is still being read from the meeting before)
+    constexpr int STEPS = RS_KC / 16;                         // per wave
+    static_assert(STEPS == 2 * RS3_RING, "the unrolled loop below is two turns of the ring");
+    const int lane = threadIdx.x & 63, kq = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+    const int64_t n = a.n;
+    const int64_t r0 = (int64_t)bx * RS_ROWS;
+    const int64_t k0 = (int64_t)by * RS_KC;
+    // the windows: W0[kk] = z_slot0[k0 + kk];  W1[x] / W2[x] = the normals from slot 1's / slot 2's first candidate's z[k0] on.
+    // Their loads go out together, behind the ring's first turn (the kernel issued it before it looked at the anchor).
+    const uint64_t item_step = 2ull * (uint64_t)n + 2ull;
+    double* W0 = lds; double* W1 = lds + RS_KC; double* W2 = W1 + 2 * RS_KC + 16;
+    constexpr int C0 = RS_KC / 256, C1 = (2 * RS_KC + 16 + 255) / 256, C2 = (2 * RS_KC + 32 + 255) / 256;
+    const double* N0 = a.Nrm + base + 2ull * (uint64_t)k0;
+    const double* N1 = N0 + item_step;
+    const double* N2 = N1 + item_step;
+    double w0[C0], w1[C1], w2[NT > 1 ? C2 : 1];
 #pragma unroll
-    for (int v = 0; v < V; ++v) {
-        double x = acc[v];
+    for (int q = 0; q < C0; ++q) w0[q] = N0[2 * (threadIdx.x + 256 * q)];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-        if (lane == 0) sh[wv * V + v] = x;
+    for (int q = 0; q < C1; ++q) { const int x = threadIdx.x + 256 * q; w1[q] = N1[x < 2 * RS_KC + 16 ? x : 0]; }
+    if (NT > 1) {
+#pragma unroll
+        for (int q = 0; q < C2; ++q) { const int x = threadIdx.x + 256 * q; w2[q] = N2[x < 2 * RS_KC + 32 ? x : 0]; }
+    }
+#pragma unroll
+    for (int q = 0; q < C0; ++q) W0[threadIdx.x + 256 * q] = w0[q];
+#pragma unroll
+    for (int q = 0; q < C1; ++q) { const int x = threadIdx.x + 256 * q; if (x < 2 * RS_KC + 16) W1[x] = w1[q]; }
+    if (NT > 1) {
+#pragma unroll
+        for (int q = 0; q < C2; ++q) { const int x = threadIdx.x + 256 * q; if (x < 2 * RS_KC + 32) W2[x] = w2[q]; }
     }
     __syncthreads();
-    double bs = 0.0;
-    if (threadIdx.x < V) bs = (sh[threadIdx.x] + sh[V + threadIdx.x]) + (sh[2 * V + threadIdx.x] + sh[3 * V + threadIdx.x]);
-    if (E == 1) {
-        if (threadIdx.x < V) sh[4 * V + threadIdx.x] = bs;
-        if (threadIdx.x == 0) sh[5 * V] = 1.0;
-        __syncthreads();
-    } else {
-        double* slot = a.partial + (size_t)(sync & 1) * RS3_MAX_WGS * V;
-        if (wv == 0) {
-            if (lane < V) __hip_atomic_store(slot + w * V + lane, bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) {
-                __hip_atomic_fetch_add(a.cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long need = (unsigned long long)E * (unsigned long long)(sync + 1);
-                int spins = 0;
-                unsigned long long seen = __hip_atomic_load(a.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                while (seen < need && ++spins < (1 << 22)) {
-                    __builtin_amdgcn_s_sleep(1);
-                    seen = __hip_atomic_load(a.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                sh[5 * V] = (seen >= need) ? 1.0 : 0.0;
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < V && sh[5 * V] != 0.0) {
-            double r = 0.0;
-            for (int q = 0; q < E; ++q) r += __hip_atomic_load(slot + q * V + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sh[4 * V + threadIdx.x] = r;
-        }
-        __syncthreads();
-    }
+    // lane (i, g) at the wave's step s reads column kk = kq * RS_KC / 4 + 4 s + g of the part
+    const int kk0 = kq * (RS_KC / 4) + g;
+    const double* B0 = (i == 0) ? W0 + kk0 : W1 + 2 * kk0 + (i - 1);
+    const int st0 = (i == 0) ? 4 : 8;                         // doubles per step
+    const double* B1 = W2 + 2 * kk0 + i;
+    d4 acc[2][NT];
 #pragma unroll
-    for (int v = 0; v < V; ++v) tot[v] = sh[4 * V + v];
-    return sh[5 * V] != 0.0;
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) acc[t][ct] = d4{ 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const int u = s % RS3_RING;
+        const double2 al = av[u];
+        if (s + RS3_RING < STEPS) av[u] = *reinterpret_cast<const double2*>(Lp + (s + RS3_RING) * 128);
+        double b[NT];
+        b[0] = B0[s * st0];
+        if (NT > 1) {
+#pragma unroll
+            for (int ct = 1; ct < NT; ++ct) b[ct] = B1[s * 8 + 16 * (ct - 1)];
+        }
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+            acc[0][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(al.x, b[ct], acc[0][ct], 0, 0, 0);
+            acc[1][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(al.y, b[ct], acc[1][ct], 0, 0, 0);
+        }
+    }
+    // quarters 1, 2, 3 are added to quarter 0 in that order (the windows' space is free behind the barrier)
+    __syncthreads();
+    if (kq > 0) {
+        double* mine = lds + (size_t)(kq - 1) * (8 * NT * 64) + lane;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mine[((t * NT + ct) * 4 + r) * 64] = acc[t][ct][r];
+    }
+    __syncthreads();
+    if (kq != 0) return;
+    for (int q = 0; q < 3; ++q) {
+        const double* theirs = lds + (size_t)q * (8 * NT * 64) + lane;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[t][ct][r] += theirs[((t * NT + ct) * 4 + r) * 64];
+    }
+    // lane (i, g): acc[t][ct][r] = row r0 + 2 pi(g + 4 r) + t = r0 + 8 g + 2 r + t, candidate 16 ct + i
+    double* out = a.part + ((int64_t)by * RS3_CAND) * n;
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) {
+        double* oc = out + (int64_t)(16 * ct + i) * n + r0 + 8 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int64_t row = r0 + 8 * g + 2 * r + t;
+                if (row < n) oc[2 * r + t] = acc[t][ct][r];
+            }
+    }
+}
+
+// one work-group per unit of the table the sampler built (rs3_unit_table): full parts first, then the ragged ones.  What a
+// work-group waits for before its first MFMA is kept to one memory round trip: its first kilobytes of L depend on the unit
+// alone and go out before the anchor is even looked at; the anchor is ONE 32-byte record (item, start, end of Nrm).
+__global__ __launch_bounds__(256, 3) void rs3_products_kernel(Rs3Args a)
+{
+    __shared__ double lds[RS3_LDS_DOUBLES];
+    const uint32_t unit = a.units[blockIdx.x];
+    const int bx = (int)(unit & 0xffffu), by = (int)(unit >> 16);
+    const bool full = (int)blockIdx.x < a.nfull;
+    const double* Lp = a.Lt + ((int64_t)bx * a.nkb + (((int64_t)by * RS_KC) >> 2) + (int64_t)(threadIdx.x >> 6) * (RS_KC / 16)) * 128 + 2 * (threadIdx.x & 63);
+    double2 av[RS3_RING];
+    if (full) {
+#pragma unroll
+        for (int u = 0; u < RS3_RING; ++u) av[u] = *reinterpret_cast<const double2*>(Lp + u * 128);
+    }
+    const uint64_t item0 = a.anchor[0], base = a.anchor[1];
+    if (item0 >= (uint64_t)a.m) return;                       // every item is done (or the draw has failed): a spare pass
+    const bool three = (uint64_t)a.m - item0 >= 3;            // (the last items: slots 0 and 1 alone)
+    if (full) {
+        if (three) rs3_product_full<3>(a, base, bx, by, lds, Lp, av);
+        else       rs3_product_full<1>(a, base, bx, by, lds, Lp, av);
+    } else {
+        if (three) rs3_product_block<3>(a, base, bx, by, lds);
+        else       rs3_product_block<1>(a, base, bx, by, lds);
+    }
 }
 
 // ess() (src/draw-f.cpp:21-60) for the items of a pass, one after the other, the formula as written (no ll_fast: an R-stream
-// replay keeps the reference's arithmetic).  The rows are spread over the E work-groups of the launch, R per thread, in
-// registers; every work-group carries the same bracket state and takes the same branches.
+// replay keeps the reference's arithmetic).  What bounds it is latency -- a slot is a chain of memory round trips, one
+// sin / cos, one likelihood term and one meeting of the work-groups -- so the work is spread WIDE: E <= 256 work-groups of
+// 32 R rows (R = 2 at n = 8192: 128 work-groups), five waves each:
+//   waves 0..3  lane (row rl = lane & 31, half h = lane >> 5): trial point t = 2 wave + h of the round for its R rows -- the
+//               eight points of a round are evaluated side by side, ONE term per thread and row;
+//   wave 0      (h = 0) also the current state's ll_bar (first round);     wave 4  lanes 0..7: cos / sin of the eight points.
+// The next item's f, mu, y are loaded while the current one is evaluated (they depend on nothing); nu = the parts of the
+// selected column, eight groups of parts summed side by side (fixed order); the uniforms a round can consume are fetched
+// TOGETHER into LDS before the bracket sequence is walked (read one by one from the 150 MB window, each at an address the one
+// before decides -- :56 consumes nothing when the bracket has closed -- they were ten dependent HBM misses per item).
+// Meeting (sync): every work-group stores its <= 9 partial sums write-through at agent scope, waits for the stores, raises
+// ITS OWN flag word to the meeting's tag (tags grow monotonically over passes and draws: nothing is ever reset); thread q
+// polls work-group q's flag (bounded, like every in-kernel wait of this library: on expiry the draw fails with GPIRT_E_HIP);
+// then all partial sums are read with agent-scope loads and added in one fixed order -- every work-group sees the same bits
+// and takes the same branches.  No atomics: 128 adds to one counter would queue for longer than the rest of the meeting.
+// The work-groups are the whole grid of a launch on an otherwise idle stream, <= one per CU: resident together.
 template <int R>
-__global__ __launch_bounds__(256) void rs3_slice_kernel(Rs3Args a)
+__global__ __launch_bounds__(320) void rs3_slice_kernel(Rs3Args a)
 {
-    constexpr int T = RS3_TRIALS, V = T + 1;
-    __shared__ double sh[5 * V + 1];
+    constexpr int T = RS3_TRIALS, V = T + 1, RW = 32 * R;
+    __shared__ double ul[T + 2];
     __shared__ double cs[2 * T];
-    const int tid = threadIdx.x, w = blockIdx.x, E = a.wgs;
+    __shared__ double psum[8][RW];
+    __shared__ double vals[RS3_MAX_WGS * V];
+    __shared__ double csum[V * 16];
+    __shared__ double tots[V];
+    __shared__ int expired;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, rl = lane & 31, hh = lane >> 5;
+    const int w = blockIdx.x, E = gridDim.x;
     const int64_t n = a.n;
-    if (*(volatile int*)a.err != 0) return;
-    const int item0 = *(volatile int*)a.next_item;
-    if (item0 >= (int)a.m) return;
+    if (a.anchor[0] >= (uint64_t)a.m) return;                 // every item is done (or the draw has failed)
+    const int item0 = (int)a.anchor[0];
     const int ns = ((int)a.m - item0 < RS3_SLOTS) ? (int)a.m - item0 : RS3_SLOTS;
-    const uint64_t nrm_end = *a.nrm_end;
-    uint64_t start = a.posv[item0];
-    const int64_t i0 = (int64_t)w * (R * 256) + tid;
+    const uint64_t nrm_end = a.anchor[2];
+    uint64_t start = a.anchor[1];
+    const int64_t i0 = (int64_t)w * RW + rl;                  // this thread's rows: i0 + 32 e
+    // parts of this work-group's rows: group gq = 2 wave + h (waves 0..3) adds parts [gq pp, (gq + 1) pp)
+    const int64_t last_row = ((int64_t)(w + 1) * RW < n ? (int64_t)(w + 1) * RW : n) - 1;
+    const int maxparts = (int)((((last_row / RS_ROWS) + 1) * RS_ROWS < n ? ((last_row / RS_ROWS) + 1) * RS_ROWS : n) + RS_KC - 1) / RS_KC;
+    const int pp = (maxparts + 7) / 8;
     int usum = 0, resolved = 0, sync = 0, fail = 0;
+    if (tid == 0) expired = 0;
+    double Fn[R], Mn[R], Yn[R];                               // the NEXT slot's rows
+    auto fetch_rows = [&](const int64_t j) {
+#pragma unroll
+        for (int e = 0; e < R; ++e) {
+            const int64_t i = i0 + 32 * e;
+            Fn[e] = 0.0; Mn[e] = 0.0; Yn[e] = __builtin_nan("");             // NaN = skipped, like a missing response
+            if (i < n) { Fn[e] = a.f[j * n + i]; Mn[e] = a.mu[j * n + i]; Yn[e] = a.y[j * n + i]; }
+        }
+    };
+    fetch_rows(item0);
     for (int g = 0; g < ns; ++g) {
         int col = 0;
         if (g == 1) { if (usum >= a.lim1) break; col = 1 + usum; }
@@ -416,68 +516,135 @@ __global__ __launch_bounds__(256) void rs3_slice_kernel(Rs3Args a)
         const int64_t j = item0 + g;
         // the item's 2n uniforms (all its normals were built) and its first two slice uniforms lie inside the window
         if (start + 2ull * (uint64_t)n + 2ull > a.cap || start + 2ull * (uint64_t)(n - 1) >= nrm_end) { fail = GPIRT_E_RNG; break; }
-        double* fj = a.f + j * n; const double* yj = a.y + j * n; const double* mj = a.mu + j * n;
-        double F[R], Vn[R], M[R], Y[R];
+        const uint64_t p0 = start + 2ull * (uint64_t)n;                       // behind the n normals
+        uint32_t uidx = 0, ubase = 0;
+        __syncthreads();                                                       // (ul, psum, cs are still being read from the slot before)
+        // the uniforms of the first round: u, the first point and one per rejection
+        if (tid < T + 2) { const uint64_t q = p0 + tid; ul[tid] = q < a.cap ? a.U[q] : __builtin_nan(""); }
+        if (wv < 4) {
+            const int gq = 2 * wv + hh;
 #pragma unroll
-        for (int e = 0; e < R; ++e) {
-            const int64_t i = i0 + 256 * e;
-            F[e] = 0.0; Vn[e] = 0.0; M[e] = 0.0; Y[e] = __builtin_nan("");      // NaN = skipped, like a missing response
-            if (i < n) {
-                // nu = the parts of column `col`, added in part order
-                const int64_t grp = (i / RS_ROWS) * RS_ROWS;
-                const int64_t kall = (grp + RS_ROWS < n) ? grp + RS_ROWS : n;
-                const int parts = (int)((kall + RS_KC - 1) / RS_KC);
-                double v = a.part[(int64_t)col * n + i];
-                for (int q = 1; q < parts; ++q) v += a.part[((int64_t)q * RS3_CAND + col) * n + i];
-                Vn[e] = v; F[e] = fj[i]; M[e] = mj[i]; Y[e] = yj[i];
+            for (int e = 0; e < R; ++e) {
+                const int64_t i = i0 + 32 * e;
+                double v = 0.0;
+                if (i < n) {
+                    const int64_t grp = (i / RS_ROWS) * RS_ROWS;
+                    const int64_t kall = (grp + RS_ROWS < n) ? grp + RS_ROWS : n;
+                    const int parts = (int)((kall + RS_KC - 1) / RS_KC);
+                    int q1 = (gq + 1) * pp; if (q1 > parts) q1 = parts;
+                    for (int q0 = gq * pp; q0 < q1; q0 += 4) {    // (four loads in flight, not four round trips)
+                        double t[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) t[u] = (q0 + u < q1) ? a.part[((int64_t)(q0 + u) * RS3_CAND + col) * n + i] : 0.0;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v += t[u];
+                    }
+                }
+                psum[gq][32 * e + rl] = v;
             }
         }
-        const uint64_t p0 = start + 2ull * (uint64_t)n;                       // behind the n normals
-        uint32_t uidx = 0;
+        double F[R], Vn[R], M[R], Y[R];
+#pragma unroll
+        for (int e = 0; e < R; ++e) { F[e] = Fn[e]; M[e] = Mn[e]; Y[e] = Yn[e]; }
+        if (g + 1 < ns) fetch_rows(j + 1);
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < R; ++e) {
+            double v = psum[0][32 * e + rl];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) v += psum[q][32 * e + rl];
+            Vn[e] = v;
+        }
         bool bad_u = false;
         auto next_u = [&]() -> double {
-            const uint64_t q = p0 + uidx;
+            const double x = ul[uidx - ubase];
             ++uidx;
-            if (q >= a.cap) { bad_u = true; return 0.5; }
-            return a.U[q];
+            if (x != x) { bad_u = true; return 0.5; }        // (past the window: reported if the draw gets that far)
+            return x;
         };
         const double u = next_u();                                             // draw-f.cpp:28
         double eps_min = 0.0, eps_max = GP_2PI;                                // :33-34
         double eps = eps_min + (eps_max - eps_min) * next_u();                 // :35
         eps_min = eps - GP_2PI;                                                // :36
         int k = 0;
-        double log_y = 0.0, c = 1.0, s = 0.0;
+        double log_y = 0.0, c = 1.0, sn = 0.0;
         uint32_t uacc = 0;
         bool first = true, done = false;
         while (!done) {
+            if (!first) {
+                // a further round: the T uniforms it can consume
+                ubase = uidx;
+                __syncthreads();
+                if (tid < T) { const uint64_t q = p0 + ubase + tid; ul[tid] = q < a.cap ? a.U[q] : __builtin_nan(""); }
+                __syncthreads();
+            }
             // the next T trial points: each is what :50-56 makes of the one before, were it rejected
             uint32_t Ut[T]; bool Bt[T];
             double my_eps = 0.0;
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                if (tid == t) my_eps = eps;
+                if (lane == t) my_eps = eps;
                 Ut[t] = uidx; Bt[t] = bad_u;
                 if (eps < 0.0) eps_min = eps; else eps_max = eps;              // :50-55
                 if (eps_min == eps_max) eps = eps_min;                         // R::runif(a, a) = a, nothing consumed
                 else eps = eps_min + (eps_max - eps_min) * next_u();           // :56
             }
-            __syncthreads();                                                   // (cs is still being read from the round before)
-            if (tid < T) { cs[tid] = cos(my_eps); cs[T + tid] = sin(my_eps); }
-            __syncthreads();
-            double acc[V], tot[V];
+            double mine = 0.0, mine0 = 0.0;                                    // this thread's term sums: its trial point / ll_bar(f)
+            if (wv == 4) {
+                if (lane < T) { cs[lane] = cos(my_eps); cs[T + lane] = sin(my_eps); }
+            } else if (first && wv == 0 && hh == 0) {
 #pragma unroll
-            for (int v = 0; v < V; ++v) acc[v] = 0.0;
-            if (first) {
-#pragma unroll
-                for (int e = 0; e < R; ++e) if (Y[e] == Y[e]) acc[0] += ll_term(Y[e] * (F[e] + M[e]));          // :29
+                for (int e = 0; e < R; ++e) if (Y[e] == Y[e]) mine0 += ll_term(Y[e] * (F[e] + M[e]));          // :29
             }
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
+            __syncthreads();
+            const uint64_t tag = a.tag + (uint64_t)sync;
+            double* rec = a.partial + (size_t)(sync & 1) * RS3_MAX_WGS * V;
+            unsigned long long* flg = a.flags + (size_t)(sync & 1) * RS3_MAX_WGS;
+            if (wv < 4) {
+                const int t = 2 * wv + hh;
                 const double ct = cs[t], st = cs[T + t];
 #pragma unroll
-                for (int e = 0; e < R; ++e) if (Y[e] == Y[e]) acc[1 + t] += ll_term(Y[e] * ((F[e] * ct + Vn[e] * st) + M[e]));   // :43
+                for (int e = 0; e < R; ++e) if (Y[e] == Y[e]) mine += ll_term(Y[e] * ((F[e] * ct + Vn[e] * st) + M[e]));   // :43
+                // sums over the 32 lanes of a half (fixed tree)
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) { mine += __shfl_down(mine, off, 64); mine0 += __shfl_down(mine0, off, 64); }
+                if (rl == 0) __hip_atomic_store(rec + w * V + 1 + t, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (first && tid == 0) __hip_atomic_store(rec + w * V, mine0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            if (!rs3_sum_all<V>(a, w, E, sync++, acc, sh, tot)) { fail = GPIRT_E_HIP; break; }
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(flg + w, (unsigned long long)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid < E) {
+                int spins = 0;
+                unsigned long long seen = __hip_atomic_load(flg + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while (seen < tag && ++spins < (1 << 22)) {
+                    __builtin_amdgcn_s_sleep(1);
+                    seen = __hip_atomic_load(flg + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (seen < tag) expired = 1;
+            }
+            __syncthreads();
+            if (expired) { fail = GPIRT_E_HIP; break; }
+            for (int x = tid; x < E * V; x += 320) vals[x] = __hip_atomic_load(rec + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (tid < V * 16) {
+                const int v = tid >> 4, ch = tid & 15, per = (E + 15) / 16;
+                int q1 = (ch + 1) * per; if (q1 > E) q1 = E;
+                double r = 0.0;
+                for (int q = ch * per; q < q1; ++q) r += vals[q * V + v];
+                csum[tid] = r;
+            }
+            __syncthreads();
+            if (tid < V) {
+                double r = csum[tid * 16];
+                for (int ch = 1; ch < 16; ++ch) r += csum[tid * 16 + ch];
+                tots[tid] = r;
+            }
+            __syncthreads();
+            double tot[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) tot[v] = tots[v];
+            ++sync;
             if (first) { log_y = -tot[0] + log(u); first = false; }            // :29
             int hit = -1;
 #pragma unroll
@@ -492,7 +659,7 @@ __global__ __launch_bounds__(256) void rs3_slice_kernel(Rs3Args a)
             if (hit >= 0) {
                 bool bad = false;
 #pragma unroll
-                for (int t = 0; t < T; ++t) if (t == hit) { c = cs[t]; s = cs[T + t]; uacc = Ut[t]; bad = Bt[t]; }
+                for (int t = 0; t < T; ++t) if (t == hit) { c = cs[t]; sn = cs[T + t]; uacc = Ut[t]; bad = Bt[t]; }
                 if (bad) { fail = GPIRT_E_RNG; break; }
                 k += hit; done = true;
             } else {
@@ -502,10 +669,12 @@ __global__ __launch_bounds__(256) void rs3_slice_kernel(Rs3Args a)
             }
         }
         if (fail) break;
+        if (wv == 0 && hh == 0) {
 #pragma unroll
-        for (int e = 0; e < R; ++e) {
-            const int64_t i = i0 + 256 * e;
-            if (i < n) fj[i] = F[e] * c + Vn[e] * s;
+            for (int e = 0; e < R; ++e) {
+                const int64_t i = i0 + 32 * e;
+                if (i < n) a.f[j * n + i] = F[e] * c + Vn[e] * sn;
+            }
         }
         start = p0 + uacc;
         usum += (int)uacc - 2;
@@ -513,8 +682,8 @@ __global__ __launch_bounds__(256) void rs3_slice_kernel(Rs3Args a)
         if (w == 0 && tid == 0) { a.k_out[j] = k; a.posv[j + 1] = start; }
     }
     if (tid == 0) {
-        if (fail) atomicCAS(a.err, 0, fail);                  // every later kernel of the pass leaves at once
-        else if (w == 0) { *a.next_item = item0 + resolved; *a.pos = start; }
+        if (fail) { atomicCAS(a.err, 0, fail); a.anchor[0] = (uint64_t)a.m; }        // every later kernel of the draw leaves at once
+        else if (w == 0) { a.anchor[0] = (uint64_t)(item0 + resolved); a.anchor[1] = start; *a.pos = start; }
     }
 }
 
@@ -669,23 +838,42 @@ int launch_rs3_begin(hipStream_t stream, const Rs3Args& a, uint64_t span)
 
 int launch_rs3_products(hipStream_t stream, const Rs3Args& a)
 {
-    const unsigned nbx = (unsigned)((a.n + RS_ROWS - 1) / RS_ROWS), parts = (unsigned)((a.n + RS_KC - 1) / RS_KC);
-    hipLaunchKernelGGL(rs3_products_kernel, dim3(nbx * parts), dim3(256), 0, stream, a);
+    if (a.nunits <= 0) return 0;
+    hipLaunchKernelGGL(rs3_products_kernel, dim3((unsigned)a.nunits), dim3(256), 0, stream, a);
     GP_HIP(hipGetLastError());
     return 0;
 }
 
-int rs3_slice_wgs(int64_t n) { const int64_t e = (n + 255) / 256; return (int)(e < RS3_MAX_WGS ? e : RS3_MAX_WGS); }
+// the work-groups of a products launch: every (row group, part) that holds a non-zero of L, full parts first
+void rs3_unit_table(int64_t n, std::vector<uint32_t>& units, int* nfull)
+{
+    std::vector<uint32_t> ragged;
+    units.clear();
+    const int64_t nbx = (n + RS_ROWS - 1) / RS_ROWS;
+    for (int64_t bx = 0; bx < nbx; ++bx) {
+        const int64_t kall = ((bx + 1) * RS_ROWS < n) ? (bx + 1) * RS_ROWS : n;
+        for (int64_t by = 0; by * RS_KC < kall; ++by) {
+            const uint32_t u = (uint32_t)bx | ((uint32_t)by << 16);
+            if ((by + 1) * RS_KC <= kall) units.push_back(u); else ragged.push_back(u);
+        }
+    }
+    *nfull = (int)units.size();
+    units.insert(units.end(), ragged.begin(), ragged.end());
+}
+
+// rows per thread of the slice kernel (32 R rows per work-group): the fewest that keep the grid at <= 128 work-groups
+int rs3_slice_rows(int64_t n) { const int64_t r = (n + 4095) / 4096; return r <= 1 ? 1 : r <= 2 ? 2 : r <= 4 ? 4 : 8; }
+int rs3_slice_wgs(int64_t n) { const int64_t rw = 32 * (int64_t)rs3_slice_rows(n); return (int)((n + rw - 1) / rw); }
 
 int launch_rs3_slice(hipStream_t stream, const Rs3Args& a)
 {
-    const int rows = (int)((a.n + (int64_t)a.wgs * 256 - 1) / ((int64_t)a.wgs * 256));     // per thread
-    switch (rows) {
-    case 1: hipLaunchKernelGGL(rs3_slice_kernel<1>, dim3((unsigned)a.wgs), dim3(256), 0, stream, a); break;
-    case 2: hipLaunchKernelGGL(rs3_slice_kernel<2>, dim3((unsigned)a.wgs), dim3(256), 0, stream, a); break;
-    case 3: hipLaunchKernelGGL(rs3_slice_kernel<3>, dim3((unsigned)a.wgs), dim3(256), 0, stream, a); break;
-    case 4: hipLaunchKernelGGL(rs3_slice_kernel<4>, dim3((unsigned)a.wgs), dim3(256), 0, stream, a); break;
-    default: set_error("R-stream replay: n = %lld is beyond the slice kernel's %d rows", (long long)a.n, RS3_MAX_WGS * 1024); return GPIRT_E_ARG;
+    const int wgs = rs3_slice_wgs(a.n);
+    if (wgs > RS3_MAX_WGS) { set_error("R-stream replay: n = %lld is beyond the slice kernel's %lld rows", (long long)a.n, (long long)RS3_MAX_N); return GPIRT_E_ARG; }
+    switch (rs3_slice_rows(a.n)) {
+    case 1: hipLaunchKernelGGL(rs3_slice_kernel<1>, dim3((unsigned)wgs), dim3(320), 0, stream, a); break;
+    case 2: hipLaunchKernelGGL(rs3_slice_kernel<2>, dim3((unsigned)wgs), dim3(320), 0, stream, a); break;
+    case 4: hipLaunchKernelGGL(rs3_slice_kernel<4>, dim3((unsigned)wgs), dim3(320), 0, stream, a); break;
+    default: hipLaunchKernelGGL(rs3_slice_kernel<8>, dim3((unsigned)wgs), dim3(320), 0, stream, a); break;
     }
     GP_HIP(hipGetLastError());
     return 0;

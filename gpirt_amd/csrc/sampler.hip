@@ -104,12 +104,11 @@ struct gpirt_sampler_s {
     // draw_f of the replay, three items per pass over L (rng_ess.hip): Nrm = the normal that starts at every position of the
     // window, rs_part = the parts of a pass's 48 candidate products, next_item = the first item no pass has resolved yet
     bool spec_ok = false;
-    uint64_t *posv = nullptr, *nrm_end = nullptr;
-    int *next_item = nullptr, *h_next = nullptr;
-    unsigned long long* rs_cnt = nullptr; double* rs_partial = nullptr;
+    uint64_t *posv = nullptr, *anchor = nullptr, *h_next = nullptr;
+    unsigned long long* rs_flags = nullptr; double* rs_partial = nullptr; uint64_t rs_tag = 0;
     double* Lt = nullptr;             // L in the candidate products' tile order (rebuilt at the start of every draw_f)
     double *Nrm = nullptr, *rs_part = nullptr;
-    int64_t rs_passes_cap = 0;        // words of rs_cnt (one per pass of a draw)
+    uint32_t* rs_units = nullptr; int rs_nunits = 0, rs_nfull = 0;
     // bookkeeping
     int iter = 0;                     // completed iterations
     bool initialised = false;
@@ -412,15 +411,15 @@ int do_draw_f(gpirt_sampler_s* s)
     // every item done leaves at once -- and reads the item counter back once.
     GP_TRY(launch_rs_tiles(st, s->L, n, s->ldl, s->Lt));
     Rs3Args a{};
-    a.U = s->U; a.cap = s->U_cap; a.Nrm = s->Nrm; a.nrm_end = s->nrm_end; a.pos = s->pos; a.posv = s->posv; a.k_out = s->ess_k;
-    a.next_item = s->next_item; a.err = s->flags; a.n = n; a.m = m; a.Lt = s->Lt; a.nkb = rs_tile_quads(n); a.part = s->rs_part;
+    a.U = s->U; a.cap = s->U_cap; a.Nrm = s->Nrm; a.anchor = s->anchor; a.pos = s->pos; a.posv = s->posv; a.k_out = s->ess_k;
+    a.err = s->flags; a.n = n; a.m = m; a.Lt = s->Lt; a.nkb = rs_tile_quads(n); a.part = s->rs_part;
+    a.units = s->rs_units; a.nunits = s->rs_nunits; a.nfull = s->rs_nfull;
     a.lim1 = RS3_C1; a.lim2 = RS3_C2;
     if (h->rs_cand_limit > 0) {
         if (h->rs_cand_limit < a.lim1) a.lim1 = h->rs_cand_limit;
         if (h->rs_cand_limit < a.lim2) a.lim2 = h->rs_cand_limit;
     }
-    a.f = s->f; a.y = s->y; a.mu = s->mu; a.wgs = rs3_slice_wgs(n); a.partial = s->rs_partial;
-    GP_HIP(hipMemsetAsync(s->rs_cnt, 0, sizeof(unsigned long long) * (size_t)s->rs_passes_cap, st));
+    a.f = s->f; a.y = s->y; a.mu = s->mu; a.partial = s->rs_partial; a.flags = s->rs_flags;
     // the normals draw_f can reach: m items of 2n + 2 uniforms + their rejections (the window's own slack, stream_window)
     GP_TRY(launch_rs3_begin(st, a, (uint64_t)m * (2ull * (uint64_t)n + 2ull) + 512ull * (uint64_t)m + 4096ull));
     int64_t pass = 0, done = 0;
@@ -428,20 +427,20 @@ int do_draw_f(gpirt_sampler_s* s)
     while (done < m) {
         const int64_t left = m - done;
         int64_t count = (left + RS3_SLOTS - 1) / RS3_SLOTS + left / 40 + 2;
-        if (pass + count > s->rs_passes_cap) count = s->rs_passes_cap - pass;
-        if (count <= 0) { set_error("R-stream replay: draw_f made no progress"); return GPIRT_E_NUMERIC; }   // (a pass resolves >= 1 item)
+        if (pass > 2 * m + 64) { set_error("R-stream replay: draw_f made no progress"); return GPIRT_E_NUMERIC; }   // (a pass resolves >= 1 item)
         for (int64_t q = 0; q < count; ++q, ++pass) {
-            a.cnt = s->rs_cnt + pass;
+            s->rs_tag += 1ull << 20;
+            a.tag = s->rs_tag;
             GP_TRY(launch_rs3_products(st, a));
             GP_TRY(launch_rs3_slice(st, a));
         }
-        GP_HIP(hipMemcpyAsync(s->h_next, s->next_item, sizeof(int), hipMemcpyDeviceToHost, st));
+        GP_HIP(hipMemcpyAsync(s->h_next, s->anchor, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         GP_HIP(hipMemcpyAsync(s->h_next + 1, s->flags, sizeof(int), hipMemcpyDeviceToHost, st));
         if (s->stream_open && !topped) { GP_TRY(ahead_topup(s, stream_window(s))); topped = true; }     // the next window's uniforms, while the items run
         GP_HIP(hipStreamSynchronize(st));
-        if (s->h_next[1] != 0) break;                         // (an error flag: stream_end / check report it)
-        if (s->h_next[0] <= done) { set_error("R-stream replay: draw_f made no progress"); return GPIRT_E_NUMERIC; }
-        done = s->h_next[0];
+        if ((int)s->h_next[1] != 0) break;                    // (an error flag: stream_end / check report it)
+        if ((int64_t)s->h_next[0] <= done) { set_error("R-stream replay: draw_f made no progress"); return GPIRT_E_NUMERIC; }
+        done = (int64_t)s->h_next[0];
     }
     return 0;
 }
@@ -857,14 +856,20 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
         if (s->spec_ok) {
             const size_t parts = (size_t)((n + RS_KC - 1) / RS_KC);
             const size_t nrm = (size_t)s->U_cap + 6 * (size_t)n + 128;        // (the products read up to 6n + 39 past an anchor)
-            s->rs_passes_cap = m + 64;
             GP_A(s->Lt, rs_tile_doubles(n));
-            GP_A(s->posv, m + 1);    GP_A(s->next_item, 2);    GP_A(s->nrm_end, 2);
-            GP_A(s->rs_cnt, s->rs_passes_cap);    GP_A(s->rs_partial, 2 * RS3_MAX_WGS * (RS3_TRIALS + 1));
+            GP_A(s->posv, m + 1);    GP_A(s->anchor, 4);
+            GP_A(s->rs_flags, 2 * RS3_MAX_WGS);    GP_A(s->rs_partial, 2 * RS3_MAX_WGS * (RS3_TRIALS + 1));
+            hipMemsetAsync(s->rs_flags, 0, sizeof(unsigned long long) * 2 * RS3_MAX_WGS, st);
             GP_A(s->Nrm, nrm);       GP_A(s->rs_part, parts * RS3_CAND * (size_t)n);
             hipMemsetAsync(s->Nrm, 0, sizeof(double) * nrm, st);              // (positions no draw has filled are read, never used)
             hipMemsetAsync(s->rs_part, 0, sizeof(double) * parts * RS3_CAND * (size_t)n, st);
-            hipMemsetAsync(s->next_item, 0, 2 * sizeof(int), st);
+            hipMemsetAsync(s->anchor, 0, 4 * sizeof(uint64_t), st);
+            std::vector<uint32_t> units;
+            rs3_unit_table(n, units, &s->rs_nfull);
+            s->rs_nunits = (int)units.size();
+            GP_A(s->rs_units, units.size());
+            hipMemcpyAsync(s->rs_units, units.data(), units.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+            hipStreamSynchronize(st);                                          // (units leaves scope)
         }
         GP_A(s->beta_off, m);
         GP_A(s->fstar_off, N + 8);
@@ -872,7 +877,7 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
             hipHostMalloc(&s->hA, s->U_cap * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
             hipHostMalloc(&s->h_pos, 2 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess ||
             hipStreamCreateWithFlags(&s->cs, hipStreamNonBlocking) != hipSuccess ||
-            hipHostMalloc(&s->h_next, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc(&s->h_next, 2 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess ||
             hipEventCreateWithFlags(&s->ev_up, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s->ev_asm, hipEventDisableTiming) != hipSuccess) {
             set_error("pinned allocation for the R-stream window failed");
