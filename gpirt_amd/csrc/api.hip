@@ -424,6 +424,15 @@ int gpirt_debug_rs_cand_limit(gpirt_handle_t h, int limit)
     return 0;
 }
 
+// Debug: pass number `pass` of every replayed draw_f on this handle leaves in-kernel time stamps in the sampler's "rs_trace"
+// array (128 64-bit words, 100 MHz wall clock: tools/rs_trace.py); pass < 0 switches it off.
+int gpirt_debug_rs_trace(gpirt_handle_t h, int pass)
+{
+    GP_ARG(h != nullptr);
+    h->rs_trace_pass = pass;
+    return 0;
+}
+
 int gpirt_debug_trip_guard(gpirt_handle_t h, int nth)
 {
     GP_ARG(nth >= 0);

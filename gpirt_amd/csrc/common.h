@@ -127,6 +127,7 @@ struct gpirt_handle_s {
     gpirt::RtState* rt = nullptr;         // runtime.hip (GPIRT_RUNTIME=2), built on first use for one (n, rows)
     int          guard_fallbacks = 0;
     long long    factor_count = 0;        // factorisations enqueued on this handle (launch_potrf_lower)
+    int          rs_trace_pass = -1;      // debug (gpirt_debug_rs_trace): the pass of every replayed draw_f whose kernels stamp their phases
     int          rs_cand_limit = 0;       // debug (gpirt_debug_rs_cand_limit): candidates the replay's draw_f may use (0: all)
     long long    trip_guard_at = -1;      // debug (gpirt_debug_trip_guard): the factorisation with this count raises the
                                           //   guard word and poisons its result behind itself, as an expiry would leave it

@@ -155,13 +155,16 @@ constexpr int RS_ROWS = 32;          // rows of L per work-group of a candidate 
 constexpr int RS_SPEC_MIN_N = 64;    // below: item by item, four launches each
 constexpr int RS3_SLOTS = 3;         // items a pass can resolve
 constexpr int RS3_C1 = 15;           // slot 1: the item before consumed 0 .. 14 uniforms behind its first two
-constexpr int RS3_C2 = 32;           // slot 2: the two items before consumed 0 .. 31 together
-constexpr int RS3_CAND = 48;         // columns of a pass: [slot 0 | slot 1 x 15 | slot 2 x 32] = three 16-wide MFMA tiles
+constexpr int RS3_C2 = 16;           // slot 2: the two items before consumed 0 .. 15 together
+constexpr int RS3_NT = 2;            // 16-wide MFMA tiles of a pass ...
+constexpr int RS3_CAND = 16 * RS3_NT;   // ... = its columns: [slot 0 | slot 1 x 15 | slot 2 x 16]
+static_assert(1 + RS3_C1 == 16 && RS3_C2 == 16 * (RS3_NT - 1), "tile 0 = slots 0 and 1, the other tiles = slot 2");
 constexpr int RS3_TRIALS = 8;        // trial points of a slice loop evaluated per meeting of the work-groups
 constexpr int RS3_MAX_WGS = 256;     // work-groups of the slice kernel (32 R rows each, R <= 8 rows per thread)
 constexpr int64_t RS3_MAX_N = (int64_t)RS3_MAX_WGS * 256;
-constexpr int RS3_LDS_DOUBLES = 3 * 8 * 3 * 64;     // products: the three Nrm windows of a part (5 RS_KC + 48), then three waves' accumulators
-static_assert(5 * RS_KC + 48 <= RS3_LDS_DOUBLES, "the windows must fit");
+constexpr int RS3_QSTRIDE = 8 * RS3_NT * 65;             // products: one wave's 24 accumulators per lane in LDS (rows of 65: bank spread)
+constexpr int RS3_LDS_DOUBLES = 4 * RS3_QSTRIDE;     //   the three Nrm windows of a part (5 RS_KC + 16 + RS3_C2 doubles), then the four waves' accumulators
+static_assert(5 * RS_KC + 16 + RS3_C2 <= RS3_LDS_DOUBLES, "the windows must fit");
 struct Rs3Args {
     const double* U; uint64_t cap;   // the window of stream uniforms
     double* Nrm;                     // Nrm[r] = rnorm(U[r], U[r + 1]) for r in [cursor at the start of draw_f, *nrm_end)
@@ -182,6 +185,7 @@ struct Rs3Args {
     // work-group raises its flag to the meeting's tag = tag + (meetings before it in this launch); the host hands every
     // launch a range of 2^20 tags above all earlier ones, so nothing is ever reset
     double* partial; unsigned long long* flags; uint64_t tag;
+    long long* trace;                // debug (gpirt_debug_rs_trace): in-kernel time stamps of this pass, or null
 };
 inline int64_t rs_tile_quads(int64_t n) { return (n + 3) / 4 + 1; }
 inline size_t rs_tile_doubles(int64_t n) { return (size_t)((n + RS_ROWS - 1) / RS_ROWS) * (size_t)rs_tile_quads(n) * 128; }

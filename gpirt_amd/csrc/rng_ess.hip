@@ -148,25 +148,31 @@ __global__ __launch_bounds__(256) void ess_kernel(EssArgs a)
 
 // ---- R-stream replay: three items per pass over L ---------------------------------------------------------------------
 // Item j's normals start where item j - 1's slice loop stopped consuming (src/draw-f.cpp:26,56), so nu_j = L z_j cannot be
-// STARTED before that loop ends -- but it has few possible values, and a pass over L (268 MB at n = 8192: HBM-bound) costs
-// nearly the same for 48 right-hand sides as for one.  R's inversion normal takes two consecutive uniforms
-// (src/mvnormal.h:8), so with  Nrm[r] = rnorm(U[r], U[r + 1])  computed ONCE per iteration for every position r of the
-// window (rs3_begin_kernel), the normals of an item that starts at position p are simply Nrm[p + 2 i]: every candidate is a
-// strided window of one array, nothing per candidate is ever materialised.
+// STARTED before that loop ends -- but it has few possible values, and a pass over L (268 MB at n = 8192) costs little more
+// for 32 right-hand sides than for one.  R's inversion normal takes two consecutive uniforms (src/mvnormal.h:8), so with
+// Nrm[r] = rnorm(U[r], U[r + 1])  computed ONCE per iteration for every position r of the window (rs3_begin_kernel), the
+// normals of an item that starts at position p are simply Nrm[p + 2 i]: every candidate is a strided window of one array,
+// nothing per candidate is ever materialised.
 // A pass is anchored at an item a whose start posv[a] is known exactly and serves THREE items (kernels.h, RS3_*):
 //   slot 0  item a          1 candidate            start  posv[a]
-//   slot 1  item a + 1     15 candidates  c = used(a) in 0..14            start  posv[a] + (2n + 2) + c
-//   slot 2  item a + 2     32 candidates  c = used(a) + used(a+1) in 0..31   start  posv[a] + 2 (2n + 2) + c
-// (used = uniforms the slice loop consumed behind its first two = its rejection count, src/draw-f.cpp:56): 48 columns = three
-// 16-wide MFMA tiles per step of L.  rs3_products_kernel computes the 48 products, rs3_slice_kernel then runs the three
+//   slot 1  item a + 1     15 candidates  c = used(a) in 0..14               start  posv[a] + (2n + 2) + c
+//   slot 2  item a + 2     16 candidates  c = used(a) + used(a+1) in 0..15   start  posv[a] + 2 (2n + 2) + c
+// (used = uniforms the slice loop consumed behind its first two = its rejection count, src/draw-f.cpp:56): 32 columns = two
+// 16-wide MFMA tiles per step of L.  rs3_products_kernel computes the 32 products, rs3_slice_kernel then runs the three
 // slice loops one after the other, each on the column its predecessors' counts select, and leaves the next anchor.  A count
 // beyond a slot's candidates just ends the pass early -- the next pass is anchored at the first unresolved item -- so there is
 // no host round trip and no other path: the host enqueues ceil(m / 3) passes + a few spare ones (a pass that finds every
 // item done leaves at once) and looks at the item counter once at the end.
+// Why 32 columns and not 48 (slot 2 with sums up to 31): the products kernel takes 23 us + 17 us per tile at n = 8192 (the
+// tiles' MFMAs at the pipes' rate: 49 / 57 / 74 us for 2 / 2 with the old epilogue / 3 tiles), and the third tile bought 0.03
+// items per pass -- two consecutive slice loops reject 16 times or more between them in 3 % of the cases.
 //
 // The slice loop itself is evaluated RS3_TRIALS points at a time: a rejected point only moves the bracket end of its own
 // sign (src/draw-f.cpp:50-55), so the sequence of trial points is a function of the stream alone, not of the data -- the
 // likelihoods of the next eight points are one pass over the rows and ONE meeting of the work-groups instead of eight.
+
+// debug stamps (gpirt_debug_rs_trace): 100 MHz wall clock, one writer per slot
+__device__ __forceinline__ void rs_stamp(long long* trace, int idx) { if (trace) trace[idx] = (long long)wall_clock64(); }
 
 __device__ __forceinline__ uint32_t mt_temper(uint32_t y)
 {
@@ -322,28 +328,29 @@ __device__ __forceinline__ void rs3_product_block(const Rs3Args& a, const uint64
 
 // The same product for a FULL part (every wave has RS_KC / 16 steps), the form 9 of 10 work-groups run.  The candidates'
 // normals come from LDS: the part's columns need three windows of Nrm -- slot 0: every other normal from the anchor on,
-// slots 1 / 2: 2 RS_KC + 14 / + 31 consecutive normals -- which the work-group stages once (21 KB); the B operand of a step is
-// then three conflict-free ds_read_b64 (the lanes of a tile touch 22 consecutive doubles) instead of three gathers through
-// the vector memory path that had to be held in 48 registers a batch ahead.  That leaves the registers to L: a ring of
+// slots 1 / 2: 2 RS_KC + 14 / + 15 consecutive normals -- which the work-group stages once (21 KB); the B operand of a step is
+// then one conflict-free ds_read_b64 per tile (the lanes of a tile touch 22 consecutive doubles) instead of gathers through
+// the vector memory path that had to be held in registers a batch ahead.  That leaves the registers to L: a ring of
 // RS3_RING steps (1 KiB each) per wave, refilled as it is consumed -- every load address is known up front, nothing is
-// conditional, so the compiler's vmcnt bookkeeping lets step s start the moment ITS kilobyte has arrived while 15 more are in
-// flight behind it (v1 issued eight, waited for all, and only then computed).
-constexpr int RS3_RING = 16;
+// conditional, so the compiler's vmcnt bookkeeping lets step s start the moment ITS kilobyte has arrived while 11 more are in
+// flight behind it (the first form issued eight, waited for all, and only then computed).
+constexpr int RS3_RING = 12;       // (8 / 12 / 16 measure the same; the four waves taking the part's steps in turn, one 128 KB stream per
+                                   //  work-group instead of four of 32 KB, too: gpurun_out/r5h, r5i)
 template <int NT>
 __device__ __forceinline__ void rs3_product_full(const Rs3Args& a, const uint64_t base, const int bx, const int by, double* lds,
-                                                 const double* Lp, double2 (&av)[RS3_RING])
+                                                 const double* Lp, long long* tr)
 {
     constexpr int STEPS = RS_KC / 16;                         // per wave
-    static_assert(STEPS == 2 * RS3_RING, "the unrolled loop below is two turns of the ring");
+    constexpr int TS = 128;                                   // doubles between a wave's consecutive steps
     const int lane = threadIdx.x & 63, kq = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     const int64_t n = a.n;
     const int64_t r0 = (int64_t)bx * RS_ROWS;
     const int64_t k0 = (int64_t)by * RS_KC;
     // the windows: W0[kk] = z_slot0[k0 + kk];  W1[x] / W2[x] = the normals from slot 1's / slot 2's first candidate's z[k0] on.
-    // Their loads go out together, behind the ring's first turn (the kernel issued it before it looked at the anchor).
+    // Their loads go out together ...
     const uint64_t item_step = 2ull * (uint64_t)n + 2ull;
     double* W0 = lds; double* W1 = lds + RS_KC; double* W2 = W1 + 2 * RS_KC + 16;
-    constexpr int C0 = RS_KC / 256, C1 = (2 * RS_KC + 16 + 255) / 256, C2 = (2 * RS_KC + 32 + 255) / 256;
+    constexpr int C0 = RS_KC / 256, C1 = (2 * RS_KC + 16 + 255) / 256, C2 = (2 * RS_KC + RS3_C2 + 255) / 256;
     const double* N0 = a.Nrm + base + 2ull * (uint64_t)k0;
     const double* N1 = N0 + item_step;
     const double* N2 = N1 + item_step;
@@ -354,21 +361,28 @@ __device__ __forceinline__ void rs3_product_full(const Rs3Args& a, const uint64_
     for (int q = 0; q < C1; ++q) { const int x = threadIdx.x + 256 * q; w1[q] = N1[x < 2 * RS_KC + 16 ? x : 0]; }
     if (NT > 1) {
 #pragma unroll
-        for (int q = 0; q < C2; ++q) { const int x = threadIdx.x + 256 * q; w2[q] = N2[x < 2 * RS_KC + 32 ? x : 0]; }
+        for (int q = 0; q < C2; ++q) { const int x = threadIdx.x + 256 * q; w2[q] = N2[x < 2 * RS_KC + RS3_C2 ? x : 0]; }
     }
+    // ... and the ring's first turn straight behind them: loads return in order, so the windows (L2 hits) are in LDS while
+    // the kilobytes of L are still on their way (the other way round the windows queued behind 64 KB from HBM: 3.6-6 us)
+    double2 av[RS3_RING];
+#pragma unroll
+    for (int u = 0; u < RS3_RING; ++u) av[u] = *reinterpret_cast<const double2*>(Lp + u * TS);
 #pragma unroll
     for (int q = 0; q < C0; ++q) W0[threadIdx.x + 256 * q] = w0[q];
 #pragma unroll
     for (int q = 0; q < C1; ++q) { const int x = threadIdx.x + 256 * q; if (x < 2 * RS_KC + 16) W1[x] = w1[q]; }
     if (NT > 1) {
 #pragma unroll
-        for (int q = 0; q < C2; ++q) { const int x = threadIdx.x + 256 * q; if (x < 2 * RS_KC + 32) W2[x] = w2[q]; }
+        for (int q = 0; q < C2; ++q) { const int x = threadIdx.x + 256 * q; if (x < 2 * RS_KC + RS3_C2) W2[x] = w2[q]; }
     }
     __syncthreads();
+    rs_stamp(tr, 2);                                          // windows staged
     // lane (i, g) at the wave's step s reads column kk = kq * RS_KC / 4 + 4 s + g of the part
     const int kk0 = kq * (RS_KC / 4) + g;
     const double* B0 = (i == 0) ? W0 + kk0 : W1 + 2 * kk0 + (i - 1);
     const int st0 = (i == 0) ? 4 : 8;                         // doubles per step
+    constexpr int st1 = 8;
     const double* B1 = W2 + 2 * kk0 + i;
     d4 acc[2][NT];
 #pragma unroll
@@ -379,12 +393,12 @@ __device__ __forceinline__ void rs3_product_full(const Rs3Args& a, const uint64_
     for (int s = 0; s < STEPS; ++s) {
         const int u = s % RS3_RING;
         const double2 al = av[u];
-        if (s + RS3_RING < STEPS) av[u] = *reinterpret_cast<const double2*>(Lp + (s + RS3_RING) * 128);
+        if (s + RS3_RING < STEPS) av[u] = *reinterpret_cast<const double2*>(Lp + (s + RS3_RING) * TS);
         double b[NT];
         b[0] = B0[s * st0];
         if (NT > 1) {
 #pragma unroll
-            for (int ct = 1; ct < NT; ++ct) b[ct] = B1[s * 8 + 16 * (ct - 1)];
+            for (int ct = 1; ct < NT; ++ct) b[ct] = B1[s * st1 + 16 * (ct - 1)];
         }
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) {
@@ -392,66 +406,59 @@ __device__ __forceinline__ void rs3_product_full(const Rs3Args& a, const uint64_
             acc[1][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(al.y, b[ct], acc[1][ct], 0, 0, 0);
         }
     }
-    // quarters 1, 2, 3 are added to quarter 0 in that order (the windows' space is free behind the barrier)
+    // The four quarters meet in LDS (the windows' space is free behind the barrier) and ALL 256 threads add them, in the order
+    // ((q0 + q1) + q2) + q3, and store: thread x takes (row x & 31, candidate x >> 5 + 8 p), so a wave writes two whole
+    // 256-byte row segments per store.  (Wave 0 alone adding its own 24 accumulators and storing them lane by lane -- 64 lines
+    // touched per store instruction, 43 registers spilled around the additions -- took 5 to 16 us per work-group, as long
+    // as its MFMAs: in-kernel stamps, tools/rs_trace.py.)
+    rs_stamp(tr, 3);                                          // this wave's MFMAs issued
     __syncthreads();
-    if (kq > 0) {
-        double* mine = lds + (size_t)(kq - 1) * (8 * NT * 64) + lane;
+    rs_stamp(tr, 4);
+    {
+        double* mine = lds + (size_t)kq * RS3_QSTRIDE + lane;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mine[((t * NT + ct) * 4 + r) * 64] = acc[t][ct][r];
+                for (int r = 0; r < 4; ++r) mine[((t * NT + ct) * 4 + r) * 65] = acc[t][ct][r];      // (65: the readers' bank spread)
     }
     __syncthreads();
-    if (kq != 0) return;
-    for (int q = 0; q < 3; ++q) {
-        const double* theirs = lds + (size_t)q * (8 * NT * 64) + lane;
+    // lane (i, g) of a wave held acc[t][ct][r] = row 8 g + 2 r + t of the group, candidate 16 ct + i
+    double* out = a.part + ((int64_t)by * RS3_CAND) * n + r0;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int ct = 0; ct < NT; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[t][ct][r] += theirs[((t * NT + ct) * 4 + r) * 64];
+    for (int p = 0; p < (16 * NT) / 8; ++p) {
+        const int x = threadIdx.x + 256 * p;
+        const int row = x & 31, c = x >> 5;
+        const int gg = row >> 3, rr = (row >> 1) & 3, tt = row & 1, ii = c & 15, cc = c >> 4;
+        const double* src = lds + ((tt * NT + cc) * 4 + rr) * 65 + ii + 16 * gg;
+        const double v = ((src[0] + src[RS3_QSTRIDE]) + src[2 * RS3_QSTRIDE]) + src[3 * RS3_QSTRIDE];
+        if (r0 + row < n) out[(int64_t)c * n + row] = v;
     }
-    // lane (i, g): acc[t][ct][r] = row r0 + 2 pi(g + 4 r) + t = r0 + 8 g + 2 r + t, candidate 16 ct + i
-    double* out = a.part + ((int64_t)by * RS3_CAND) * n;
-#pragma unroll
-    for (int ct = 0; ct < NT; ++ct) {
-        double* oc = out + (int64_t)(16 * ct + i) * n + r0 + 8 * g;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int64_t row = r0 + 8 * g + 2 * r + t;
-                if (row < n) oc[2 * r + t] = acc[t][ct][r];
-            }
-    }
+    rs_stamp(tr, 5);
 }
 
-// one work-group per unit of the table the sampler built (rs3_unit_table): full parts first, then the ragged ones.  What a
-// work-group waits for before its first MFMA is kept to one memory round trip: its first kilobytes of L depend on the unit
-// alone and go out before the anchor is even looked at; the anchor is ONE 32-byte record (item, start, end of Nrm).
-__global__ __launch_bounds__(256, 3) void rs3_products_kernel(Rs3Args a)
+// one work-group per unit of the table the sampler built (rs3_unit_table): full parts first, then the ragged ones.  The
+// anchor is ONE 32-byte record (item, start, end of Nrm): one scalar load, in flight together with the unit's.
+__global__ __launch_bounds__(256, 4) void rs3_products_kernel(Rs3Args a)
 {
     __shared__ double lds[RS3_LDS_DOUBLES];
+    const uint64_t item0 = a.anchor[0], base = a.anchor[1];   // (both scalar loads of the prologue go out together)
     const uint32_t unit = a.units[blockIdx.x];
     const int bx = (int)(unit & 0xffffu), by = (int)(unit >> 16);
     const bool full = (int)blockIdx.x < a.nfull;
     const double* Lp = a.Lt + ((int64_t)bx * a.nkb + (((int64_t)by * RS_KC) >> 2) + (int64_t)(threadIdx.x >> 6) * (RS_KC / 16)) * 128 + 2 * (threadIdx.x & 63);
-    double2 av[RS3_RING];
-    if (full) {
-#pragma unroll
-        for (int u = 0; u < RS3_RING; ++u) av[u] = *reinterpret_cast<const double2*>(Lp + u * 128);
-    }
-    const uint64_t item0 = a.anchor[0], base = a.anchor[1];
+    long long* tr = (a.trace && threadIdx.x == 0 && (blockIdx.x == 0 || (int)blockIdx.x == a.nfull / 2 || (int)blockIdx.x == a.nfull - 1))
+                        ? a.trace + 64 + 8 * (blockIdx.x == 0 ? 0 : (int)blockIdx.x == a.nfull / 2 ? 1 : 2) : nullptr;
+    rs_stamp(tr, 0);
     if (item0 >= (uint64_t)a.m) return;                       // every item is done (or the draw has failed): a spare pass
+    rs_stamp(tr, 1);
     const bool three = (uint64_t)a.m - item0 >= 3;            // (the last items: slots 0 and 1 alone)
     if (full) {
-        if (three) rs3_product_full<3>(a, base, bx, by, lds, Lp, av);
-        else       rs3_product_full<1>(a, base, bx, by, lds, Lp, av);
+        if (three) rs3_product_full<RS3_NT>(a, base, bx, by, lds, Lp, tr);
+        else       rs3_product_full<1>(a, base, bx, by, lds, Lp, tr);
     } else {
-        if (three) rs3_product_block<3>(a, base, bx, by, lds);
+        if (three) rs3_product_block<RS3_NT>(a, base, bx, by, lds);
         else       rs3_product_block<1>(a, base, bx, by, lds);
     }
 }
@@ -499,6 +506,9 @@ __global__ __launch_bounds__(320) void rs3_slice_kernel(Rs3Args a)
     const int pp = (maxparts + 7) / 8;
     int usum = 0, resolved = 0, sync = 0, fail = 0;
     if (tid == 0) expired = 0;
+    long long* tr = (w == 0 && tid == 0) ? a.trace : nullptr;
+    int ti = 0;
+    rs_stamp(tr, ti++);
     double Fn[R], Mn[R], Yn[R];                               // the NEXT slot's rows
     auto fetch_rows = [&](const int64_t j) {
 #pragma unroll
@@ -518,6 +528,7 @@ __global__ __launch_bounds__(320) void rs3_slice_kernel(Rs3Args a)
         if (start + 2ull * (uint64_t)n + 2ull > a.cap || start + 2ull * (uint64_t)(n - 1) >= nrm_end) { fail = GPIRT_E_RNG; break; }
         const uint64_t p0 = start + 2ull * (uint64_t)n;                       // behind the n normals
         uint32_t uidx = 0, ubase = 0;
+        rs_stamp(tr, ti++);                                                    // slot start
         __syncthreads();                                                       // (ul, psum, cs are still being read from the slot before)
         // the uniforms of the first round: u, the first point and one per rejection
         if (tid < T + 2) { const uint64_t q = p0 + tid; ul[tid] = q < a.cap ? a.U[q] : __builtin_nan(""); }
@@ -548,6 +559,7 @@ __global__ __launch_bounds__(320) void rs3_slice_kernel(Rs3Args a)
         for (int e = 0; e < R; ++e) { F[e] = Fn[e]; M[e] = Mn[e]; Y[e] = Yn[e]; }
         if (g + 1 < ns) fetch_rows(j + 1);
         __syncthreads();
+        rs_stamp(tr, ti++);                                                    // loads in
 #pragma unroll
         for (int e = 0; e < R; ++e) {
             double v = psum[0][32 * e + rl];
@@ -579,24 +591,49 @@ __global__ __launch_bounds__(320) void rs3_slice_kernel(Rs3Args a)
                 __syncthreads();
             }
             // the next T trial points: each is what :50-56 makes of the one before, were it rejected
+            // (the uniforms are read from LDS all at once, as if every rejection consumed one -- true unless the bracket has
+            // closed, eps_min == eps_max, where :56 consumes nothing: then the walk is redone with dependent reads)
             uint32_t Ut[T]; bool Bt[T];
             double my_eps = 0.0;
+            {
+                double uu[T];
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
-                if (lane == t) my_eps = eps;
-                Ut[t] = uidx; Bt[t] = bad_u;
-                if (eps < 0.0) eps_min = eps; else eps_max = eps;              // :50-55
-                if (eps_min == eps_max) eps = eps_min;                         // R::runif(a, a) = a, nothing consumed
-                else eps = eps_min + (eps_max - eps_min) * next_u();           // :56
+                for (int t = 0; t < T; ++t) uu[t] = ul[uidx - ubase + t];
+                double e0 = eps, emin = eps_min, emax = eps_max;
+                bool closed = false, badf = bad_u;
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    if (lane == t) my_eps = e0;
+                    Ut[t] = uidx + t; Bt[t] = badf;
+                    if (e0 < 0.0) emin = e0; else emax = e0;                   // :50-55
+                    if (emin == emax) closed = true;
+                    double x = uu[t];
+                    if (x != x) { badf = true; x = 0.5; }
+                    e0 = emin + (emax - emin) * x;                             // :56
+                }
+                if (!closed) { eps = e0; eps_min = emin; eps_max = emax; uidx += T; bad_u = badf; }
+                else {
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        if (lane == t) my_eps = eps;
+                        Ut[t] = uidx; Bt[t] = bad_u;
+                        if (eps < 0.0) eps_min = eps; else eps_max = eps;      // :50-55
+                        if (eps_min == eps_max) eps = eps_min;                 // R::runif(a, a) = a, nothing consumed
+                        else eps = eps_min + (eps_max - eps_min) * next_u();   // :56
+                    }
+                }
             }
             double mine = 0.0, mine0 = 0.0;                                    // this thread's term sums: its trial point / ll_bar(f)
-            if (wv == 4) {
-                if (lane < T) { cs[lane] = cos(my_eps); cs[T + lane] = sin(my_eps); }
+            if (wv == 4) {                                                     // (cos and sin on two waves: side by side)
+                if (lane < T) cs[lane] = cos(my_eps);
+            } else if (wv == 3) {
+                if (lane < T) cs[T + lane] = sin(my_eps);
             } else if (first && wv == 0 && hh == 0) {
 #pragma unroll
                 for (int e = 0; e < R; ++e) if (Y[e] == Y[e]) mine0 += ll_term(Y[e] * (F[e] + M[e]));          // :29
             }
             __syncthreads();
+            rs_stamp(tr, ti++);                                                // sequence, cos / sin, ll_bar(f)
             const uint64_t tag = a.tag + (uint64_t)sync;
             double* rec = a.partial + (size_t)(sync & 1) * RS3_MAX_WGS * V;
             unsigned long long* flg = a.flags + (size_t)(sync & 1) * RS3_MAX_WGS;
@@ -613,6 +650,7 @@ __global__ __launch_bounds__(320) void rs3_slice_kernel(Rs3Args a)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __syncthreads();
+            rs_stamp(tr, ti++);                                                // terms, partial sums stored
             if (tid == 0) __hip_atomic_store(flg + w, (unsigned long long)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (tid < E) {
                 int spins = 0;
@@ -622,11 +660,16 @@ __global__ __launch_bounds__(320) void rs3_slice_kernel(Rs3Args a)
                     seen = __hip_atomic_load(flg + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 if (seen < tag) expired = 1;
+                // work-group tid's sums, straight behind its flag (nine loads in flight)
+                double t9[V];
+#pragma unroll
+                for (int v = 0; v < V; ++v) t9[v] = __hip_atomic_load(rec + tid * V + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int v = 0; v < V; ++v) vals[tid * V + v] = t9[v];
             }
             __syncthreads();
+            rs_stamp(tr, ti++);                                                // every flag seen, every sum read
             if (expired) { fail = GPIRT_E_HIP; break; }
-            for (int x = tid; x < E * V; x += 320) vals[x] = __hip_atomic_load(rec + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
             if (tid < V * 16) {
                 const int v = tid >> 4, ch = tid & 15, per = (E + 15) / 16;
                 int q1 = (ch + 1) * per; if (q1 > E) q1 = E;
@@ -644,6 +687,7 @@ __global__ __launch_bounds__(320) void rs3_slice_kernel(Rs3Args a)
             double tot[V];
 #pragma unroll
             for (int v = 0; v < V; ++v) tot[v] = tots[v];
+            rs_stamp(tr, ti++);                                                // sums read and added
             ++sync;
             if (first) { log_y = -tot[0] + log(u); first = false; }            // :29
             int hit = -1;
@@ -681,6 +725,8 @@ __global__ __launch_bounds__(320) void rs3_slice_kernel(Rs3Args a)
         ++resolved;
         if (w == 0 && tid == 0) { a.k_out[j] = k; a.posv[j + 1] = start; }
     }
+    rs_stamp(tr, ti++);
+    if (tr) tr[63] = ti;
     if (tid == 0) {
         if (fail) { atomicCAS(a.err, 0, fail); a.anchor[0] = (uint64_t)a.m; }        // every later kernel of the draw leaves at once
         else if (w == 0) { a.anchor[0] = (uint64_t)(item0 + resolved); a.anchor[1] = start; *a.pos = start; }
@@ -861,8 +907,8 @@ void rs3_unit_table(int64_t n, std::vector<uint32_t>& units, int* nfull)
     units.insert(units.end(), ragged.begin(), ragged.end());
 }
 
-// rows per thread of the slice kernel (32 R rows per work-group): the fewest that keep the grid at <= 128 work-groups
-int rs3_slice_rows(int64_t n) { const int64_t r = (n + 4095) / 4096; return r <= 1 ? 1 : r <= 2 ? 2 : r <= 4 ? 4 : 8; }
+// rows per thread of the slice kernel (32 R rows per work-group): the fewest that keep the grid at <= 256 work-groups
+int rs3_slice_rows(int64_t n) { const int64_t r = (n + 8191) / 8192; return r <= 1 ? 1 : r <= 2 ? 2 : r <= 4 ? 4 : 8; }
 int rs3_slice_wgs(int64_t n) { const int64_t rw = 32 * (int64_t)rs3_slice_rows(n); return (int)((n + rw - 1) / rw); }
 
 int launch_rs3_slice(hipStream_t stream, const Rs3Args& a)

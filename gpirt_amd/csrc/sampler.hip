@@ -109,6 +109,7 @@ struct gpirt_sampler_s {
     double* Lt = nullptr;             // L in the candidate products' tile order (rebuilt at the start of every draw_f)
     double *Nrm = nullptr, *rs_part = nullptr;
     uint32_t* rs_units = nullptr; int rs_nunits = 0, rs_nfull = 0;
+    long long* rs_trace = nullptr;    // debug stamps of one pass (gpirt_debug_rs_trace)
     // bookkeeping
     int iter = 0;                     // completed iterations
     bool initialised = false;
@@ -431,6 +432,7 @@ int do_draw_f(gpirt_sampler_s* s)
         for (int64_t q = 0; q < count; ++q, ++pass) {
             s->rs_tag += 1ull << 20;
             a.tag = s->rs_tag;
+            a.trace = (h->rs_trace_pass >= 0 && pass == h->rs_trace_pass) ? s->rs_trace : nullptr;
             GP_TRY(launch_rs3_products(st, a));
             GP_TRY(launch_rs3_slice(st, a));
         }
@@ -857,7 +859,8 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
             const size_t parts = (size_t)((n + RS_KC - 1) / RS_KC);
             const size_t nrm = (size_t)s->U_cap + 6 * (size_t)n + 128;        // (the products read up to 6n + 39 past an anchor)
             GP_A(s->Lt, rs_tile_doubles(n));
-            GP_A(s->posv, m + 1);    GP_A(s->anchor, 4);
+            GP_A(s->posv, m + 1);    GP_A(s->anchor, 4);    GP_A(s->rs_trace, 128);
+            hipMemsetAsync(s->rs_trace, 0, 128 * sizeof(long long), st);
             GP_A(s->rs_flags, 2 * RS3_MAX_WGS);    GP_A(s->rs_partial, 2 * RS3_MAX_WGS * (RS3_TRIALS + 1));
             hipMemsetAsync(s->rs_flags, 0, sizeof(unsigned long long) * 2 * RS3_MAX_WGS, st);
             GP_A(s->Nrm, nrm);       GP_A(s->rs_part, parts * RS3_CAND * (size_t)n);
@@ -1263,7 +1266,7 @@ static int lookup(gpirt_sampler_t s, const char* name, void** p, int64_t* count)
         { "mu_star", s->mu_star, N * m }, { "fstar", s->fstar, N * m }, { "L", s->L, n * n },
         { "logpost", s->logpost, N * n }, { "irf_sum", s->irf_sum, N * m }, { "ess_k", s->ess_k, m },
         { "s", s->s, N }, { "mean", s->mean, N * m }, { "nu", s->NU, n * m }, { "z", s->Z, n * m },
-        { "y", s->y, n * m },
+        { "y", s->y, n * m }, { "rs_trace", s->rs_trace, s->rs_trace ? 128 : 0 },
         { "fstar_full", s->fstar_full, s->fstar_full ? N * s->blk_m : 0 }, { "theta_stage", s->theta_stage, s->theta_stage ? n : 0 },
     };
     for (auto& e : tab)

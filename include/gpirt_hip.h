@@ -88,6 +88,9 @@ int         gpirt_debug_trip_guard(gpirt_handle_t h, int nth);
 /* Tests only: the R-stream replay's speculative draw_f uses candidates for rejection counts < limit only (0: all 32; see
  * DESIGN.md section 2), so the fallback of an item whose predecessor's slice loop ran longer is exercised. */
 int         gpirt_debug_rs_cand_limit(gpirt_handle_t h, int limit);
+/* Debug: pass number `pass` (0-based; < 0: none) of every R-stream draw_f on this handle leaves the in-kernel time stamps of
+ * its two kernels in the sampler's "rs_trace" array (gpirt_sampler_get, 128 64-bit words, 100 MHz): tools/rs_trace.py. */
+int         gpirt_debug_rs_trace(gpirt_handle_t h, int pass);
 int         gpirt_debug_last_mcmc_fallbacks(void);
 /* Debug (GPIRT_RUNTIME=2): where the work-groups of the dependency-driven factorisation land.  host_out == NULL arms it;
  * otherwise copies out [2][4096][4] words {HW_ID, XCC_ID, arrival index, stayed} (update workers, then CU holders), then

@@ -1,0 +1,31 @@
+"""In-kernel time stamps of ONE pass of the R-stream replay's draw_f (rs3_products_kernel + rs3_slice_kernel, rng_ess.hip):
+    python tools/rs_trace.py [n = 8192] [m = 64] [pass = 5]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from gpirt_amd import _lib
+from gpirt_amd.ops import Handle, RStream
+from gpirt_amd.sampler import Sampler
+from gpirt_amd.synthetic import make_responses
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+m = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+p = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+lib = _lib.load()
+y, th0 = make_responses(n, m, seed=20240)
+h = Handle()
+s = Sampler(h, y, th0, rng="reference", rstream=RStream(20240), theta_stabilise=True, fstar_fused=False)
+s.init(); s.check(); s.step(); s.check()
+_lib.check(lib.gpirt_debug_rs_trace(h._h, p))
+s.step(); s.check()
+import ctypes as C
+t = np.empty(128, dtype=np.int64)
+_lib.check(lib.gpirt_sampler_get(s._s, b"rs_trace", C.c_void_p(t.ctypes.data), 128))
+_lib.check(lib.gpirt_debug_rs_trace(h._h, -1))
+ns = int(t[63])
+st = t[:ns].astype(float) / 100.0
+print("slice kernel, work-group 0 (us from its start):", np.round(st - st[0], 2).tolist())
+for b in range(3):
+    q = t[64 + 8 * b: 64 + 8 * b + 6].astype(float) / 100.0
+    print(f"products work-group {b} (0 / middle / last full): anchor {q[1]-q[0]:.2f}, windows staged +{q[2]-q[1]:.2f}, MFMAs +{q[3]-q[2]:.2f}, "
+          f"barrier +{q[4]-q[3]:.2f}, sum + store +{q[5]-q[4]:.2f}; started {q[0]-t[64]/100.0:.2f} us after work-group 0")
+print("slice kernel started %.2f us after the products' work-group 0" % (st[0] - t[64] / 100.0))
