@@ -118,6 +118,8 @@ def main():
 
     def make(form, single=False):
         def factory(y_loc, th, pm, ps, st, item0, m_total):
+            if form == "lowrank":       # the headline: the library's throughput preset, gpirt_fast_options() (include/gpirt_hip.h)
+                return Sampler(handle, y_loc, th, pm, ps, st, preset="fast", seed=20240, item0=item0, m_total=m_total)
             return Sampler(handle, y_loc, th, pm, ps, st, rng="item", seed=20240, theta_stabilise=True,
                            item0=item0, m_total=m_total, **FORMS[form])
         if single:      # the FULL problem on this rank alone (rank 0's single-GPU reference inside a sharded run)

@@ -36,7 +36,10 @@ class Options(C.Structure):
         ("reserved0", C.c_int),
         ("item0", C.c_int64),
         ("m_total", C.c_int64),
-        ("reserved", C.c_int * 8),
+        ("reserved1", C.c_int),
+        ("kernel_fp32", C.c_int),
+        ("kstar_rank", C.c_int),
+        ("reserved", C.c_int * 5),
     ]
 
 
@@ -63,8 +66,6 @@ SIGNATURES = {
     "gpirt_debug_rs_cand_limit": (_i32, [_vp, _i32]),
     "gpirt_debug_rs_trace": (_i32, [_vp, _i32]),
     "gpirt_debug_last_mcmc_fallbacks": (_i32, []),
-    "gpirt_debug_rt_census": (_i32, [_vp, _vp]),
-    "gpirt_debug_rt_tasks": (_i32, [_vp, _vp, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "gpirt_se_kernel": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _dbl]),
     "gpirt_potrf_lower": (_i32, [_vp, _vp, _i64, _i64]),
     "gpirt_factor": (_i32, [_vp, _vp, _i64, _vp, _i64]),
@@ -98,6 +99,7 @@ SIGNATURES = {
     "gpirt_rstream_unif": (_i32, [_vp, _dp, _i64]),
     "gpirt_rstream_norm": (_i32, [_vp, _dp, _i64]),
     "gpirt_default_options": (None, [C.POINTER(Options)]),
+    "gpirt_fast_options": (None, [C.POINTER(Options)]),
     "gpirt_mcmc": (_i32, [_dp, _i64, _i64, _dp, _i32, _i32, _dp, _dp, _dp, C.POINTER(Options), _vp,
                            TICK_FN, _vp, _dp, _dp, _dp, _dp]),
     "gpirt_sampler_create": (_i32, [C.POINTER(_vp), _vp, _dp, _i64, _i64, _dp, _dp, _dp, _dp,
@@ -182,4 +184,11 @@ def check(rc: int) -> int:
 def default_options() -> Options:
     o = Options()
     load().gpirt_default_options(C.byref(o))
+    return o
+
+
+def fast_options() -> Options:
+    """The throughput preset of the C ABI (gpirt_fast_options): item-keyed RNG, theta_stabilise, fused + rank-64 draw_fstar."""
+    o = Options()
+    load().gpirt_fast_options(C.byref(o))
     return o

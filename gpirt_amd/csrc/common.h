@@ -70,12 +70,9 @@ struct Config {
     int  bordered = 1;            // GPIRT_BORDERED: 2 = draw_fstar solves for L^-1 K(theta, c) / L^-1 k* explicitly
     int  early_inv = 1;           // GPIRT_EARLY_INV: 2 = no side work beside the factorisation's last outer panel
     int  prep_early = 1;          // GPIRT_PREP_EARLY: 2 = the factor-only part of the rank-r draw_fstar waits for nu = L z
-    int  runtime = 1;             // GPIRT_RUNTIME: 2 = the dependency-driven factorisation (runtime.hip)
-    int  rt_workers = 0, rt_reserved = 0;   // GPIRT_RT_WORKERS / GPIRT_RT_RESERVED: tuning of runtime.hip (0 = its defaults)
     int  guard_verbose = 0;       // GPIRT_GUARD_VERBOSE: 1 = a hang-guard fallback prints the guard record to stderr
 };
 const Config& env_config();
-struct RtState;                   // runtime.hip: task lists and counters of the dependency-driven factorisation
 
 }  // namespace gpirt
 
@@ -123,8 +120,6 @@ struct gpirt_handle_s {
     // stream of a handle that had already been freed.
     int          live_samplers = 0;
     bool         zombie = false;
-    unsigned int* rt_census = nullptr;    // debug (gpirt_debug_rt_census): where the update workers and CU holders landed
-    gpirt::RtState* rt = nullptr;         // runtime.hip (GPIRT_RUNTIME=2), built on first use for one (n, rows)
     int          guard_fallbacks = 0;
     long long    factor_count = 0;        // factorisations enqueued on this handle (launch_potrf_lower)
     int          rs_trace_pass = -1;      // debug (gpirt_debug_rs_trace): the pass of every replayed draw_f whose kernels stamp their phases

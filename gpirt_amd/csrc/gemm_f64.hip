@@ -392,11 +392,7 @@ __device__ __forceinline__ void gemm_mainloop_fast(const GemmParams& p, const in
 }
 
 // C tile <- alpha * acc + beta * C (masked at the matrix edge and, for syrk, above the diagonal)
-// WTHRU: the tile is handed to OTHER work-groups of a running kernel (runtime.hip's update workers): stored write-through at
-// agent scope (sc1), so that nothing of it stays dirty in this XCD's L2 and the publisher needs no L2 write-back -- with
-// plain stores + an agent-scope release per tile, 72 workers per XCD each flushing everybody's dirty tiles made a tile
-// task ~10x longer than its MFMAs
-template <int T, bool WTHRU = false>
+template <int T>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const int bi, const int bj,
                                               const d4 (&acc)[Cfg<T>::NT][Cfg<T>::NT])
 {
@@ -436,15 +432,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const int bi,
                 if ((interior || (m < p.M && n < p.N)) && !(lower_mask && m < n)) {
                     double v = alpha * acc[tn][tm][r];
                     if (use_c) v += beta * cv[r][tm];
-                    if (WTHRU) __hip_atomic_store(p.C + (int64_t)m + (int64_t)n * p.ldc, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    else p.C[(int64_t)m + (int64_t)n * p.ldc] = v;
+                    p.C[(int64_t)m + (int64_t)n * p.ldc] = v;
                 }
             }
         }
     }
 }
 
-template <bool TA, bool TB, int T, bool WTHRU = false>
+template <bool TA, bool TB, int T>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int bi, const int bj, double* smem)
 {
     constexpr int NT = Cfg<T>::NT;
@@ -470,7 +465,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int bi, con
                       kend > kbeg && ((kend - kbeg) % BK) == 0;
     if (fast) gemm_mainloop_fast<TA, TB, T>(p, bi, bj, smem, kbeg, (kend - kbeg) / BK, acc);
     else gemm_mainloop<TA, TB, T>(p, bi, bj, smem, kbeg, kend, acc);
-    gemm_epilogue<T, WTHRU>(p, bi, bj, acc);
+    gemm_epilogue<T>(p, bi, bj, acc);
 }
 
 // PAD only distinguishes instantiations by name (see launch_gemm_trailing); it adds PAD doubles of LDS.
@@ -840,337 +835,6 @@ int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri,
         }
     }
     return launch_gemm_t<64>(stream, ta, tb, p);
-}
-
-
-// ---- the persistent update kernel of the dependency-driven factorisation (runtime.hip) -------------------------------
-// Every MFMA product of the blocked Cholesky -- the K = 512 update inside an outer panel, the two K = 512 halves and the
-// K = 1024 rest of the update the pivot chain waits for, the trailing updates of the later block columns -- is a list of
-// 64 x 64 x K tile tasks, and ONE launch of this kernel per factorisation works it off: its work-groups (three per compute
-// unit on every CU but the ones held free for the panel kernels) stay resident, claim the first ready task of the urgent
-// queue, else of the bulk queue, run gemm_tile on it and publish.  No kernel boundary between updates, no partial last
-// round of a grid, no parts through a workspace, and the pivot chain's tiles are picked up by the next work-group that
-// finishes anything (a tile task is 25-100 us; with ~600 workers one frees up every fraction of a microsecond).
-// A task is READY when the row-block groups it reads have been swept by the panel kernels (DONE counters) and the tile
-// carries all earlier updates (PROG: per tile the updates keep the launch-ordered schedule's order, so L is the same bit
-// for bit).  Hand-offs are agent-scope release / acquire pairs: an acquire before the tile's loads (operands were written
-// by panel kernels, C by another work-group), a release behind its stores, then the counters.
-// Deadlock freedom: a worker never waits INSIDE a task; a worker without a ready task naps and looks again; both queues
-// are in a topological order of the dependency graph (runtime.hip), so the first unclaimed task of a queue only ever waits
-// for panel kernels (which run on compute units of their own) or for tasks already claimed.  Every wait is bounded: on
-// expiry the worker raises the guard word (info[1]) and the abort word, and everybody leaves.
-namespace {
-
-constexpr int RT_IDLE_LIMIT = 1 << 20;     // naps (~4 us each) without any ready task before giving up
-
-__device__ __forceinline__ unsigned long long rt_ld(const unsigned long long* p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __forceinline__ bool rt_ready(const RtArgs& a, const RtTask& t)
-{
-    if (t.dep0 >= 0 && rt_ld(a.cnt + t.dep0) < (unsigned long long)t.need0 * a.epoch) return false;
-    if (t.dep1 >= 0 && rt_ld(a.cnt + t.dep1) < (unsigned long long)t.need1 * a.epoch) return false;
-    return t.prog_need == 0 || rt_ld(a.prog + t.tile) >= a.prog_base + t.prog_need;     // (a tile's first update waits for nobody)
-}
-
-__global__ __launch_bounds__(256, 3) void update_worker_kernel(RtArgs a)
-{
-    __shared__ __attribute__((aligned(16))) double smem[4 * Cfg<64>::TILE + 16];
-    __shared__ int s_task, s_queue;
-    if (threadIdx.x == 0) {
-        // The compute units the panel kernels need are held by place-holders until (nearly) every worker is resident: the
-        // worker whose arrival reaches the quorum releases them.  A work-group that only becomes resident AFTER that -- the
-        // dispatcher deals work-groups to the 8 XCDs round-robin, so one XCD may hold a few fewer than its share -- would land
-        // on a reserved compute unit: it leaves at once (the queues do not care how many workers there are).
-        int go = 1;
-        unsigned long long v = ~0ull;
-        if (rt_ld(a.ctl + 1) >= a.epoch) go = 0;
-        else {
-            v = __hip_atomic_fetch_add(a.ctl + 0, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (v + 1 == (unsigned long long)a.quorum) __hip_atomic_store(a.ctl + 1, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (a.census) {
-            unsigned int* c = a.census + 4 * blockIdx.x;
-            c[0] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));        // HW_REG_HW_ID
-            c[1] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));       // HW_REG_XCC_ID
-            c[2] = (unsigned int)v; c[3] = (unsigned int)go;
-        }
-        s_task = go;
-    }
-    __syncthreads();
-    if (__builtin_amdgcn_readfirstlane(s_task) == 0) return;
-    __syncthreads();
-    long long st_tasks = 0, st_gemm = 0, st_deq = 0, st_t0 = 0, st_mark = 0, st_q0 = 0;
-    if (a.census && threadIdx.x == 0) { st_t0 = wall_clock64(); st_mark = st_t0; }
-    for (;;) {
-        if (threadIdx.x < 64) {
-            // Wave 0 looks at the first 64 entries behind each queue's head AT ONCE (one entry per lane: its claim flag, its
-            // descriptor, its counters -- a scan by one lane cost ~5 us per entry and made a dequeue 100+ us), moves the head
-            // over the claimed prefix and claims the first ready entry; the urgent queue first.  With nothing ready it naps
-            // on ONE word -- the event count every publisher bumps -- and looks again only when that has moved: 600 idle
-            // workers re-scanning the queues every few microseconds slowed the panel kernels' own polls threefold.
-            const int lane = (int)threadIdx.x;
-            int got = -1, gq = 0;
-            for (;;) {
-                const unsigned long long ev0 = rt_ld(a.ctl + 4);
-                bool finished = true;
-                if (rt_ld(a.ctl + 2) >= a.epoch) got = -2;
-                // one range of a queue: 64 entries at a time from its head on, until a ready one turns up, the range ends or
-                // `max_chunks` have been looked at.  (Entries that wait for work of another queue may sit in front of ready
-                // ones for a while -- the head cannot pass an unclaimed entry -- and with a look-ahead of ONE window eight such
-                // entries walled off the rest of the urgent queue: guard expiry.  So a search that found nothing anywhere is
-                // repeated without the limit before the worker naps.)
-                auto scan = [&](const int q, unsigned long long* hp, const int begin, const int end, const int max_chunks) {
-                    const unsigned long long hraw = rt_ld(hp);
-                    const int h = __builtin_amdgcn_readfirstlane((int)hraw < begin ? begin : (int)hraw);
-                    if (h >= end) return;
-                    finished = false;
-                    int chunks = 0;
-                    for (int base = h; base < end && got == -1 && chunks < max_chunks; base += 64, ++chunks) {
-                        const int i = base + lane;
-                        int st = 1;
-                        bool rdy = false;
-                        if (i < end) {
-                            st = __hip_atomic_load(a.state[q] + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (st == 0) rdy = rt_ready(a, a.tasks[q][i]);
-                        }
-                        if (base == h) {
-                            const unsigned long long claimed = __ballot(i < end && st != 0);
-                            const int lead = (~claimed == 0ull) ? 64 : (__ffsll((unsigned long long)~claimed) - 1);
-                            if (lane == 0 && lead > 0) {
-                                unsigned long long expect = hraw;
-                                __hip_atomic_compare_exchange_strong(hp, &expect, (unsigned long long)(h + lead), __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                                     __HIP_MEMORY_SCOPE_AGENT);
-                            }
-                        }
-                        // Claim ONE of the ready entries, starting from a different one per worker: with every worker going for
-                        // the first, 500 of them lost the same compare-and-swap 60 times in a row (64 claims per ~100 us).
-                        const unsigned long long m = __ballot(rdy);
-                        const int nrdy = __popcll(m);
-                        if (nrdy > 0) {
-                            unsigned long long mm = m;
-                            const int skip = (int)(((unsigned)blockIdx.x * 40503u + (unsigned)ev0 * 7u) % (unsigned)nrdy);
-                            for (int s2 = 0; s2 < skip; ++s2) mm &= mm - 1;
-                            for (int tries = 0; tries < nrdy; ++tries) {
-                                if (!mm) mm = m;
-                                const int l = __ffsll(mm) - 1;
-                                mm &= mm - 1;
-                                int ok = 0;
-                                if (lane == l) {
-                                    int expect = 0;
-                                    ok = __hip_atomic_compare_exchange_strong(a.state[q] + i, &expect, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
-                                }
-                                ok = __shfl(ok, l);
-                                if (ok) { got = base + l; gq = q; break; }
-                            }
-                        }
-                    }
-                };
-                if (got == -1) scan(0, a.head, 0, a.ntasks[0], 1 << 30);
-                // the bulk queue, segment by segment (the step that needs the tiles next): the front of a segment holds the
-                // entries whose operands exist, its end the ones that wait for sub-panels still to come
-                for (int d = 0; d < a.nseg && got == -1; ++d) scan(1, a.head + 1 + d, a.seg_begin[d], a.seg_begin[d + 1], 3);
-                if (got == -1 && finished) got = -2;
-                if (got != -1) break;
-                // Nothing at the fronts.  While things are moving (the event count changes within ~30 us) look at the fronts
-                // again; only when the chip has gone quiet is every entry of every segment looked at -- that search is what
-                // guarantees progress (a ready entry may sit anywhere behind blocked ones), but it walks ~500 windows, and
-                // taken whenever the fronts were empty it cost every worker a millisecond at a time.
-                int quiet = 0;
-                if (lane == 0) {
-                    int spins = 0;
-                    while (rt_ld(a.ctl + 4) == ev0 && rt_ld(a.ctl + 2) < a.epoch && ++spins < 8) __builtin_amdgcn_s_sleep(127);
-                    quiet = (rt_ld(a.ctl + 4) == ev0) ? 1 : 0;
-                }
-                if (!__shfl(quiet, 0)) continue;
-                finished = true;
-                if (rt_ld(a.ctl + 2) >= a.epoch) got = -2;
-                if (got == -1) scan(0, a.head, 0, a.ntasks[0], 1 << 30);
-                for (int d = 0; d < a.nseg && got == -1; ++d) scan(1, a.head + 1 + d, a.seg_begin[d], a.seg_begin[d + 1], 1 << 30);
-                if (got == -1 && finished) got = -2;
-                if (got != -1) break;
-                // nothing ready anywhere: nap until something is published
-                int spins = 0, expired = 0;
-                if (lane == 0) {
-                    while (rt_ld(a.ctl + 4) == ev0 && rt_ld(a.ctl + 2) < a.epoch && ++spins < RT_IDLE_LIMIT) __builtin_amdgcn_s_sleep(127);
-                    if (spins >= RT_IDLE_LIMIT) {
-                        if (atomicCAS(a.info + 1, 0, 1) == 0) {
-                            a.info[2] = -4; a.info[3] = (int)rt_ld(a.head + 1);
-                            a.info[4] = (int)rt_ld(a.head + 0); a.info[5] = 0; a.info[6] = a.ntasks[0]; a.info[7] = a.ntasks[1];
-                        }
-                        __hip_atomic_store(a.ctl + 2, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        expired = 1;
-                    }
-                }
-                if (__shfl(expired, 0)) { got = -2; break; }
-            }
-            if (lane == 0) { s_task = got; s_queue = gq; }
-        }
-        __syncthreads();
-        const int ti = __builtin_amdgcn_readfirstlane(s_task), tq = __builtin_amdgcn_readfirstlane(s_queue);   // wave-uniform: the
-        __syncthreads();                                                            // task's fields then live in scalar registers
-        if (ti < 0) {
-            if (a.census && threadIdx.x == 0) {
-                long long* st = reinterpret_cast<long long*>(a.census + 4 * 8192) + 8 * blockIdx.x;
-                const long long now = wall_clock64();
-                st[0] = st_tasks; st[1] = st_gemm; st[2] = st_deq; st[3] = now - st_t0; st[4] = st_q0;
-            }
-            return;
-        }
-        if (a.census && threadIdx.x == 0) {
-            const long long now = wall_clock64(); st_deq += now - st_mark; st_mark = now; st_tasks += 1; if (tq == 0) st_q0 += 1;
-            const int gidx = ti + (tq ? a.ntasks[0] : 0);
-            if (gidx < 65536) (reinterpret_cast<long long*>(a.census + 4 * 8192) + 8 * 4096)[2 * gidx] = now;
-        }
-        const RtTask* tp = (tq == 0 ? a.tasks[0] : a.tasks[1]) + ti;
-        const int t_bi = tp->bi, t_bj = tp->bj, t_kb = tp->kb, t_klen = tp->klen, t_tile = tp->tile, t_prog = tp->prog_need;
-        const int t_last = tp->last, t_type = tp->type, t_out = tp->out_idx;
-        // what this tile reads was written by other work-groups (panel kernels: the operands; earlier tasks: C)
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        // (the matrix base and leading dimension are re-materialised per task behind an empty asm: otherwise every per-lane
-        // offset gemm_tile derives from them is hoisted out of the task loop and kept alive across it -- 46 spilled VGPRs)
-        int64_t lda_t = a.lda;
-        double* A_t = a.A;
-        asm volatile("" : "+s"(lda_t), "+s"(A_t));
-        GemmParams p;
-        p.lda = p.ldb = lda_t;
-        p.M = a.M; p.Mr = 0;
-        p.mblocks = p.nblocks = 0;
-        p.fastA = p.fastB = ((((uintptr_t)A_t) & 15) == 0) && (lda_t % 2 == 0);
-        p.sA = p.sB = p.sC = 0; p.ksplit = 0;
-        p.fz_A = nullptr; p.fz_lda = 0; p.fz_nb = 0; p.fz_k0 = 0; p.fz_info = nullptr;
-        if (t_type == 0) {
-            p.A = A_t + (int64_t)t_kb * 64 * lda_t; p.B = p.A; p.C = A_t; p.ldc = lda_t;
-            p.N = a.N; p.K = t_klen * 64;
-            p.alpha = -1.0; p.beta = 1.0; p.tri = TRI_SYRK_LOWER;
-            gemm_tile<false, true, 64, true>(p, t_bi, t_bj, smem);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (every byte was stored sc1: accepted = visible at agent scope)
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                __hip_atomic_store(a.prog + t_tile, a.prog_base + (unsigned long long)t_prog + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (t_last) __hip_atomic_fetch_add(a.cnt + t_out, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(a.ctl + 4, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        } else {
-            // X tile = A[rows, sub-panel columns] W^T[:, 64 bj ...]: W^T is upper triangular, so K stops at this column block
-            const int par = (t_kb >> 3) & 1;
-            double* stage = a.stage + (int64_t)par * a.ld_stage * 512;
-            p.A = A_t + (int64_t)t_kb * 64 * lda_t;
-            p.B = A_t + a.wt_row0 + (int64_t)t_kb * 64 * lda_t;
-            p.C = stage; p.ldc = a.ld_stage;
-            p.N = t_klen * 64; p.K = (t_bj + 1) * 64;
-            p.alpha = 1.0; p.beta = 0.0; p.tri = TRI_NONE;
-            gemm_tile<false, false, 64, true>(p, t_bi, t_bj, smem);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                const unsigned long long old = __hip_atomic_fetch_add(a.strip + (int64_t)par * 4096 + t_bi, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_task = ((old + 1) % (unsigned long long)t_last == 0) ? 1 : 0;
-            }
-            __syncthreads();
-            const bool copy_back = __builtin_amdgcn_readfirstlane(s_task) != 0;
-            __syncthreads();
-            if (copy_back) {
-                // the row block's last tile: all of them are in the stage (acquire), copy the row block over A, count it in
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const int r = threadIdx.x & 63, c0 = threadIdx.x >> 6;
-                const int64_t row = (int64_t)t_bi * 64 + r;
-                if (row < a.M) {
-                    for (int c = c0; c < t_klen * 64; c += 4)
-                        __hip_atomic_store(A_t + row + ((int64_t)t_kb * 64 + c) * lda_t, stage[row + (int64_t)c * a.ld_stage], __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (threadIdx.x == 0) {
-                    __hip_atomic_fetch_add(a.cnt + t_out, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_fetch_add(a.ctl + 4, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
-        if (a.census && threadIdx.x == 0) {
-            const long long now = wall_clock64(); st_gemm += now - st_mark; st_mark = now;
-            const int gidx = ti + (tq ? a.ntasks[0] : 0);
-            if (gidx < 65536) (reinterpret_cast<long long*>(a.census + 4 * 8192) + 8 * 4096)[2 * gidx + 1] = now;
-        }
-    }
-}
-
-// Holds a whole compute unit (the dynamic LDS request leaves room for nothing else) until the update workers are all
-// resident: launched BEFORE them, so they land on the other CUs; when these leave, only kernels that need a whole CU --
-// the panel kernels -- find room here, for the rest of the factorisation.
-__global__ __launch_bounds__(64) void cu_holder_kernel(unsigned long long* ctl, unsigned long long epoch, int* info, unsigned int* census)
-{
-    extern __shared__ double hold[];
-    if (threadIdx.x != 0) return;
-    hold[0] = 0.0;
-    if (census) {
-        unsigned int* c = census + 4 * (4096 + blockIdx.x);
-        c[0] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
-        c[1] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
-        c[2] = 0; c[3] = 1;
-    }
-    __hip_atomic_fetch_add(ctl + 3, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int spins = 0;
-    while (rt_ld(ctl + 1) < epoch && rt_ld(ctl + 2) < epoch && ++spins < (1 << 21)) __builtin_amdgcn_s_sleep(64);
-    if (rt_ld(ctl + 1) < epoch && rt_ld(ctl + 2) < epoch) {
-        if (atomicCAS(info + 1, 0, 1) == 0) { info[2] = -5; info[3] = (int)blockIdx.x; info[4] = (int)rt_ld(ctl + 0); info[5] = 0; info[6] = 0; info[7] = 0; }
-        __hip_atomic_store(ctl + 2, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-__global__ void wait_counter_kernel(const unsigned long long* cnt, unsigned long long need, unsigned long long* abort_word,
-                                    unsigned long long epoch, int* info)
-{
-    if (threadIdx.x != 0) return;
-    int spins = 0;
-    while (rt_ld(cnt) < need && ++spins < (1 << 21)) __builtin_amdgcn_s_sleep(32);
-    if (rt_ld(cnt) < need) {
-        if (atomicCAS(info + 1, 0, 1) == 0) { info[2] = -6; info[3] = 0; info[4] = (int)need; info[5] = 0; info[6] = (int)rt_ld(cnt); info[7] = 0; }
-        if (abort_word) __hip_atomic_store(abort_word, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-}  // namespace
-
-int update_workers_per_cu(int* per_cu)
-{
-    int nb = 0;
-    GP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(update_worker_kernel), 256, 0));
-    *per_cu = nb;
-    return 0;
-}
-
-int launch_update_workers(hipStream_t stream, const RtArgs& a, int grid)
-{
-    hipLaunchKernelGGL(update_worker_kernel, dim3((unsigned)grid), dim3(256), 0, stream, a);
-    GP_HIP(hipGetLastError());
-    return 0;
-}
-
-int launch_cu_holders(hipStream_t stream, unsigned long long* ctl, unsigned long long epoch, int count, int* info, unsigned int* census)
-{
-    static bool attr_set = false;
-    const size_t lds = panel_ll_smem_bytes();         // what a panel work-group takes: nothing else fits beside a holder either
-    if (!attr_set) {
-        GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cu_holder_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(cu_holder_kernel, dim3((unsigned)count), dim3(64), lds, stream, ctl, epoch, info, census);
-    GP_HIP(hipGetLastError());
-    return 0;
-}
-
-int launch_wait_counter(hipStream_t stream, const unsigned long long* cnt, unsigned long long need, int* info)
-{
-    hipLaunchKernelGGL(wait_counter_kernel, dim3(1), dim3(64), 0, stream, cnt, need, (unsigned long long*)nullptr, 0ull, info);
-    GP_HIP(hipGetLastError());
-    return 0;
 }
 
 }  // namespace gpirt

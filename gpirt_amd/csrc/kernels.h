@@ -41,10 +41,8 @@ int launch_se_kernel_lower(hipStream_t stream, const double* x, int64_t n, doubl
                            double jitter, bool fp32 = false);
 
 // potrf.hip
-// has_scratch: the buffer holds potrf_runtime_scratch_rows() rows of scratch from row potrf_runtime_scratch_row0(n +
-// extra_rows) on (lda covers them): the dependency-driven schedule may be used (runtime.hip, GPIRT_RUNTIME=2)
 int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda,
-                       bool zero_upper, bool reset_info = true, int64_t extra_rows = 0, bool has_scratch = false);
+                       bool zero_upper, bool reset_info = true, int64_t extra_rows = 0);
 
 int potrf_guard_reset(gpirt_handle_t h, hipStream_t stream);      // hang-guard fallback: see potrf.hip
 
@@ -63,59 +61,8 @@ int potrf_panel_copy(hipStream_t stream, double* A, int64_t n, int64_t lda, int6
                      int64_t extra_rows = 0, int half = 2, int64_t capacity = -1);
 
 // panel.hip: columns [K0, c1) of the Cholesky factor, all rows below, one persistent kernel
-// (runtime.hip) dataflow links of a panel launch: see PanelArgs in panel.hip
-struct PanelLink { const unsigned long long* in_cnt; const unsigned int* in_need; unsigned long long epoch; unsigned long long* done_cnt; int rows_per_group;
-                   int64_t extra_row0; unsigned long long* ev_cnt; };
-
-// runtime.hip / gemm_f64.hip: one 64 x 64 x K tile product of the dependency-driven factorisation
-//   C[tile (bi, bj)] -= A[rows of bi, K] A[rows of bj, K]^T,  K = columns [64 kb, 64 (kb + klen))
-//   (type 0)  C[tile (bi, bj)] -= A[rows of bi, K] A[rows of bj, K]^T,  K = columns [64 kb, 64 (kb + klen))
-//   (type 1)  the far rows' share of a sub-panel, X = A W^T with W the inverse of its diagonal block (W^T = what the panel
-//             kernel's sweep leaves in the identity rows below the matrix): STAGE[rows of bi, 64 bj ...] = A[rows of bi,
-//             columns 64 kb ... 64 (kb + klen)) W^T[:, 64 bj ...]; the work-group that finishes a row block's last tile
-//             copies the row block back over A and counts it into the DONE counters like a panel kernel would
-struct RtTask {
-    uint16_t bi, bj, kb, klen;
-    int32_t  dep0, dep1;          // indices into the counters (-1: none); ready when CNT[dep] >= need * epoch
-    uint32_t need0, need1;
-    int32_t  tile;                // index into the tile progress words; ready when PROG[tile] >= prog_base + prog_need
-    uint16_t prog_need;           //   ... (the updates of one tile are applied in one fixed order)
-    uint8_t  last;                // type 0: 1 = the tile is complete -> CNT[out_idx] += 1; type 1: tiles per row block
-    uint8_t  type;
-    int32_t  out_idx;
-};
-struct RtArgs {
-    double* A; int64_t lda; int M, N;
-    const RtTask* tasks[2]; int ntasks[2];        // queue 0: what the pivot chain waits for next; queue 1: everything else
-    int* state[2];                                // 0 = free, 1 = claimed
-    unsigned long long* head;                     // [0] urgent queue; [1 + d] bulk segment d: entries claimed from the segment's start
-    int nseg; int seg_begin[40];                  // bulk queue = nseg segments [seg_begin[d], seg_begin[d + 1])
-    unsigned long long* cnt;                      // DONE (+= 1 per finished row block: panel kernels, type-1 tasks) | IN (+= 1 per
-                                                  //   finished tile: type-0 tasks; panel kernels and type-1 tasks wait on it)
-    unsigned long long* prog;
-    unsigned long long* strip;                    // [2][row blocks]: finished type-1 tiles per row block (sub-panel parity)
-    double* stage; int64_t ld_stage;              // [2] x (rows x 512): type-1 results before they are copied back
-    int64_t wt_row0;                              // first identity row
-    unsigned long long epoch, prog_base;
-    unsigned long long* ctl;                      // [0] workers arrived  [1] release of the CU holders  [2] abort  [3] holders arrived
-                                                  // [4] event count: += 1 with every publication (what idle workers nap on)
-    unsigned int* census;                         // debug (may be null): [kind 0 worker / 1 holder][index][4] = {HW_ID, XCC_ID, arrival, stayed}
-    int nworkers, quorum;                         // grid; arrivals that release the CU holders (ctl[0] is cleared per factorisation)
-    int* info;
-};
-int launch_update_workers(hipStream_t stream, const RtArgs& a, int grid);
-int update_workers_per_cu(int* per_cu);
-int launch_cu_holders(hipStream_t stream, unsigned long long* ctl, unsigned long long epoch, int count, int* info, unsigned int* census = nullptr);
-int launch_wait_counter(hipStream_t stream, const unsigned long long* cnt, unsigned long long need, int* info);
-int potrf_runtime(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t nr);
-bool potrf_runtime_usable(gpirt_handle_t h, int64_t n, int64_t nr);
-int64_t potrf_runtime_scratch_row0(int64_t nr);     // first of the potrf_runtime_scratch_rows() identity rows a caller must provide
-int64_t potrf_runtime_scratch_rows();
-void potrf_runtime_reset(gpirt_handle_t h);
-int potrf_runtime_tasks(gpirt_handle_t h, RtTask* host_out, int max_tasks, int* n0, int* n1);
-void potrf_runtime_destroy(gpirt_handle_t h);
 int launch_panel_ll(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t K0, int64_t c1,
-                    int64_t row_end = 0, unsigned long long* epoch_out = nullptr, const PanelLink* link = nullptr);
+                    int64_t row_end = 0, unsigned long long* epoch_out = nullptr);
 size_t panel_ll_smem_bytes();
 
 // trsm.hip

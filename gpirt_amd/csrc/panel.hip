@@ -47,22 +47,7 @@ struct PanelArgs {
     int nrb;                               // row blocks of this panel (rows K0 .. n-1)
     int ncb;                               // column blocks of this panel
     int rb_begin, rb_end;                  // this launch sweeps the panel's row blocks [rb_begin, rb_end) (relative to K0)
-    int rb2_begin, rb2_end;                // ... and a second range (runtime.hip: the identity rows below the matrix, whose sweep
-                                           // leaves the inverse of the sub-panel's diagonal block); empty when rb2_begin >= rb2_end
     long long* trace;                      // optional (tools/micro/panel_bench.hip): [row block][step][8] 100 MHz stamps
-    // Dataflow links of the dependency-driven factorisation (runtime.hip; all null in the launch-ordered schedule).  Row
-    // blocks are grouped by outer panel of rows (group = absolute row block / link_rpb):
-    //   in_cnt / in_need   the row block's INPUT (its tiles of this sub-panel's columns, fully updated by the persistent
-    //                      update kernel) is ready when in_cnt[group] >= in_need[group] -- this kernel may be resident long
-    //                      before that (its work-groups then spin here, on compute units reserved for them);
-    //   done_cnt           += 1 per finished row block, behind an agent-scope release of its X stores: what the update
-    //                      kernel's tasks wait for.
-    const unsigned long long* in_cnt;
-    const unsigned int* in_need;           // per group and factorisation; the counters run on: target = in_need * link_epoch
-    unsigned long long link_epoch;
-    unsigned long long* done_cnt;
-    unsigned long long* ev_cnt;            // += 1 with every done_cnt add: the one word idle update workers nap on
-    int link_rpb;
 };
 
 #define PANEL_STAMP(slot)                                                                         \
@@ -277,21 +262,11 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
     double* A = p.A;      // read and written by many work-groups: no restrict anywhere in this file
     const int64_t lda = p.lda, n = p.n;
     const int cb0 = (int)(p.K0 / PB);                 // absolute index of the panel's first block
-    const int n_first = p.rb_end - p.rb_begin, n_all = n_first + (p.rb2_end > p.rb2_begin ? p.rb2_end - p.rb2_begin : 0);
+    const int n_all = p.rb_end - p.rb_begin;
     for (int idx = blockIdx.x; idx < n_all; idx += gridDim.x) {
-        const int Rr = idx < n_first ? p.rb_begin + idx : p.rb2_begin + (idx - n_first);
+        const int Rr = p.rb_begin + idx;
         const int64_t row0 = p.K0 + (int64_t)Rr * PB;
         const bool is_diag = Rr < p.ncb;
-        if (p.in_cnt && idx < n_first) {
-            // (runtime.hip) the tiles this row block starts from are written by the update kernel while this kernel is
-            // already resident: wait for them, then drop whatever this CU's L1 holds of them (agent-scope acquire)
-            const int grp = (cb0 + Rr) / p.link_rpb;
-            unsigned long long have_in = 0;
-            if (!wait_prog(p.in_cnt + grp, (unsigned long long)p.in_need[grp] * p.link_epoch, have_in, &s_seen, p.info, false, cb0 + Rr, -3 - grp)) return;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
         const int jend = is_diag ? Rr : p.ncb;        // off-diagonal column blocks of this row block
         unsigned long long* my_prog = p.prog + cb0 + Rr;
         d4 D[4];
@@ -573,18 +548,6 @@ __global__ __launch_bounds__(256) void panel_ll_kernel(PanelArgs p)
             publish(my_prog, p.base + (unsigned long long)(Rr + 1));
             PANEL_STAMP(1);
         }
-        if (p.done_cnt) {
-            // (runtime.hip) this row block's X is complete: every wave's stores accepted, then ONE lane writes the XCD's
-            // dirty lines back (rows nobody reads inside this kernel are stored plainly) and counts the row block in
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_fetch_add(p.done_cnt + (cb0 + Rr) / p.link_rpb, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (p.ev_cnt) __hip_atomic_fetch_add(p.ev_cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
         __syncthreads();
     }
 }
@@ -637,7 +600,7 @@ int panel_workspaces(gpirt_handle_t h, hipStream_t stream, int64_t n)
 // Factor panel columns [K0, c1) with the persistent kernel, sweeping the rows [K0, row_end) (row_end <= 0: all n rows).
 // Opens a new epoch of the progress counters.
 int launch_panel_ll(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t K0, int64_t c1,
-                    int64_t row_end, unsigned long long* epoch_out, const PanelLink* link)
+                    int64_t row_end, unsigned long long* epoch_out)
 {
     if (K0 >= c1) return 0;
     GP_TRY(panel_workspaces(h, stream, n));
@@ -661,17 +624,7 @@ int launch_panel_ll(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, 
         if (row_end < c1 || (row_end - K0) % PB != 0) { set_error("restricted panel launch: row_end must cover the diagonal blocks in whole 64-row blocks"); return GPIRT_E_ARG; }
         p.rb_end = (int)((row_end - K0) / PB);
     }
-    p.in_cnt = link ? link->in_cnt : nullptr; p.in_need = link ? link->in_need : nullptr;
-    p.link_epoch = link ? link->epoch : 0;
-    p.done_cnt = link ? link->done_cnt : nullptr; p.link_rpb = link ? link->rows_per_group / PB : 1;
-    p.ev_cnt = link ? link->ev_cnt : nullptr;
-    p.rb2_begin = p.rb2_end = 0;
-    if (link && link->extra_row0 > 0) {          // the identity rows [extra_row0, extra_row0 + (c1 - K0)) ride along
-        if ((link->extra_row0 - K0) % PB != 0 || link->extra_row0 + (c1 - K0) > n) { set_error("panel launch: bad extra rows"); return GPIRT_E_ARG; }
-        p.rb2_begin = (int)((link->extra_row0 - K0) / PB);
-        p.rb2_end = p.rb2_begin + p.ncb;
-    }
-    const int nb = (p.rb_end - p.rb_begin) + (p.rb2_end - p.rb2_begin);
+    const int nb = p.rb_end - p.rb_begin;
     const int grid = nb < n_cu ? nb : n_cu;
     hipLaunchKernelGGL(panel_ll_kernel, dim3((unsigned)grid), dim3(256), panel_ll_smem_bytes(), stream, p);
     GP_HIP(hipGetLastError());

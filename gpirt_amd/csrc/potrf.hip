@@ -281,24 +281,11 @@ int potrf_panel_update(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
 // every panel and trailing update and end up holding  E L^-T  for the rows E they held on entry (a bordered Cholesky:
 // draw_fstar's L^-1 K(theta, c) comes out of the factorisation instead of a triangular solve).  Needs n % 64 == 0.
 int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda,
-                       bool zero_upper, bool reset_info, int64_t extra_rows, bool has_scratch)
+                       bool zero_upper, bool reset_info, int64_t extra_rows)
 {
     if (n <= 0) return 0;
     if (extra_rows > 0 && (n % NBI) != 0) { set_error("bordered factorisation needs n %% 64 == 0"); return GPIRT_E_ARG; }
     const int64_t nr = n + extra_rows;          // rows of every panel / update; column limits stay n
-    if (has_scratch && !zero_upper && potrf_runtime_usable(h, n, nr) &&
-        lda >= potrf_runtime_scratch_row0(nr) + potrf_runtime_scratch_rows()) {
-        // GPIRT_RUNTIME=2: one persistent update kernel + windowed sub-panel kernels on reserved compute units (runtime.hip)
-        if (reset_info) GP_HIP(hipMemsetAsync(h->d_info, 0, sizeof(int), stream));
-        GP_TRY(potrf_runtime(h, stream, A, n, lda, nr));
-        h->factor_count += 1;
-        if (h->trip_guard_at >= 0 && h->factor_count == h->trip_guard_at) {
-            const int64_t c = n / 2;
-            GP_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->d_info + 1), 1, 1, stream));
-            GP_HIP(hipMemset2DAsync(A + c + c * lda, (size_t)lda * 8, 0xFF, (size_t)(n - c) * 8, (size_t)8, stream));
-        }
-        return 0;
-    }
     const int64_t nbo = potrf_panel_width();
     const int64_t nbp_la = round64(h->cfg.nbp, NBP);
     const bool persistent = h->cfg.panel != 2;
@@ -449,7 +436,6 @@ int potrf_guard_reset(gpirt_handle_t h, hipStream_t stream)
     GP_HIP(hipMemsetAsync(h->d_info, 0, 8 * sizeof(int), stream));
     if (h->d_prog) GP_HIP(hipMemsetAsync(h->d_prog, 0, 2 * h->prog_cap * sizeof(unsigned long long), stream));
     GP_HIP(hipStreamSynchronize(stream));
-    potrf_runtime_reset(h);
     h->guard_fallbacks += 1;
     return 0;
 }

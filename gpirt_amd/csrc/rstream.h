@@ -94,5 +94,22 @@ struct RStream {
 // owner / resolve: a sampler that replays this stream keeps it AHEAD of what the chain has consumed (uniforms generated
 // while the device works, sampler.hip: stream_begin / stream_end); whoever looks at the state, draws from it or destroys
 // it calls rstream_sync first, which puts the state back to exactly the consumed position and detaches the sampler.
-struct gpirt_rstream_s { gpirt::RStream r; void* owner = nullptr; void (*resolve)(void* owner, bool gone) = nullptr; };
+// attached / forget: EVERY sampler created on this stream, running ahead or not (before its first step, after an error
+// handed the generator back, after another sampler took it over): gpirt_rstream_destroy tells each of them that the
+// stream is gone, so that none is left with a dangling pointer (a later step then fails with "the R stream of this sampler
+// has been destroyed" instead of reading freed memory).
+struct gpirt_rstream_s {
+    gpirt::RStream r;
+    void* owner = nullptr;
+    void (*resolve)(void* owner, bool gone) = nullptr;
+    std::vector<void*> attached;
+    void (*forget)(void* sampler) = nullptr;
+};
 inline void rstream_sync(gpirt_rstream_s* r, bool gone = false) { if (r && r->owner) r->resolve(r->owner, gone); }
+inline void rstream_gone(gpirt_rstream_s* r)
+{
+    if (!r) return;
+    rstream_sync(r, true);
+    if (r->forget) for (void* s : r->attached) r->forget(s);
+    r->attached.clear();
+}

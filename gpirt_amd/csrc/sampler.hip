@@ -43,7 +43,7 @@ struct gpirt_sampler_s {
            *fstar = nullptr, *L = nullptr, *tstar = nullptr, *kstar = nullptr, *rhs = nullptr,
            *mean = nullptr, *s = nullptr, *Gpm = nullptr, *logpost = nullptr, *irf_sum = nullptr,
            *pm = nullptr, *ps = nullptr, *step = nullptr;
-    // low-rank K* (opt.reserved[2] = r > 0): Chebyshev nodes, interpolation matrix V (N x r), split-K parts
+    // low-rank K* (opt.kstar_rank = r > 0): Chebyshev nodes, interpolation matrix V (N x r), split-K parts
     int kr = 0;
     double *knodes = nullptr, *kV = nullptr, *kparts = nullptr, *kP = nullptr;
     // L is stored (n + ext) x n with leading dimension ldl.  ext = kr when the low-rank K* is on and n % 64 == 0: the
@@ -55,7 +55,6 @@ struct gpirt_sampler_s {
     // from outside, rebuilt by an explicit solve on demand (rebuild_rows).
     int64_t ext = 0, ldl = 0;
     bool ext_grid = false, rows_valid = false;
-    bool scratch = false;             // the L buffer carries the scratch rows of the dependency-driven factorisation (runtime.hip)
     // Work that needs only L (not this iteration's f) runs on a stream of the sampler's own, beside draw_f's elliptical
     // slice kernel: the part of the low-rank draw_fstar that depends on the factor alone (C = L^-T B, G = B^T B).
     // haux is the main handle's side handle (h->aux, shared by the samplers of that handle, not owned) on that stream (its own trsm / split-K workspaces: several
@@ -178,6 +177,13 @@ void ahead_resolve(void* owner, bool gone)
     s->ahead_gen = s->ahead_used = s->a_len = 0;
     if (s->rs_obj) { s->rs_obj->owner = nullptr; s->rs_obj->resolve = nullptr; }
     if (gone) { s->rs_obj = nullptr; s->rs = nullptr; }
+}
+
+// gpirt_rstream_destroy: the stream object this sampler was created on is being freed
+void rstream_forget(void* sampler)
+{
+    gpirt_sampler_s* s = static_cast<gpirt_sampler_s*>(sampler);
+    s->rs_obj = nullptr; s->rs = nullptr;
 }
 
 int stream_begin(gpirt_sampler_s* s, uint64_t count)
@@ -652,7 +658,7 @@ int aux_join(gpirt_sampler_s* s, bool beta_too = true, bool z_too = true)
 int build_cov(gpirt_sampler_s* s)
 {
     hipStream_t st = s->h->stream;
-    GP_TRY(launch_se_kernel_lower(st, s->theta, s->n, s->L, s->ldl, GPIRT_JITTER, s->opt.reserved[1] != 0));
+    GP_TRY(launch_se_kernel_lower(st, s->theta, s->n, s->L, s->ldl, GPIRT_JITTER, s->opt.kernel_fp32 != 0));
     if (s->ext > 0 && !s->ext_grid) GP_TRY(launch_se_kernel(st, s->knodes, s->ext, s->theta, s->n, s->L + s->n, s->ldl, 0.0));
     if (s->ext_grid) GP_TRY(launch_se_kernel(st, s->tstar, s->N, s->theta, s->n, s->L + s->n, s->ldl, 0.0));
     return 0;
@@ -680,7 +686,7 @@ int do_factor(gpirt_sampler_s* s)
     invalidate_factor_products(s);
     GP_TRY(build_cov(s));                                                                                  // :76-77
     s->rows_valid = true;
-    GP_TRY(launch_potrf_lower(s->h, st, s->L, s->n, s->ldl, false, !s->sticky_info, s->ext, s->scratch)); // :78
+    GP_TRY(launch_potrf_lower(s->h, st, s->L, s->n, s->ldl, false, !s->sticky_info, s->ext)); // :78
     // The low-rank draw_fstar's transposed solve (fstar_prep) goes through the inverses of L's 1024 x 1024 diagonal blocks:
     // ~5 GFLOP to build at n = 8192, and they only need the DIAGONAL blocks, final panel by panel.  Those of every outer
     // panel but the last are built on the sampler's own stream while the last outer panel is factored (16 + 8 whole-CU
@@ -795,6 +801,7 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
         }
         rstream_sync(rs);            // (another sampler may be running ahead on this stream: it hands it back first)
         s->rs = &rs->r; s->rs_obj = rs;
+        rs->attached.push_back(s); rs->forget = rstream_forget;
     }
     const int64_t N = s->N;
     hipStream_t st = h->stream;
@@ -802,7 +809,7 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
 #define GP_A(p, cnt) do { rc = dalloc(s, &(p), (size_t)(cnt)); if (rc) { gpirt_sampler_destroy(s); return rc; } } while (0)
     GP_A(s->y, n * m);       GP_A(s->Ypm, n * 2 * m);  GP_A(s->theta, n);       GP_A(s->theta_new, n);
     GP_A(s->f, n * m);       GP_A(s->Z, n * m);        GP_A(s->NU, n * (m > 1 + TRMV_SPLIT ? m : 1 + TRMV_SPLIT));   GP_A(s->beta, 2 * m);   // (NU: >= 1 + TRMV_SPLIT columns, launch_trmv_lower's parts)
-    s->kr = s->opt.reserved[2];
+    s->kr = s->opt.kstar_rank;
     if (s->kr != 0 && (!s->opt.fstar_fused || s->kr < 16 || s->kr > 128 || (s->kr % 16) != 0)) {
         set_error("kstar_rank must be a multiple of 16 in 16..128 and needs fstar_fused");
         gpirt_sampler_destroy(s);
@@ -815,12 +822,6 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
         s->ext_grid = true;
     }
     s->ldl = n + s->ext;
-    if (!stream_mode(s) && potrf_runtime_usable(h, n, n + s->ext)) {
-        // GPIRT_RUNTIME=2 (runtime.hip): rows of scratch below the factor -- the identity rows whose sweep leaves the inverse
-        // of a sub-panel's diagonal block -- from the next multiple of an outer panel on
-        s->scratch = true;
-        s->ldl = potrf_runtime_scratch_row0(n + s->ext) + potrf_runtime_scratch_rows();
-    }
     GP_A(s->mu, n * m);      GP_A(s->mu_star, N * m + 1); GP_A(s->fstar, N * m + 1); GP_A(s->L, s->ldl * n);
     GP_A(s->tstar, N + 1);   GP_A(s->rhs, n * (N + m) + 2); GP_A(s->mean, N * m + 1); GP_A(s->s, N + 1);
     GP_A(s->Gpm, ((N + 127) / 128 * 128) * 2 * m + 2); GP_A(s->logpost, N * n + 2); GP_A(s->irf_sum, N * m + 1);
@@ -977,6 +978,10 @@ int gpirt_sampler_destroy(gpirt_sampler_t s)
     if (!s) return 0;
     if (s->h) hipStreamSynchronize(s->h->stream);
     if (s->rs_obj && s->rs_obj->owner == s) ahead_resolve(s, false);     // the caller's generator goes back to the consumed position
+    if (s->rs_obj) {
+        auto& at = s->rs_obj->attached;
+        for (size_t q = 0; q < at.size(); ++q) if (at[q] == s) { at.erase(at.begin() + (std::ptrdiff_t)q); break; }
+    }
     if (s->cs) { hipStreamSynchronize(s->cs); hipStreamDestroy(s->cs); }
     if (s->h_next) hipHostFree(s->h_next);
     if (s->ev_up) hipEventDestroy(s->ev_up);

@@ -35,8 +35,8 @@ def _options(rng, seed, theta_stabilise, fstar_fused, device, item0=0, m_total=0
     o.device = -1 if device is None else int(device)
     o.item0 = int(item0)
     o.m_total = int(m_total)
-    o.reserved[1] = int(bool(kernel_fp32))
-    o.reserved[2] = int(kstar_rank)
+    o.kernel_fp32 = int(bool(kernel_fp32))
+    o.kstar_rank = int(kstar_rank)
     return o
 
 
@@ -103,11 +103,13 @@ def gpirtMCMC(data, sample_iterations, burn_iterations, vote_codes=None, beta_pr
 
 
 class Sampler:
-    """Stage-driven sampler (gpirt_sampler_*): device-resident state, one iteration per step()."""
+    """Stage-driven sampler (gpirt_sampler_*): device-resident state, one iteration per step().
+    preset="fast": the options are gpirt_fast_options() (what bench.py's headline is timed with) with this call's seed,
+    item0 / m_total and kernel_fp32; rng, theta_stabilise, fstar_fused and kstar_rank are then the preset's."""
 
     def __init__(self, handle, y, theta_init, beta_prior_means=None, beta_prior_sds=None,
                  beta_proposal_sds=None, *, rng="item", seed=1, rstream=None, theta_stabilise=True,
-                 fstar_fused=False, item0=0, m_total=0, kernel_fp32=False, kstar_rank=0):
+                 fstar_fused=False, item0=0, m_total=0, kernel_fp32=False, kstar_rank=0, preset=None):
         self.lib = _lib.load()
         self.handle = handle
         y = _f64(y)
@@ -118,7 +120,15 @@ class Sampler:
         st = _f64(np.full((2, m), 0.1) if beta_proposal_sds is None else beta_proposal_sds)
         theta0 = np.ascontiguousarray(theta_init, dtype=np.float64)
         self.rs = rstream
-        o = _options(rng, seed, theta_stabilise, fstar_fused, handle.device, item0, m_total, kernel_fp32, kstar_rank)
+        if preset == "fast":
+            o = _lib.fast_options()
+            o.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+            o.device = -1 if handle.device is None else int(handle.device)
+            o.item0, o.m_total, o.kernel_fp32 = int(item0), int(m_total), int(bool(kernel_fp32))
+        elif preset is None:
+            o = _options(rng, seed, theta_stabilise, fstar_fused, handle.device, item0, m_total, kernel_fp32, kstar_rank)
+        else:
+            raise ValueError(f"unknown preset {preset!r}")
         s = C.c_void_p()
         check(self.lib.gpirt_sampler_create(C.byref(s), handle.ptr, _ptr(y), self.n, m, _ptr(theta0), _ptr(pm),
                                             _ptr(ps), _ptr(st), C.byref(o),

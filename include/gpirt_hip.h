@@ -71,7 +71,7 @@ int         gpirt_destroy(gpirt_handle_t h);
 int         gpirt_synchronize(gpirt_handle_t h);
 int         gpirt_set_stream(gpirt_handle_t h, void* stream);
 /* The library's switches (README.md: GPIRT_PANEL, GPIRT_LOOKAHEAD, GPIRT_DEFER, GPIRT_TRSM_INV, GPIRT_LL_EXACT,
- * GPIRT_BORDERED, GPIRT_EARLY_INV, GPIRT_PREP_EARLY, GPIRT_RUNTIME; GPIRT_NBO / GPIRT_NBP read-only).  The environment
+ * GPIRT_BORDERED, GPIRT_EARLY_INV, GPIRT_PREP_EARLY; GPIRT_NBO / GPIRT_NBP read-only).  The environment
  * is read ONCE per process; every handle starts from those values and a caller may change them per handle here (drains
  * the handle's stream; takes effect from the next call on).  Nothing in the library reads the environment per call. */
 int         gpirt_config_get(gpirt_handle_t h, const char* name, int* value);
@@ -92,12 +92,6 @@ int         gpirt_debug_rs_cand_limit(gpirt_handle_t h, int limit);
  * its two kernels in the sampler's "rs_trace" array (gpirt_sampler_get, 128 64-bit words, 100 MHz): tools/rs_trace.py. */
 int         gpirt_debug_rs_trace(gpirt_handle_t h, int pass);
 int         gpirt_debug_last_mcmc_fallbacks(void);
-/* Debug (GPIRT_RUNTIME=2): where the work-groups of the dependency-driven factorisation land.  host_out == NULL arms it;
- * otherwise copies out [2][4096][4] words {HW_ID, XCC_ID, arrival index, stayed} (update workers, then CU holders), then
- * [4096][8] 64-bit per-worker counters and [65536][2] 64-bit task start / end stamps (100 MHz): tools/rt_trace.py. */
-int         gpirt_debug_rt_census(gpirt_handle_t h, unsigned int* host_out);
-/* ... and the task lists the update workers work off (32-byte records: csrc/kernels.h RtTask), urgent queue first. */
-int         gpirt_debug_rt_tasks(gpirt_handle_t h, void* host_out, int max_tasks, int* n_urgent, int* n_bulk);
 /* Peak fp64 MFMA rate of this device measured by a back-to-back v_mfma_f64_16x16x4_f64 loop
  * (TFLOP/s); used to calibrate the roofline. */
 int         gpirt_calibrate_mfma_f64(gpirt_handle_t h, double* tflops);
@@ -240,12 +234,15 @@ typedef struct gpirt_options {
      * global problem with m_total items; y / priors / outputs passed in are the LOCAL columns. */
     int64_t  item0;
     int64_t  m_total;
-    int      reserved[8];     /* reserved[1] = 1: build K(theta,theta) with single-precision exp() before the
-                               * fp64 factorisation (BASELINE config C5; parity then only statistical)
-                               * reserved[2] = r (16..128, multiple of 16; needs fstar_fused): draw_fstar works
-                               * with the rank-r Chebyshev factorisation K(theta, theta*) = K(theta, c) V^T of
-                               * src/draw-fstar.cpp:17 (exact to 1.3e-15 for r >= 56) and solves r + m
-                               * right-hand sides instead of 1001 + m; 0 = every grid column is solved */
+    int      reserved1;       /* must be 0 */
+    int      kernel_fp32;     /* 1: K(theta, theta) is built with single-precision exp() before the fp64 factorisation
+                               * (BASELINE config C5; parity then only statistical) */
+    int      kstar_rank;      /* r (16..128, multiple of 16; needs fstar_fused): draw_fstar works with the rank-r Chebyshev
+                               * factorisation K(theta, theta*) = K(theta, c) V^T of src/draw-fstar.cpp:17 (exact to 1.3e-15
+                               * for r >= 56) and solves r + m right-hand sides instead of 1001 + m; 0 = every grid column
+                               * is solved */
+    int      reserved[5];     /* must be 0.  (Up to version 100 kernel_fp32 and kstar_rank were the unnamed slots
+                               * reserved[1] and reserved[2] of an int reserved[8] at this offset: same layout, same size.) */
 } gpirt_options;
 
 /* The reference's contract: GPIRT_RNG_RSTREAM (draw-for-draw replay of R's stream), draw_theta and draw_fstar as
@@ -253,6 +250,12 @@ typedef struct gpirt_options {
  * (or with unmodified defaults) and rs == NULL fail with GPIRT_E_ARG ("GPIRT_RNG_RSTREAM needs an R stream state");
  * a host without R's RNG state sets rng_kind = GPIRT_RNG_ITEM (and a seed) explicitly. */
 void gpirt_default_options(gpirt_options* o);
+/* The throughput preset -- what bench.py times as its headline and what BASELINE.json's metric is quoted on: the item-keyed
+ * RNG (seed = 1: set your own), theta_stabilise = 1, fstar_fused = 1, kstar_rank = 64.  Same sampler, every form
+ * algebraically identical to the reference's (DESIGN.md sections 4-5: f* within 1e-9 of the as-written form relative to
+ * max|f*| at 8192 x 1024, checked in every bench.py run); draws are NOT those of R's stream (gpirt_default_options is
+ * that contract).  One call away from the drop-in: the R shim selects it with options(gpirt.hip.preset = "fast"). */
+void gpirt_fast_options(gpirt_options* o);
 
 /* Whole-call drop-in for .gpirtMCMC (src/gpirtMCMC.cpp:5-117), all pointers HOST:
  *   h_y            n x m   responses (never modified)

@@ -92,15 +92,24 @@ SEXP _gpirt_gpirtMCMC(SEXP ySEXP, SEXP thetaSEXP, SEXP sample_iterationsSEXP, SE
 
     gpirt_options opt;
     gpirt_default_options(&opt);                             /* = the reference's contract: R stream, no extras */
-    opt.theta_stabilise = asLogical(GetOption1(install("gpirt.hip.theta_stabilise"))) == TRUE;
-    opt.fstar_fused = asLogical(GetOption1(install("gpirt.hip.fstar_fused"))) == TRUE;
-    opt.reserved[2] = opt.fstar_fused ? asInteger(GetOption1(install("gpirt.hip.kstar_rank"))) : 0;
-    if (opt.reserved[2] == NA_INTEGER) opt.reserved[2] = 0;
+    /* options(gpirt.hip.preset = "fast"): the throughput preset of the library (gpirt_fast_options: item-keyed RNG,
+     * stabilised draw_theta, fused + rank-64 draw_fstar -- what its benchmark is quoted on); single options below
+     * still override it */
+    SEXP preset = GetOption1(install("gpirt.hip.preset"));
+    const int fast = isString(preset) && strcmp(CHAR(STRING_ELT(preset, 0)), "fast") == 0;
+    if (fast) gpirt_fast_options(&opt);
+    SEXP o1 = GetOption1(install("gpirt.hip.theta_stabilise"));
+    if (o1 != R_NilValue) opt.theta_stabilise = asLogical(o1) == TRUE;
+    SEXP o2 = GetOption1(install("gpirt.hip.fstar_fused"));
+    if (o2 != R_NilValue) opt.fstar_fused = asLogical(o2) == TRUE;
+    SEXP o3 = GetOption1(install("gpirt.hip.kstar_rank"));
+    if (o3 != R_NilValue) opt.kstar_rank = asInteger(o3);
+    if (opt.kstar_rank == NA_INTEGER || !opt.fstar_fused) opt.kstar_rank = 0;
 
     /* options(gpirt.hip.rng = "item") selects the batched counter-based contract; the default
      * replays R's own stream so results are draw-for-draw those of the RcppArmadillo build */
     SEXP rngopt = GetOption1(install("gpirt.hip.rng"));
-    const int item_rng = isString(rngopt) && strcmp(CHAR(STRING_ELT(rngopt, 0)), "item") == 0;
+    const int item_rng = isString(rngopt) ? strcmp(CHAR(STRING_ELT(rngopt, 0)), "item") == 0 : fast;
 
     gpirt_rstream_t rs = NULL;
     SEXP seedvec = R_NilValue;

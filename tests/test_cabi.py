@@ -35,10 +35,20 @@ def test_exports_every_declared_symbol(lib):
 
 def test_version_and_options(lib):
     from gpirt_amd import _lib
-    assert lib.gpirt_version() >= 100
+    assert lib.gpirt_version() >= 101
     o = _lib.default_options()
     # the C defaults are the reference's contract: R-stream replay, draw_theta as written
     assert o.rng_kind == _lib.RNG_RSTREAM and o.device == -1 and o.theta_stabilise == 0 and o.fstar_fused == 0
+    assert o.kernel_fp32 == 0 and o.kstar_rank == 0 and o.reserved0 == 0 and o.reserved1 == 0 and not any(o.reserved)
+    # the throughput preset: exactly what bench.py times as its headline (gpirt_fast_options, include/gpirt_hip.h)
+    f = _lib.fast_options()
+    assert f.rng_kind == _lib.RNG_ITEM and f.theta_stabilise == 1 and f.fstar_fused == 1 and f.kstar_rank == 64
+    assert f.kernel_fp32 == 0 and f.device == -1 and f.item0 == 0 and f.m_total == 0 and not any(f.reserved)
+    # the named fields sit where version 100 had reserved[1] / reserved[2] of an int[8]: same layout, same size
+    import ctypes as C
+    base = _lib.Options.reserved1.offset
+    assert _lib.Options.kernel_fp32.offset == base + 4 and _lib.Options.kstar_rank.offset == base + 8
+    assert _lib.Options.reserved.offset == base + 12 and C.sizeof(_lib.Options) == base + 32
 
 
 def test_no_gpu_means_loud_failure(lib):

@@ -32,6 +32,7 @@ def test_bench_json_contract():
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
     # what the DEFAULT contract (R-stream replay, everything as written) costs on the same problem, in the same line
     rr = d["config"]["reference_rng"]
+    assert "error" not in rr, rr.get("error")             # (a failed default-contract run carries its reason, value None)
     assert rr["iterations"] == 2 and rr["value"] > 0 and d["config"]["reference_rng_iterations_per_s"] == rr["value"]
     assert rr["value"] < d["value"]
 

@@ -97,8 +97,17 @@ def test_potrf_matches_oracle(handle, oracle, n):
     assert np.abs(L - Lref).max() <= 1e-11
 
 
-@pytest.mark.parametrize("n,G", [(5000, 3), (8192, 8), (1500, 2), (900, 4)])
-def test_potrf_in_pieces_is_bit_identical(handle, n, G):
+def _oracle_factor_blocked(oracle, theta):
+    """arma::chol(K + 0.001 I, "lower") by the oracle's blocked all-core potrf (seconds up to n ~ 3000)."""
+    S = oracle.se_kernel(theta, theta)
+    S[np.diag_indices(len(theta))] += 0.001
+    L, info = oracle.potrf_lower(S, blocked=True)
+    assert info == 0
+    return np.tril(L)
+
+
+@pytest.mark.parametrize("n,G", [(5000, 3), (8192, 8), (1500, 2), (900, 4), (2600, 3)])
+def test_potrf_in_pieces_is_bit_identical(handle, oracle, n, G):
     """the factorisation as a distributing host drives it -- 1-D block-cyclic ownership of the outer
     panels over G ranks (played here by G copies of S on the one device), owner factors, the panel travels through the
     dense buffer, every rank applies it to the block columns it owns -- must reproduce gpirt_potrf_lower BIT FOR BIT on
@@ -127,19 +136,35 @@ def test_potrf_in_pieces_is_bit_identical(handle, n, G):
     handle.potrf_finish()
     for r in range(G):
         assert torch.equal(torch.tril(ranks[r]), torch.tril(ref)), f"rank {r} differs from the single-GPU factor"
+    if n <= 2600:          # ... and the assembled factor is the ORACLE's (src/gpirtMCMC.cpp:17), not only the single-GPU one
+        Lo = _oracle_factor_blocked(oracle, th0)
+        for r in range(G):
+            assert np.abs(np.tril(ranks[r].cpu().numpy()) - Lo).max() <= 1e-11, f"rank {r} differs from the oracle's factor"
 
 
-@pytest.mark.parametrize("n,G", [(5000, 3), (8192, 8), (2600, 2)])
-def test_potrf_in_half_panels_is_bit_identical(handle, n, G):
+@pytest.mark.parametrize("n,G,panel", [(5000, 3, 1), (8192, 8, 1), (2600, 2, 1), (1500, 3, 1), (900, 2, 1), (2600, 2, 2), (1500, 3, 2)])
+def test_potrf_in_half_panels_is_bit_identical(handle, oracle, n, G, panel):
     """The pipelined form of the same host (round 3): an outer panel travels as its first sub-panel and the rest, and the
     next owner applies the first half's share of the update of its first columns before the second half exists
     (gpirt_potrf_panel_*_part, in the order gpirt_amd/distributed.py issues them).  Same launches, same order: every
-    rank must again hold gpirt_potrf_lower's factor BIT FOR BIT."""
+    rank must again hold gpirt_potrf_lower's factor BIT FOR BIT -- and, at the sizes the oracle reaches in seconds, the
+    ORACLE's factor to 1e-11.  panel = 2: the same with the launch-per-step panel (GPIRT_PANEL=2, what ShardedSampler(chol=
+    "distributed") runs when more than two ranks share a card, and what a hang-guard fallback refactors with)."""
     import torch
     from gpirt_amd.ops import to_device
     from gpirt_amd.synthetic import make_responses
     _, th0 = make_responses(n, 2, seed=n)
     th = to_device(th0)
+    old_panel = handle.config_get("GPIRT_PANEL")
+    handle.config_set("GPIRT_PANEL", panel)
+    try:
+        _half_panels_body(handle, oracle, n, G, th, th0)
+    finally:
+        handle.config_set("GPIRT_PANEL", old_panel)
+
+
+def _half_panels_body(handle, oracle, n, G, th, th0):
+    import torch
     ref = handle.factor(th)
     W, H = handle.panel_width, handle.subpanel_width
     NP = (n + W - 1) // W
@@ -173,6 +198,10 @@ def test_potrf_in_half_panels_is_bit_identical(handle, n, G):
     handle.potrf_finish()
     for r in range(G):
         assert torch.equal(torch.tril(ranks[r]), torch.tril(ref)), f"rank {r} differs from the single-GPU factor"
+    if n <= 2600:
+        Lo = _oracle_factor_blocked(oracle, th0)
+        for r in range(G):
+            assert np.abs(np.tril(ranks[r].cpu().numpy()) - Lo).max() <= 1e-11, f"rank {r} differs from the oracle's factor"
 
 
 def test_potrf_operator_on_user_matrix(handle, oracle):

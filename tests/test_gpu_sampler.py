@@ -558,6 +558,56 @@ def test_r_stream_draw_f_redoes_an_item_whose_candidates_ran_out(handle, oracle,
     assert state[1] == mti_ref and np.array_equal(state[0], mt_ref)
 
 
+@pytest.mark.parametrize("n,m", [(97, 11), (1025, 7), (640, 40)])
+def test_r_stream_draw_f_three_items_per_pass_odd_shapes(handle, oracle, n, m):
+    """The replay's draw_f resolves up to three items per pass over L (rng_ess.hip): odd n (rows and columns past the last
+    32-row group / 512-column part are padding), m not a multiple of three (the last pass has one or two slots), and enough
+    items that some pass ends early on its own (a count beyond a slot's candidates) -- every draw must be the oracle's."""
+    from gpirt_amd import Sampler
+    from gpirt_amd.ops import RStream
+    from gpirt_amd.synthetic import make_responses
+    y, th0 = make_responses(n, m, seed=3 * n + m)
+    rs = RStream(99)
+    s = Sampler(handle, y, th0, rng="reference", rstream=rs)
+    s.init()
+    for _ in range(3):
+        s.step()
+    s.check()
+    got = {k: s.get(k) for k in ("theta", "f", "beta")}
+    state = rs.state()
+    s.close()
+    r = oracle.RStream(99)
+    ref = oracle.gpirt_mcmc(r, y, th0, 3, 0)
+    assert np.array_equal(got["theta"], ref["theta"][3])
+    assert np.abs(got["f"] - ref["f"][:, :, 3]).max() <= 1e-9
+    assert np.abs(got["beta"] - ref["beta"][:, :, 3]).max() <= 1e-9
+    mt_ref, mti_ref = r.mt_state()
+    assert state[1] == mti_ref and np.array_equal(state[0], mt_ref)
+
+
+def test_r_stream_destroyed_under_an_attached_sampler_is_an_error_not_a_dangling_pointer(handle):
+    """gpirt_rstream_destroy while a sampler created on the stream is alive but NOT running ahead of it (right after init,
+    or after another sampler took the generator over): the sampler must learn that its stream is gone -- the next step fails
+    with a named error instead of reading freed memory (round-4 advisor finding)."""
+    from gpirt_amd import Sampler, _lib
+    from gpirt_amd.ops import RStream
+    from gpirt_amd.synthetic import make_responses
+    lib = _lib.load()
+    y, th0 = make_responses(128, 5, seed=4)
+    rs = RStream(5)
+    a = Sampler(handle, y, th0, rng="reference", rstream=rs)
+    b = Sampler(handle, y, th0, rng="reference", rstream=rs)
+    a.init(); b.init()
+    a.step(); a.check()                                   # a runs ahead
+    b.step(); b.check()                                   # b took the generator over: a is attached, not the owner
+    lib.gpirt_rstream_destroy(rs._r); rs._r = None
+    for s in (a, b):
+        with pytest.raises(_lib.GpirtError) as e:
+            s.step()
+        assert "has been destroyed" in str(e.value)
+    a.close(); b.close()
+
+
 def test_two_samplers_alternating_on_one_r_stream(handle, oracle):
     """Two chains drawing from ONE R stream in turns (each step continues where the other's left the generator): each
     sampler runs ahead of its own chain between ITS steps, so every step of the other must first get the generator back
