@@ -38,6 +38,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP64_MFMA_TFLOPS = 78.6      # MI355X fp64 matrix peak (public spec; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
+PEAK_HBM_GBS = 8000.0             # HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec, 6.29 TB/s measured for a copy)
 
 
 def cpu_baseline(n, m, sampler, y):
@@ -49,6 +50,18 @@ def cpu_baseline(n, m, sampler, y):
 
 
 FSTAR_TOL = 1e-9       # tolerance of every f* comparison (north star: posterior means within 1e-8 relative)
+
+
+def _roof_entry(prof, bound, peak, unit, kernel):
+    """One more roofline entry from the library's event pairs: (ms, launches, flops, bytes) of a kernel class."""
+    if not prof or not prof[1] or prof[0] <= 0:
+        return None
+    ms, nl, fl, by = prof
+    work = fl if bound == "mfma" else by
+    achieved = work / (ms * 1e-3) / (1e12 if bound == "mfma" else 1e9)
+    return {"kernel": kernel, "bound": bound, "launches": int(nl), "avg_launch_ms": ms / nl,
+            "flops_per_launch": fl / nl, "algorithmic_bytes_per_launch": by / nl,
+            "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak}
 
 
 def main():
@@ -131,6 +144,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    prof_other = {}
+
     def timed_run(ss, local=False):
         """W warm-up steps, then exactly K timed steps between barrier + synchronize; max over ranks.
         local: this rank alone (no barrier, no reduction): rank 0's single-GPU reference run."""
@@ -150,6 +165,7 @@ def main():
             ss.step()
         ss.engine.check()
         handle.prof_syrk(reset=True)
+        handle.prof_other(reset=True)
         # The roofline events are an instrument with a price: a pair of hipEventRecord around each of the 54 syrk
         # launches of a step costs 4 % of the iteration rate when every timed step carries them (124.3 against 129.6 it/s).
         # So they ride on a sample of the timed steps -- the first and the middle one -- which is still a measurement
@@ -165,6 +181,7 @@ def main():
         handle.prof_enable(False)
         ss.engine.check()
         prof = handle.prof_syrk(reset=True)
+        prof_other.clear(); prof_other.update(handle.prof_other(reset=True))       # (nu = L Z of draw_f on the sampled steps)
         if world > 1:
             tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -269,6 +286,7 @@ def main():
     # draw_theta as written).  The replay is item-sequential by construction -- item j's normals start where item j - 1's
     # data-dependent slice loop stopped consuming (src/draw-f.cpp:40-58) -- so this is m dependent products per iteration.
     ref_rng = None
+    replay_prof = None
     if world == 1 and not args.no_reference_rng:
         from gpirt_amd.ops import RStream
         literal_error = None
@@ -283,13 +301,18 @@ def main():
                 sr.step()                       # (first iteration: workspaces)
                 sr.check()
                 torch.cuda.synchronize()
+                handle.prof_other(reset=True)
                 t0 = time.perf_counter()
-                for _ in range(2):
+                for it_ in range(2):
+                    handle.prof_enable(it_ == 1)        # event pairs around the second iteration's passes over L
                     sr.step()
                 torch.cuda.synchronize()
                 dtr = time.perf_counter() - t0
+                handle.prof_enable(False)
                 sr.check()
+                replay_prof = handle.prof_other(reset=True)["replay_products"]
                 ref_rng = {"value": 2.0 / dtr, "iterations": 2, "theta_stabilise": int(stab),
+                           "passes_over_L_per_iteration": int(replay_prof[1]), "items_per_pass": (m / replay_prof[1]) if replay_prof[1] else None,
                            "contract": "gpirt_default_options: rng = R-stream replay (item-sequential draw_f), draw_fstar = double_solve "
                                        "as written" + ("; theta_stabilise = 1 because the literal default (0) failed on this problem: "
                                                        + literal_error if stab else "; theta_stabilise = 0 (the literal default)")}
@@ -358,8 +381,10 @@ def main():
                 "workload": f"M: N={n} respondents x m={m} items, synthetic 2PL responses (5% NA), full MCMC "
                             f"iteration on device (draw_f, draw_fstar[{form}], draw_theta, draw_beta, K+chol), "
                             f"rng=item, theta_stabilise=1" +
-                            ("; draw_fstar[lowrank] is an OPT-IN form (off in the API defaults), checked in this run "
-                             "against the full solve (lowrank_check)" if form == "lowrank" else ""),
+                            ("; options = gpirt_fast_options() (include/gpirt_hip.h: the library's throughput preset -- item-keyed "
+                             "RNG, theta_stabilise, fused + rank-64 draw_fstar); draw_fstar[lowrank] is checked in this run against the "
+                             "full solve and the as-written form (lowrank_check)" if form == "lowrank" else ""),
+                "options_preset": "gpirt_fast_options" if form == "lowrank" else None,
                 "parallelism": (f"items sharded over {world} GPU(s); chol {args.chol}; draw_theta: " +
                                 (f"all-gather of f* ({1001}x{m}), theta drawn per block of respondents, {n} draws combined"
                                  if args.theta == "gather" else
@@ -413,6 +438,18 @@ def main():
                 "algorithmic_bytes_per_launch": (tot_by / tot_n) if tot_n else None,
                 "traffic_over_algorithmic": (traffic / (tot_by / tot_n)) if (traffic and tot_n and tot_by) else None,
                 "by_class": by_class,
+                # the whole factorisation (K + chol): n^3 / 3 flops against the stage's device time -- pivot chain, panels and all
+                "factor_overall": {"bound": "mfma", "flops": n ** 3 / 3.0, "stage_ms": stage_ms.get("factor"),
+                                   "achieved": (n ** 3 / 3.0 / (stage_ms["factor"] * 1e-3) / 1e12) if stage_ms.get("factor") else None,
+                                   "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": (n ** 3 / 3.0 / (stage_ms["factor"] * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS) if stage_ms.get("factor") else None},
+                # nu = L Z of draw_f (src/mvnormal.h:10 for all m columns as ONE triangular product, gemm_f64_kernel<false, false, ...>)
+                "draw_f_trmm": _roof_entry(prof_other.get("draw_f_trmm"), "mfma", PEAK_FP64_MFMA_TFLOPS, "TFLOP/s",
+                                           "gemm_f64_kernel<false, false, 128, 0, false>: n^2 m flops (the zero triangle skipped)"),
+                # the default contract's draw_f: one pass over L per three items (rs3_products_kernel), HBM-bound
+                "replay_products": _roof_entry(replay_prof, "hbm", PEAK_HBM_GBS, "GB/s",
+                                               "rs3_products_kernel (R-stream replay, gpirt_default_options): bytes = the lower triangle of L, "
+                                               "8 n (n + 1) / 2, per launch; timed in the reference_rng leg of this run"),
                 "note": "HIP events around each launch on its own stream (main or look-ahead side stream) inside the timed region, on "
                         "a sample of the timed steps (the first and the middle one: bracketing every launch of every step costs 4 % "
                         "of the iteration rate); launches of the two streams overlap each other and the panel kernel, so "

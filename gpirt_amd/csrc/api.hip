@@ -133,6 +133,26 @@ namespace gpirt {
 int create_side_handle(gpirt_handle_t* out, int device) { return create_own_stream(out, device, true); }
 }
 
+namespace gpirt {
+int prof_pair_begin(gpirt_handle_t h, hipStream_t stream, ProfPair& pp)
+{
+    pp = ProfPair{nullptr, nullptr, 0.0, 0, 0.0};
+    if (!h->prof.enabled) return 0;
+    if (!h->prof.free_pairs.empty()) { pp = h->prof.free_pairs.back(); h->prof.free_pairs.pop_back(); }
+    else { GP_HIP(hipEventCreate(&pp.e0)); GP_HIP(hipEventCreate(&pp.e1)); }
+    GP_HIP(hipEventRecord(pp.e0, stream));
+    return 0;
+}
+int prof_pair_end(gpirt_handle_t h, hipStream_t stream, ProfPair& pp, int cls, double flops, double bytes)
+{
+    if (!pp.e0) return 0;
+    GP_HIP(hipEventRecord(pp.e1, stream));
+    pp.flops = flops; pp.bytes = bytes; pp.cls = cls;
+    h->prof.pending.push_back(pp);
+    return 0;
+}
+}  // namespace gpirt
+
 extern "C" {
 
 int gpirt_version(void) { return 101; }     // 101: gpirt_options names kernel_fp32 / kstar_rank, gpirt_fast_options
@@ -662,9 +682,15 @@ static int prof_resolve(gpirt_handle_t h)
     if (h->prof.pending.empty()) return 0;
     GP_HIP(hipStreamSynchronize(h->stream));
     if (h->side) GP_HIP(hipStreamSynchronize(h->side));
+    // class 4 (the replay's pass over L): the spare passes a draw enqueues find every item done and leave at once (a few
+    // microseconds) -- they are not passes over L and stay out of the average
+    float longest4 = 0.f;
+    for (auto& pp : h->prof.pending)
+        if (pp.cls == 4) { float ms = 0.f; GP_HIP(hipEventElapsedTime(&ms, pp.e0, pp.e1)); if (ms > longest4) longest4 = ms; }
     for (auto& pp : h->prof.pending) {
         float ms = 0.f;
         GP_HIP(hipEventElapsedTime(&ms, pp.e0, pp.e1));
+        if (pp.cls == 4 && ms < 0.25f * longest4) { h->prof.free_pairs.push_back(pp); continue; }
         h->prof.ms[pp.cls] += ms;
         h->prof.launches[pp.cls] += 1;
         h->prof.flops[pp.cls] += pp.flops;

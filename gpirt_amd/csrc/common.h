@@ -43,7 +43,10 @@ void set_error(const char* fmt, ...);
 // Event-pair profiler for the syrk launches of the factorisation (the MFMA work of arma::chol): pairs are recorded
 // on the launch stream without synchronising and resolved later by gpirt_prof_syrk().  Classes:
 //   0  trailing update, 128-tile kernel   1  trailing update, 64-tile kernel   2  update inside an outer panel (K = 512)
-constexpr int PROF_CLASSES = 3;
+// ... and, with the same instrument, two kernels of draw_f:
+//   3  nu = L Z, the triangular product of the item-keyed draw_f (src/mvnormal.h:10 for all m columns)
+//   4  rs3_products_kernel, the pass over L of the R-stream replay's draw_f (bytes: the lower triangle of L)
+constexpr int PROF_CLASSES = 5;
 struct ProfPair { hipEvent_t e0, e1; double flops; int cls; double bytes; };
 struct Prof {
     bool        enabled = false;

@@ -574,6 +574,21 @@ static int launch_gemm_syrk64(hipStream_t stream, GemmParams p)
     return 0;
 }
 
+// ... and the K = 512 update BETWEEN the two sub-panels of an outer panel (potrf.hip, panel_update: on the pivot chain, beside
+// the deferred updates) runs under a name of its own (PAD = 16), so that rocprofv3's per-kernel averages show the classes
+// bench.py's roofline reports -- trailing / deferred updates (PAD = 8) and in-panel updates -- without bench.py's own timers.
+static int launch_gemm_inpanel(hipStream_t stream, GemmParams p, bool t128)
+{
+    const int T = t128 ? 128 : 64;
+    p.mblocks = (p.M + T - 1) / T;
+    p.nblocks = (p.N + T - 1) / T;
+    const int64_t grid = (int64_t)p.nblocks * p.mblocks - (int64_t)p.nblocks * (p.nblocks - 1) / 2;
+    if (t128) hipLaunchKernelGGL((gemm_f64_kernel<false, true, 128, 16>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    else      hipLaunchKernelGGL((gemm_f64_kernel<false, true, 64, 16>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    GP_HIP(hipGetLastError());
+    return 0;
+}
+
 // Panel update of the blocked Cholesky (K <= 64, lower trapezoid) with the factorisation of the next
 // diagonal block fused into work-group 0: C = A[r0:, r0:c1] and the block is C's leading 64 x 64 tile.
 int launch_gemm_update_potf2(hipStream_t stream, int64_t M, int64_t N, int64_t K, const double* P, int64_t ldp,
@@ -772,12 +787,11 @@ int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri,
     }
     if (tri == TRI_SYRK_LOWER && M < N) { set_error("syrk mode needs M >= N"); return GPIRT_E_ARG; }
     if (tri == TRI_SYRK_LOWER && !ta && tb) {
-        // the factorisation's own updates (only potrf.hip asks for this mode): same split between the tile sizes as
-        // every other product, but under the PAD = 8 names, so traces tell them apart from draw_theta's NT product
+        // the update between the sub-panels of an outer panel (only potrf.hip's panel_update asks for this mode): same split
+        // between the tile sizes as every other product, under the PAD = 16 names (launch_gemm_inpanel)
         const int64_t mb_ = (M + 127) / 128, nb_ = (N + 127) / 128;
         constexpr int t128_min_ = T128_MIN;
-        if (nb_ * mb_ - nb_ * (nb_ - 1) / 2 >= t128_min_) return launch_gemm_trailing(stream, p);
-        return launch_gemm_syrk64(stream, p);
+        return launch_gemm_inpanel(stream, p, nb_ * mb_ - nb_ * (nb_ - 1) / 2 >= t128_min_);
     }
     // 128-tiles when they already give every CU >= 2 work-groups, 64-tiles otherwise
     const int64_t mb = (M + 127) / 128, nb = (N + 127) / 128;

@@ -188,6 +188,10 @@ struct BetaArgs {
 int launch_draw_beta(hipStream_t stream, const BetaArgs& a);
 int launch_linear_mean(hipStream_t stream, const double* x, int64_t n, const double* beta, int64_t m, double* mu);
 
+// api.hip: an event pair around one launch while gpirt_prof_enable is on (classes: common.h); resolved by gpirt_prof_syrk
+int prof_pair_begin(gpirt_handle_t h, hipStream_t stream, ProfPair& pp);
+int prof_pair_end(gpirt_handle_t h, hipStream_t stream, ProfPair& pp, int cls, double flops, double bytes);
+
 // api.hip: turns the hang-guard record of the panel kernel (info[1..7]) into the error message and clears it
 int report_panel_guard(gpirt_handle_t h, const int* info_words, hipStream_t stream);
 

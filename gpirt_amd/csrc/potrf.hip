@@ -108,26 +108,13 @@ __global__ void zero_upper_kernel(double* __restrict__ A, int64_t n, int64_t lda
 namespace {
 
 // event pair around one syrk launch of the factorisation (only while gpirt_prof_enable is on)
-int prof_begin(gpirt_handle_t h, hipStream_t stream, ProfPair& pp)
-{
-    pp = ProfPair{nullptr, nullptr, 0.0, 0, 0.0};
-    if (!h->prof.enabled) return 0;
-    if (!h->prof.free_pairs.empty()) { pp = h->prof.free_pairs.back(); h->prof.free_pairs.pop_back(); }
-    else { GP_HIP(hipEventCreate(&pp.e0)); GP_HIP(hipEventCreate(&pp.e1)); }
-    GP_HIP(hipEventRecord(pp.e0, stream));
-    return 0;
-}
+int prof_begin(gpirt_handle_t h, hipStream_t stream, ProfPair& pp) { return prof_pair_begin(h, stream, pp); }
 int prof_end(gpirt_handle_t h, hipStream_t stream, ProfPair& pp, int cls, int64_t M, int64_t N, int64_t K)
 {
-    if (!pp.e0) return 0;
-    GP_HIP(hipEventRecord(pp.e1, stream));
-    // algorithmic flops of the lower trapezoid: 2 K (M N - N (N - 1) / 2)
+    // algorithmic flops of the lower trapezoid: 2 K (M N - N (N - 1) / 2); bytes: C read + written, P (M x K; its first N
+    // rows are the B operand) once
     const double trap = (double)M * (double)N - 0.5 * (double)N * (double)(N - 1);
-    pp.flops = 2.0 * (double)K * trap;
-    pp.bytes = 8.0 * (2.0 * trap + (double)M * (double)K);     // C read + written, P (M x K; its first N rows are the B operand) once
-    pp.cls = cls;
-    h->prof.pending.push_back(pp);
-    return 0;
+    return prof_pair_end(h, stream, pp, cls, 2.0 * (double)K * trap, 8.0 * (2.0 * trap + (double)M * (double)K));
 }
 // C[M x N lower trapezoid] -= P P^T inside an outer panel (between its sub-panels), profiled as class 2
 int panel_update(gpirt_handle_t h, hipStream_t stream, int64_t M, int64_t N, int64_t K, const double* P, int64_t ldp,

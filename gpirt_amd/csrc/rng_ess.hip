@@ -476,9 +476,11 @@ __global__ __launch_bounds__(256, 4) void rs3_products_kernel(Rs3Args a)
 // before decides -- :56 consumes nothing when the bracket has closed -- they were ten dependent HBM misses per item).
 // Meeting (sync): every work-group stores its <= 9 partial sums write-through at agent scope, waits for the stores, raises
 // ITS OWN flag word to the meeting's tag (tags grow monotonically over passes and draws: nothing is ever reset); thread q
-// polls work-group q's flag (bounded, like every in-kernel wait of this library: on expiry the draw fails with GPIRT_E_HIP);
-// then all partial sums are read with agent-scope loads and added in one fixed order -- every work-group sees the same bits
-// and takes the same branches.  No atomics: 128 adds to one counter would queue for longer than the rest of the meeting.
+// polls work-group q's flag (bounded, like every in-kernel wait of this library: on expiry the draw fails with GPIRT_E_HIP)
+// and reads its sums behind it; then all partial sums are added in one fixed order -- every work-group sees the same bits
+// and takes the same branches.  No atomics: 256 adds to one counter would queue for longer than the rest of the meeting.
+// (Measured and not kept: each sum as ONE 16-byte record {value, tag ^ bits(value)} polled directly, no flag and no wait
+// for the stores -- fewer round trips on paper, 5.6 instead of 3.8 us per meeting: gpurun_out/r5o.)
 // The work-groups are the whole grid of a launch on an otherwise idle stream, <= one per CU: resident together.
 template <int R>
 __global__ __launch_bounds__(320) void rs3_slice_kernel(Rs3Args a)
@@ -506,7 +508,7 @@ __global__ __launch_bounds__(320) void rs3_slice_kernel(Rs3Args a)
     const int pp = (maxparts + 7) / 8;
     int usum = 0, resolved = 0, sync = 0, fail = 0;
     if (tid == 0) expired = 0;
-    long long* tr = (w == 0 && tid == 0) ? a.trace : nullptr;
+    long long* tr = (a.trace && tid == 0 && (w == 0 || w == E - 1)) ? a.trace + (w == 0 ? 0 : 32) : nullptr;      // first and last work-group
     int ti = 0;
     rs_stamp(tr, ti++);
     double Fn[R], Mn[R], Yn[R];                               // the NEXT slot's rows
@@ -624,16 +626,20 @@ __global__ __launch_bounds__(320) void rs3_slice_kernel(Rs3Args a)
                 }
             }
             double mine = 0.0, mine0 = 0.0;                                    // this thread's term sums: its trial point / ll_bar(f)
-            if (wv == 4) {                                                     // (cos and sin on two waves: side by side)
-                if (lane < T) cs[lane] = cos(my_eps);
-            } else if (wv == 3) {
-                if (lane < T) cs[T + lane] = sin(my_eps);
-            } else if (first && wv == 0 && hh == 0) {
+            // cos and sin of the eight points on two waves, side by side; ll_bar(f) on a third meanwhile
+            // (measured and not kept: both taken from a table that one more work-group of the products kernel fills for every
+            //  candidate's first eight points -- 0.65 us less in front of the terms and as much more waiting in the meeting,
+            //  30.6 ms of draw_f either way: the meeting waits for the slowest of 256 work-groups, not for this phase)
+            if (wv == 4) { if (lane < T) cs[lane] = cos(my_eps); }
+            else if (wv == 3) { if (lane < T) cs[T + lane] = sin(my_eps); }
+            else if (first && wv == 0 && hh == 0) {
 #pragma unroll
                 for (int e = 0; e < R; ++e) if (Y[e] == Y[e]) mine0 += ll_term(Y[e] * (F[e] + M[e]));          // :29
             }
             __syncthreads();
             rs_stamp(tr, ti++);                                                // sequence, cos / sin, ll_bar(f)
+            // The meeting: partial sums stored write-through at agent scope and waited for, the work-group's barrier, its flag
+            // word raised to the meeting's tag; thread q polls work-group q's flag and reads its nine sums straight behind it.
             const uint64_t tag = a.tag + (uint64_t)sync;
             double* rec = a.partial + (size_t)(sync & 1) * RS3_MAX_WGS * V;
             unsigned long long* flg = a.flags + (size_t)(sync & 1) * RS3_MAX_WGS;
@@ -726,7 +732,7 @@ __global__ __launch_bounds__(320) void rs3_slice_kernel(Rs3Args a)
         if (w == 0 && tid == 0) { a.k_out[j] = k; a.posv[j + 1] = start; }
     }
     rs_stamp(tr, ti++);
-    if (tr) tr[63] = ti;
+    if (tr && w == 0) a.trace[63] = ti;
     if (tid == 0) {
         if (fail) { atomicCAS(a.err, 0, fail); a.anchor[0] = (uint64_t)a.m; }        // every later kernel of the draw leaves at once
         else if (w == 0) { a.anchor[0] = (uint64_t)(item0 + resolved); a.anchor[1] = start; *a.pos = start; }

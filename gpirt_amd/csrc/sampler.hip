@@ -376,7 +376,12 @@ int do_draw_f(gpirt_sampler_s* s)
             GP_TRY(z_sync(s));                                    // a prefill for ANOTHER iteration may still be writing Z
             GP_TRY(launch_item_uniforms(st, s->opt.seed, iter, GPIRT_ST_F_Z, (uint32_t)s->opt.item0, m, n, s->Z, true));
         }
-        GP_TRY(launch_gemm(h, st, false, false, TRI_A_LOWER, n, m, n, 1.0, s->L, s->ldl, s->Z, n, 0.0, s->NU, n));
+        {
+            ProfPair pp;                                          // (bench.py's roofline: class 3, n^2 m flops)
+            GP_TRY(prof_pair_begin(h, st, pp));
+            GP_TRY(launch_gemm(h, st, false, false, TRI_A_LOWER, n, m, n, 1.0, s->L, s->ldl, s->Z, n, 0.0, s->NU, n));
+            GP_TRY(prof_pair_end(h, st, pp, 3, (double)n * (double)n * (double)m, 8.0 * (0.5 * (double)n * (double)n + 2.0 * (double)n * (double)m)));
+        }
         if (prep && !early) GP_HIP(hipEventRecord(s->ev_trmm, st));
         EssArgs a{};
         a.f = s->f; a.nu = s->NU; a.y = s->y; a.mu = s->mu; a.n = n; a.m = m; a.k_out = s->ess_k;
@@ -439,7 +444,10 @@ int do_draw_f(gpirt_sampler_s* s)
             s->rs_tag += 1ull << 20;
             a.tag = s->rs_tag;
             a.trace = (h->rs_trace_pass >= 0 && pass == h->rs_trace_pass) ? s->rs_trace : nullptr;
+            ProfPair pp;                                          // (bench.py's roofline: class 4, the lower triangle's bytes)
+            GP_TRY(prof_pair_begin(h, st, pp));
             GP_TRY(launch_rs3_products(st, a));
+            GP_TRY(prof_pair_end(h, st, pp, 4, 2.0 * RS3_CAND * 0.5 * (double)n * (double)(n + 1), 8.0 * 0.5 * (double)n * (double)(n + 1)));
             GP_TRY(launch_rs3_slice(st, a));
         }
         GP_HIP(hipMemcpyAsync(s->h_next, s->anchor, sizeof(uint64_t), hipMemcpyDeviceToHost, st));

@@ -316,6 +316,19 @@ class Handle:
             out[name] = (ms.value, n.value, fl.value, by.value)
         return out
 
+    OTHER_CLASSES = {3: "draw_f_trmm", 4: "replay_products"}
+
+    def prof_other(self, reset: bool = False) -> dict:
+        """The same instrument on two kernels of draw_f (include/gpirt_hip.h, gpirt_prof_syrk classes 3 and 4):
+        {name: (ms, launches, algorithmic flops, algorithmic bytes)}."""
+        out = {}
+        for cls, name in self.OTHER_CLASSES.items():
+            ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+            check(self.lib.gpirt_prof_syrk_bytes(self._h, cls, C.byref(by)))
+            check(self.lib.gpirt_prof_syrk(self._h, cls, int(reset), C.byref(ms), C.byref(n), C.byref(fl)))
+            out[name] = (ms.value, n.value, fl.value, by.value)
+        return out
+
 
 class RStream:
     """R's default RNG on the host: RStream(seed) == set.seed(seed); .rnorm(n) == rnorm(n)."""

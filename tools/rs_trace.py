@@ -24,6 +24,8 @@ _lib.check(lib.gpirt_debug_rs_trace(h._h, -1))
 ns = int(t[63])
 st = t[:ns].astype(float) / 100.0
 print("slice kernel, work-group 0 (us from its start):", np.round(st - st[0], 2).tolist())
+sl = t[32:32 + ns].astype(float) / 100.0
+print("slice kernel, LAST work-group (us from work-group 0's start):", np.round(sl - st[0], 2).tolist())
 for b in range(3):
     q = t[64 + 8 * b: 64 + 8 * b + 6].astype(float) / 100.0
     print(f"products work-group {b} (0 / middle / last full): anchor {q[1]-q[0]:.2f}, windows staged +{q[2]-q[1]:.2f}, MFMAs +{q[3]-q[2]:.2f}, "

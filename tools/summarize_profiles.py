@@ -3,8 +3,9 @@ usage: python tools/summarize_profiles.py [raw dir] [tag]"""
 import collections, csv, glob, json, os, shutil, sys
 
 raw = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/profiles_raw"
-tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
-SYRK = {"gemm_f64_kernel<false, true, 128, 8": "128-tile", "gemm_f64_kernel<false, true, 64, 8": "64-tile"}
+tag = sys.argv[2] if len(sys.argv) > 2 else "r05"
+SYRK = {"gemm_f64_kernel<false, true, 128, 8": "128-tile", "gemm_f64_kernel<false, true, 64, 8": "64-tile",
+        "gemm_f64_kernel<false, true, 64, 16": "in-panel 64-tile"}
 PANEL = "panel_ll_kernel"
 
 
@@ -34,7 +35,8 @@ def pmc(name):
 
 fe, wr, mf = pmc("pmc_fetch"), pmc("pmc_write"), pmc("pmc_mfma")
 rl = bench["roofline"]
-cls_of = {"128-tile": ["trailing_128tile"], "64-tile": ["trailing_64tile", "in_panel_k512"]}
+cls_of = {"128-tile": ["trailing_128tile"], "64-tile": ["trailing_64tile"], "in-panel 64-tile": ["in_panel_k512"]}
+commit = open(raw + "/commit.txt").read().strip() if os.path.exists(raw + "/commit.txt") else "unknown"
 per_kernel = {}
 tot_traffic = tot_launch = 0.0
 for key, label in SYRK.items():
@@ -54,11 +56,12 @@ for key, label in SYRK.items():
     n_l = float(st[0]["Calls"]) if st else nl
     tot_traffic += traffic * n_l
     tot_launch += n_l
-json.dump({"kernel": "gemm_f64_kernel<false, true, T, 8, false>, T = 128 and 64 (every syrk launch of the factorisation)",
+json.dump({"kernel": "gemm_f64_kernel<false, true, T, PAD, false>: trailing / deferred updates (PAD = 8, T = 128 and 64) and in-panel updates (PAD = 16) of the factorisation",
+           "library_commit": commit,
            "hbm_bytes_per_launch": tot_traffic / tot_launch if tot_launch else None,
            "by_kernel": per_kernel,
            "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python3 bench.py --steps 1 --warmup 1`, "
-                     f"round {tag[1:]}; FETCH_SIZE doubled (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md "
+                     f"round {tag[1:]}, library commit {commit}; FETCH_SIZE doubled (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md "
                      f"HBM section); launch-weighted mean over both tile instantiations; Infinity-Cache hits are counted",
            }, open("profiles/trailing_traffic.json", "w"), indent=1)
 
@@ -96,4 +99,84 @@ with open(f"profiles/{tag}_summary.md", "w") as f:
     f.write("## All kernels (rocprofv3 --stats)\n\n| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
     for r in rows[:26]:
         f.write(f"| `{short(r['Name'])[:70]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.3f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |\n")
+
+
+def stat_row(rows_, key):
+    st = [r for r in rows_ if key in r["Name"]]
+    return st[0] if st else None
+
+
+with open(f"profiles/{tag}_summary.md", "a") as f:
+    f.write(f"\n## The other roofline entries of bench.py's line, against rocprofv3's averages (library commit {commit})\n\n")
+    f.write("| entry | kernel | bench.py: launches, avg ms, frac | rocprofv3: calls, avg ms | frac from the rocprofv3 average |\n|---|---|---|---|---|\n")
+    for name, key in (("draw_f_trmm", "gemm_f64_kernel<false, false, 128, 0"), ("replay_products", "rs3_products_kernel")):
+        e = rl.get(name)
+        st = stat_row(rows, key)
+        if not e or not st:
+            continue
+        avg_ms = float(st["AverageNs"]) / 1e6
+        work = e["flops_per_launch"] if e["bound"] == "mfma" else e["algorithmic_bytes_per_launch"]
+        frac = work / (avg_ms * 1e-3) / (1e12 if e["bound"] == "mfma" else 1e9) / e["peak"]
+        f.write(f"| `{name}` ({e['bound']}) | `{key}...` | {e['launches']}, {e['avg_launch_ms']:.4f}, {e['frac']:.3f} | {st['Calls']}, {avg_ms:.4f} | {frac:.3f} |\n")
+    fo = rl.get("factor_overall")
+    if fo and fo.get("frac"):
+        f.write(f"\n`factor_overall`: n^3 / 3 = {fo['flops']:.3e} flop in the factor stage's {fo['stage_ms']:.3f} ms = {fo['achieved']:.1f} TFLOP/s = "
+                f"{fo['frac']:.3f} of 78.6 (pivot chain, sub-panel kernels and all).\n")
+    rr = bench["config"].get("reference_rng")
+    if rr:
+        f.write(f"\nDefault contract in the same run (`config.reference_rng`): {rr.get('value')} iterations/s, "
+                f"{rr.get('passes_over_L_per_iteration')} passes over L per iteration ({rr.get('items_per_pass')} items per pass).\n")
+
+# ---- the default contract (R-stream replay): tools/rstream_step.py 8192 1024 under rocprofv3
+try:
+    rstats = newest(raw + "/replay_stats/**/*kernel_stats.csv")
+except ValueError:
+    rstats = None
+if rstats:
+    shutil.copy(rstats, f"profiles/{tag}_replay_kernel_stats.csv")
+    rrows = list(csv.DictReader(open(rstats)))
+    log = [l.strip() for l in open(raw + "/replay_stats.log") if ("per iteration" in l or "stage ms" in l or "rejection counts" in l)]
+
+    def one(name, counter):
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(newest(f"{raw}/{name}/**/*counter_collection.csv")))
+                if "rs3_products_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+        big = [v for v in vals if v > 0.5 * max(vals)] if vals else []       # (spare passes leave at once: not a pass over L)
+        return (sum(big) / len(big), len(big)) if big else (None, 0)
+
+    fk, nf = one("replay_pmc_fetch", "FETCH_SIZE")
+    wk, _ = one("replay_pmc_write", "WRITE_SIZE")
+    busy, _ = one("replay_pmc_mfma", "SQ_VALU_MFMA_BUSY_CYCLES")
+    gui, _ = one("replay_pmc_mfma", "GRBM_GUI_ACTIVE")
+    n_ = 8192
+    alg = 8.0 * n_ * (n_ + 1) / 2
+    with open(f"profiles/{tag}_replay_summary.md", "w") as f:
+        f.write(f"# Round {tag[1:]}: the default contract (R-stream replay), `rocprofv3 --kernel-trace --stats -- python3 tools/rstream_step.py 8192 1024` (library commit {commit})\n\n")
+        f.write("Init + five iterations at 8192 x 1024.  draw_f resolves up to THREE items per pass over L (rng_ess.hip, DESIGN.md section 2): "
+                "`rs3_products_kernel` = L z for the pass's 32 candidate columns (1 + 15 + 16), `rs3_slice_kernel` = the three slice loops, "
+                "eight trial points per meeting; `rs3_begin_kernel` = the normal that starts at every position of the iteration's window; "
+                "`rs_tile_kernel` = L re-tiled once per iteration; `rs_unpack_kernel` = Mersenne-Twister words -> unif_rand() values.\n\n")
+        for l in log:
+            f.write(l + "\n\n")
+        f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
+        for r in rrows[:14]:
+            f.write(f"| `{short(r['Name'])[:80]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.3f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |\n")
+        st = stat_row(rrows, "rs3_products_kernel")
+        if st:
+            # the spare passes (every item already done) leave at once: the average over REAL passes is what the roofline needs
+            tr = newest(raw + "/replay_stats/**/*kernel_trace.csv")
+            dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(tr)) if "rs3_products_kernel" in r["Kernel_Name"]]
+            real = [d for d in dur if d > 0.5 * max(dur)]
+            avg_us = sum(real) / len(real)
+            f.write(f"\n`rs3_products_kernel`: {len(real)} real passes of {len(dur)} launches (the others find every item done and leave at once), "
+                    f"{avg_us:.1f} us per real pass -> {alg / avg_us / 1e6:.2f} TB/s of L (algorithmic 8 n (n + 1) / 2 = {alg / 1e6:.0f} MB) = "
+                    f"{alg / avg_us / 1e6 / 8.0:.3f} of the 8 TB/s HBM peak; its 2 x 32 x n (n + 1) / 2 = {64 * n_ * (n_ + 1) / 2 / 1e9:.2f} GFLOP per pass = "
+                    f"{64 * n_ * (n_ + 1) / 2 / avg_us / 1e6:.1f} TFLOP/s = {64 * n_ * (n_ + 1) / 2 / avg_us / 1e6 / 78.6:.3f} of the fp64 MFMA peak.\n")
+        if fk:
+            f.write(f"\nPMC passes of `tools/rstream_step.py 8192 128` (separate runs), averages over the {nf} real passes: FETCH_SIZE {fk:.0f} KB raw "
+                    f"(x 2 = {2 * fk * 1024 / 1e6:.0f} MB: gfx950 tallies 128-B requests at 64 B), WRITE_SIZE {wk:.0f} KB ({wk * 1024 / 1e6:.1f} MB: the parts of the "
+                    f"32 products) -> traffic {(2 * fk + wk) * 1024 / 1e6:.0f} MB = {(2 * fk + wk) * 1024 / alg:.2f} x algorithmic")
+            if busy and gui:
+                f.write(f"; MFMA busy {busy / ((gui / 8) * 1024):.3f} of the chip's SIMDs")
+            f.write(".\n")
+    print(open(f"profiles/{tag}_replay_summary.md").read()[:2500])
 print(open(f"profiles/{tag}_summary.md").read()[:3000])
