@@ -6,8 +6,11 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profiles_raw
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alt-forms > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alt-forms --no-reference-rng > $OUT/stats.log 2>&1
 echo "stats done"
+# the same with the default-contract leg (its factorisations have other shapes: kept out of the run the syrk averages come from)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ref -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-forms > $OUT/stats_ref.log 2>&1
+echo "stats_ref done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt-forms --no-reference-rng > $OUT/pmc_fetch.log 2>&1
 echo "fetch done"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt-forms --no-reference-rng > $OUT/pmc_write.log 2>&1
