@@ -585,6 +585,33 @@ def test_r_stream_draw_f_three_items_per_pass_odd_shapes(handle, oracle, n, m):
     assert state[1] == mti_ref and np.array_equal(state[0], mt_ref)
 
 
+@pytest.mark.parametrize("n,m", [(9216, 5), (16448, 4), (33024, 3)])
+def test_r_stream_draw_f_at_large_n_against_the_oracle_stage(handle, oracle, n, m):
+    """The replay's slice kernel keeps 1 / 2 / 4 / 8 rows per thread (n <= 8192 / 16384 / 32768 / 65536, rng_ess.hip); the
+    whole-chain tests only reach the first.  Here draw_f of ONE iteration at n = 9216, 16448 (257 row blocks of 64) and
+    33024 is compared with the oracle's draw_f (src/draw-f.cpp:64-73) run on the device's own state -- f, L, mu after init and
+    the generator at the consumed position: rejection counts exact, f to 1e-9."""
+    from gpirt_amd import Sampler
+    from gpirt_amd.ops import RStream
+    from gpirt_amd.synthetic import make_responses
+    y, th0 = make_responses(n, m, seed=n + m)
+    rs = RStream(1234)
+    s = Sampler(handle, y, th0, rng="reference", rstream=rs, theta_stabilise=True)
+    s.init(); s.check()
+    mt, mti = rs.state()                                  # the generator where the chain stands
+    f0, L0, mu0 = s.get("f"), s.get("L"), s.get("mu")
+    s.step(); s.check()                                   # draw_f is the iteration's first stage; nothing later touches f
+    f1, k_dev = s.get("f"), s.get("ess_k")
+    s.close()
+    r = oracle.RStream(0)
+    for q in range(624):
+        r.s.mt[q] = int(mt[q])
+    r.s.mti = int(mti)
+    f_ref, k_ref = oracle.draw_f(r, f0, y, np.tril(L0), mu0)
+    assert np.array_equal(k_dev, k_ref), (k_dev, k_ref)
+    assert np.abs(f1 - f_ref).max() <= 1e-9 * max(1.0, np.abs(f_ref).max())
+
+
 def test_r_stream_destroyed_under_an_attached_sampler_is_an_error_not_a_dangling_pointer(handle):
     """gpirt_rstream_destroy while a sampler created on the stream is alive but NOT running ahead of it (right after init,
     or after another sampler took the generator over): the sampler must learn that its stream is gone -- the next step fails
