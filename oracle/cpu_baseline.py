@@ -5,10 +5,11 @@ nothing in the product path imports this.
 Two legs, both per MCMC iteration of src/gpirtMCMC.cpp:68-78 at (n, m):
   (i)  reference-shaped, ONE thread: the line-following C restatement (oracle/gpirt_oracle.c) with the unblocked
        Cholesky -- the per-item BLAS-2 structure stock R + reference BLAS executes;
-  (ii) the same restatement on ALL host cores: blocked Cholesky with OpenMP (oracle/oracle_fast.c, full size, not
-       extrapolated) and the item / grid-column / respondent loops of draw_f, draw_fstar, draw_beta, draw_theta
-       spread over a thread pool (the C calls release the GIL; items are independent under the item RNG).
-Every piece is timed on a sample and scaled linearly in the sampled dimension (cubically for the unblocked
+  (ii) the same restatement on ALL host cores, ONE WHOLE ITERATION AT THE FULL SIZE, nothing extrapolated: blocked Cholesky
+       with OpenMP (oracle/oracle_fast.c) and the item / grid-column / respondent loops of draw_f, draw_fstar, draw_theta,
+       draw_beta spread over a thread pool (oracle/parallel.py: the C calls release the GIL; items are independent under
+       the item RNG) -- the driver the metric-size parity test checks every draw of the device against.
+Every piece of (i) is timed on a sample and scaled linearly in the sampled dimension (cubically for the unblocked
 Cholesky, quadratically for K); the factors are returned so the reader can see how far each number is stretched.
 """
 from __future__ import annotations
@@ -21,6 +22,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 from . import oracle as O
+from . import parallel as P
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -127,14 +129,8 @@ def run(n, m, y, theta, L, f, beta, mu, fstar, nthreads=None):
     fi, yi, mui = _F(f[:, :mi]), _F(y[:, :mi]), _F(mu[:, :mi])
     one["draw_f"] = _timed(lambda: _draw_f(lib, O.ItemStream(1), 1, fi, yi, L, mui)) * (m / mi)
     factors["one.items"] = m / mi
-    per_t = 4
-    mt = min(m, per_t * nthreads)
-    chunks = [slice(a, min(a + per_t, mt)) for a in range(0, mt, per_t)]
-    args = [(_F(f[:, c]), _F(y[:, c]), _F(mu[:, c])) for c in chunks]
-    with ThreadPoolExecutor(nthreads) as pool:
-        allc["draw_f"] = _pool_time(pool, [lambda a=a: _draw_f(lib, O.ItemStream(1), 1, a[0], a[1], L, a[2]) for a in args]) * (m / mt)
-        factors["all.items"] = m / mt
-
+    allc["draw_f"] = _timed(lambda: P.draw_f(1, 1, f, y, L, mu, nthreads))            # all m items, full size
+    if True:
         # ---- draw_fstar: t = c * (grid columns) + p * (items); two calls separate c and p ---------
         gs = 16
         mu_star = _F(beta[0][None, :mi] + ts[:gs, None] * beta[1][None, :mi])
@@ -146,18 +142,8 @@ def run(n, m, y, theta, L, f, beta, mu, fstar, nthreads=None):
         c = max(tB - p, 0.0) / gs
         one["draw_fstar"] = c * N + p * m
         factors["one.grid_columns"] = N / gs
-        g_t = 4                                    # per thread: 4 grid columns, then 4 items
-        tsl = [ts[a:a + g_t].copy() for a in range(0, g_t * nthreads, g_t)]
-        fa = [(_F(f[:, cc]), _F(beta[0][None, cc] + tsl[i][:, None] * beta[1][None, cc])) for i, cc in enumerate(chunks)]
-        fb = [(_F(a[0][:, :1]), _F(a[1][:, :1])) for a in fa]
-        tA2 = _pool_time(pool, [lambda i=i: _draw_fstar(lib, O.ItemStream(1), 1, fa[i][0], theta, tsl[i], L, fa[i][1])
-                                for i in range(len(fa))])
-        tB2 = _pool_time(pool, [lambda i=i: _draw_fstar(lib, O.ItemStream(1), 1, fb[i][0], theta, tsl[i], L, fb[i][1])
-                                for i in range(len(fb))])
-        p2 = max(tA2 - tB2, 0.0) / max(per_t - 1, 1)         # wall per item per thread, all threads busy
-        c2 = max(tB2 - p2, 0.0) / g_t
-        allc["draw_fstar"] = c2 * N / nthreads + p2 * m / nthreads
-        factors["all.grid_columns"] = N / (g_t * nthreads)
+        mu_star_full = _F(beta[0][None, :] + ts[:, None] * beta[1][None, :])
+        allc["draw_fstar"] = _timed(lambda: P.draw_fstar(1, 1, f, theta, L, mu_star_full, nthreads))   # 1001 grid columns + all m items
 
         # ---- draw_theta ---------------------------------------------------------------------------
         fs = _F(fstar)
@@ -165,21 +151,14 @@ def run(n, m, y, theta, L, f, beta, mu, fstar, nthreads=None):
         ys = _F(y[:ns, :])
         one["draw_theta"] = _timed(lambda: _draw_theta(lib, O.ItemStream(1), 1, ts, prior, ys, fs)) * (n / ns)
         factors["one.respondents"] = n / ns
-        r_t = 32
-        nt = min(n, r_t * nthreads)
-        yb = [_F(y[a:a + r_t, :]) for a in range(0, nt, r_t)]
-        allc["draw_theta"] = _pool_time(pool, [lambda b=b: _draw_theta(lib, O.ItemStream(1), 1, ts, prior, b, fs) for b in yb]) * (n / nt)
-        factors["all.respondents"] = n / nt
+        allc["draw_theta"] = _timed(lambda: P.draw_theta(1, 1, y, fs, True, nthreads))     # all n respondents
 
         # ---- draw_beta ----------------------------------------------------------------------------
         pm, ps, st = np.zeros((2, mi), order="F"), np.full((2, mi), 3.0, order="F"), np.full((2, mi), 0.1, order="F")
         bi = _F(beta[:, :mi])
         one["draw_beta"] = _timed(lambda: _draw_beta(lib, O.ItemStream(1), 1, bi, theta, yi, fi, pm, ps, st)) * (m / mi)
-        bargs = [(_F(beta[:, cc]), a[1], a[0]) for cc, a in zip(chunks, args)]
-        pm4, ps4, st4 = np.zeros((2, per_t), order="F"), np.full((2, per_t), 3.0, order="F"), np.full((2, per_t), 0.1, order="F")
-        allc["draw_beta"] = _pool_time(pool, [lambda b=b: _draw_beta(lib, O.ItemStream(1), 1, b[0], theta, b[1], b[2],
-                                                                     pm4[:, :b[0].shape[1]], ps4[:, :b[0].shape[1]],
-                                                                     st4[:, :b[0].shape[1]]) for b in bargs]) * (m / mt)
+        pmf, psf, stf = np.zeros((2, m), order="F"), np.full((2, m), 3.0, order="F"), np.full((2, m), 0.1, order="F")
+        allc["draw_beta"] = _timed(lambda: P.draw_beta(1, 1, beta, theta, y, f, pmf, psf, stf, nthreads))
 
     t_one, t_all = sum(one.values()), sum(allc.values())
     return {
@@ -190,10 +169,11 @@ def run(n, m, y, theta, L, f, beta, mu, fstar, nthreads=None):
         "stage_seconds": {k: round(v, 3) for k, v in one.items()},
         "host_cores": nthreads,
         "all_cores": {
-            "value": 1.0 / t_all, "unit": "iterations/s", "cores": nthreads, "kind": "port", "extrapolated": True,
-            "sample": (f"same restatement on {nthreads} threads: blocked OpenMP potrf at the full n = {n} (not extrapolated), "
-                       f"draw_f / draw_beta on {mt} items, draw_fstar on {g_t * nthreads} grid columns + {mt} items, draw_theta on "
-                       f"{nt} respondents, {per_t} items / {g_t} columns / {r_t} respondents per thread"),
+            "value": 1.0 / t_all, "unit": "iterations/s", "cores": nthreads, "kind": "port", "extrapolated": False,
+            "sample": (f"same restatement on {nthreads} threads, ONE WHOLE ITERATION AT THE FULL SIZE ({n} x {m}), nothing extrapolated: "
+                       f"K (scalar loop, one thread, as src/covariance-function.cpp:3-14), blocked OpenMP potrf, draw_f over all {m} items, "
+                       f"draw_fstar over all {N} grid columns and {m} items, draw_theta over all {n} respondents, draw_beta "
+                       f"(oracle/parallel.py: the driver tests/test_gpu_metric_oracle.py checks every draw of the device against)"),
             "stage_seconds": {k: round(v, 3) for k, v in allc.items()},
         },
         "extrapolation_factors": {k: round(v, 1) for k, v in factors.items()},

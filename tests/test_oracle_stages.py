@@ -183,5 +183,7 @@ def test_cpu_baseline_leg_runs_on_a_small_problem(oracle):
     assert r["kind"] == "port" and r["cores"] == 1 and r["extrapolated"] is True and r["value"] > 0 and np.isfinite(r["value"])
     a = r["all_cores"]
     assert a["cores"] == 2 and a["value"] > 0 and np.isfinite(a["value"])
+    assert a["extrapolated"] is False                            # the all-core leg is one whole iteration at the full size
+    assert set(a["stage_seconds"]) == {"K", "chol", "draw_f", "draw_fstar", "draw_theta", "draw_beta"}
     assert set(r["stage_seconds"]) == {"K", "chol", "draw_f", "draw_fstar", "draw_theta", "draw_beta"}
     assert r["extrapolation_factors"]["all.chol"] == 1.0      # the all-core potrf runs at the full size
