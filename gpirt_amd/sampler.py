@@ -43,7 +43,7 @@ def _options(rng, seed, theta_stabilise, fstar_fused, device, item0=0, m_total=0
 def gpirtMCMC(data, sample_iterations, burn_iterations, vote_codes=None, beta_prior_means=None,
               beta_prior_sds=None, beta_proposal_sds=None, theta_init=None, *, rng="reference",
               seed=1, rstream=None, theta_stabilise=False, fstar_fused=False, kstar_rank=0, device=None,
-              progress=False):
+              progress=False, preset=None):
     """Drop-in for the reference's gpirtMCMC() (R/gpirtMCMC.R:85-105) on one MI355X.
 
     Positional arguments, defaults and the returned dict (theta (S+1) x n, beta 2 x m x (S+1),
@@ -54,6 +54,8 @@ def gpirtMCMC(data, sample_iterations, burn_iterations, vote_codes=None, beta_pr
       rng="item":      counter-based per-item sub-streams keyed by `seed` (batched, shardable).
     fstar_fused / kstar_rank: algebraically identical, cheaper forms of draw_fstar:
       the mean as (L^-1 k*)^T (L^-1 f), and K(theta, theta*) through its exact rank-r Chebyshev factorisation.
+    preset="fast": the library's throughput preset, gpirt_fast_options() (R: options(gpirt.hip.preset = "fast")) --
+      item-keyed RNG with this call's `seed`, theta_stabilise, fstar_fused, kstar_rank = 64; what bench.py times.
     """
     from .ops import RStream
 
@@ -68,6 +70,10 @@ def gpirtMCMC(data, sample_iterations, burn_iterations, vote_codes=None, beta_pr
     for a in (pm, ps, st):
         if a.shape != (2, m):
             raise ValueError("beta prior / proposal matrices must be 2 x ncol(data)")
+    if preset == "fast":
+        rng = "item"
+    elif preset is not None:
+        raise ValueError(f"unknown preset {preset!r}")
     rs = None
     if rng == "reference":
         rs = rstream if rstream is not None else RStream(seed)
@@ -84,7 +90,12 @@ def gpirtMCMC(data, sample_iterations, burn_iterations, vote_codes=None, beta_pr
     be = np.empty((2, m, S + 1), order="F")
     ff = np.empty((n, m, S + 1), order="F")
     irf = np.empty((NGRID, m), order="F")
-    o = _options(rng, seed, theta_stabilise, fstar_fused, device, kstar_rank=kstar_rank)
+    if preset == "fast":
+        o = _lib.fast_options()
+        o.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        o.device = -1 if device is None else int(device)
+    else:
+        o = _options(rng, seed, theta_stabilise, fstar_fused, device, kstar_rank=kstar_rank)
 
     def _tick(ctx, it, total):                                       # src/gpirtMCMC.cpp:64-66
         if progress:

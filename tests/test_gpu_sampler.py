@@ -50,6 +50,23 @@ def test_mcmc_item_rng_matches_oracle(handle, oracle, n, m, S, B, fused, rank):
     _check(res, ref)
 
 
+def test_mcmc_fast_preset_is_the_item_rng_rank64_chain(handle, oracle):
+    """preset="fast" = gpirt_fast_options() through the drop-in (what bench.py times): the same draws as the options spelled
+    out one by one, and the oracle's to the stated tolerance."""
+    from gpirt_amd import gpirtMCMC
+    from gpirt_amd.synthetic import make_responses
+    n, m, S, B, seed = 200, 20, 2, 2, 4242
+    y, th0 = make_responses(n, m, seed=3 + n)
+    codes = dict(yea=[1], nay=[-1], missing=[None])
+    a = gpirtMCMC(y, S, B, vote_codes=codes, theta_init=th0, preset="fast", seed=seed)
+    b = gpirtMCMC(y, S, B, vote_codes=codes, theta_init=th0, rng="item", seed=seed, theta_stabilise=True, fstar_fused=True,
+                  kstar_rank=64)
+    for k in ("theta", "beta", "f", "IRFs"):
+        assert np.array_equal(a[k], b[k]), k
+    ref = oracle.gpirt_mcmc(oracle.ItemStream(seed), y, th0, S, B, theta_stabilise=True, fstar_fused=True)
+    _check(a, ref)
+
+
 def test_senate116_plumbing(handle, oracle):
     """Config C1: the senate116-derived matrix (n=100, m=418) through the drop-in, 3 iterations."""
     import os
