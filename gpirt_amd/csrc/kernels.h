@@ -109,8 +109,8 @@ static_assert(1 + RS3_C1 == 16 && RS3_C2 == 16 * (RS3_NT - 1), "tile 0 = slots 0
 constexpr int RS3_TRIALS = 8;        // trial points of a slice loop evaluated per meeting of the work-groups
 constexpr int RS3_MAX_WGS = 256;     // work-groups of the slice kernel (32 R rows each, R <= 8 rows per thread)
 constexpr int64_t RS3_MAX_N = (int64_t)RS3_MAX_WGS * 256;
-constexpr int RS3_QSTRIDE = 8 * RS3_NT * 65;             // products: one wave's 24 accumulators per lane in LDS (rows of 65: bank spread)
-constexpr int RS3_LDS_DOUBLES = 4 * RS3_QSTRIDE;     //   the three Nrm windows of a part (5 RS_KC + 16 + RS3_C2 doubles), then the four waves' accumulators
+constexpr int RS3_QSTRIDE = 4 * RS3_NT * 65;         // products: one wave's accumulators of ONE tile parity per lane in LDS (rows of 65: bank spread)
+constexpr int RS3_LDS_DOUBLES = (4 * RS3_QSTRIDE > 5 * RS_KC + 16 + RS3_C2) ? 4 * RS3_QSTRIDE : 5 * RS_KC + 16 + RS3_C2;    //   the three Nrm windows of a part (5 RS_KC + 16 + RS3_C2 doubles), then the four waves' accumulators
 static_assert(5 * RS_KC + 16 + RS3_C2 <= RS3_LDS_DOUBLES, "the windows must fit");
 struct Rs3Args {
     const double* U; uint64_t cap;   // the window of stream uniforms

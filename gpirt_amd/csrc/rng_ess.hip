@@ -334,8 +334,10 @@ __device__ __forceinline__ void rs3_product_block(const Rs3Args& a, const uint64
 // RS3_RING steps (1 KiB each) per wave, refilled as it is consumed -- every load address is known up front, nothing is
 // conditional, so the compiler's vmcnt bookkeeping lets step s start the moment ITS kilobyte has arrived while 11 more are in
 // flight behind it (the first form issued eight, waited for all, and only then computed).
-constexpr int RS3_RING = 12;       // (8 / 12 / 16 measure the same; the four waves taking the part's steps in turn, one 128 KB stream per
-                                   //  work-group instead of four of 32 KB, too: gpurun_out/r5h, r5i)
+constexpr int RS3_RING = 10;       // (8 / 12 / 16 measure the same at four work-groups per CU; the four waves taking the part's steps in
+                                   //  turn, one 128 KB stream per work-group instead of four of 32 KB, too: gpurun_out/r5h, r5i.  10 = what
+                                   //  fits the 96 registers of FIVE work-groups per CU: 29.7 ms of draw_f at 8192 x 1024 against 30.8 with
+                                   //  four; six / seven / eight with rings of 8 / 6 / 4: 30.2-30.3 / 30.8 / 30.2)
 template <int NT>
 __device__ __forceinline__ void rs3_product_full(const Rs3Args& a, const uint64_t base, const int bx, const int by, double* lds,
                                                  const double* Lp, long long* tr)
@@ -407,40 +409,41 @@ __device__ __forceinline__ void rs3_product_full(const Rs3Args& a, const uint64_
         }
     }
     // The four quarters meet in LDS (the windows' space is free behind the barrier) and ALL 256 threads add them, in the order
-    // ((q0 + q1) + q2) + q3, and store: thread x takes (row x & 31, candidate x >> 5 + 8 p), so a wave writes two whole
-    // 256-byte row segments per store.  (Wave 0 alone adding its own 24 accumulators and storing them lane by lane -- 64 lines
+    // ((q0 + q1) + q2) + q3, and store: thread x takes (one row of a parity, candidate x >> 4 + 16 p): coalesced down to
+    // every other row of a candidate's 256-byte segment, the other half follows in the second phase.  (Wave 0 alone adding its own 24 accumulators and storing them lane by lane -- 64 lines
     // touched per store instruction, 43 registers spilled around the additions -- took 5 to 16 us per work-group, as long
     // as its MFMAs: in-kernel stamps, tools/rs_trace.py.)
     rs_stamp(tr, 3);                                          // this wave's MFMAs issued
-    __syncthreads();
-    rs_stamp(tr, 4);
-    {
-        double* mine = lds + (size_t)kq * RS3_QSTRIDE + lane;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int ct = 0; ct < NT; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mine[((t * NT + ct) * 4 + r) * 65] = acc[t][ct][r];      // (65: the readers' bank spread)
-    }
-    __syncthreads();
-    // lane (i, g) of a wave held acc[t][ct][r] = row 8 g + 2 r + t of the group, candidate 16 ct + i
+    // ... in two phases, the even rows of the group (tile t = 0), then the odd ones: half the LDS (16.6 KB, less than the
+    // windows' 20.7), which is what lets a fifth work-group onto every compute unit
     double* out = a.part + ((int64_t)by * RS3_CAND) * n + r0;
 #pragma unroll
-    for (int p = 0; p < (16 * NT) / 8; ++p) {
-        const int x = threadIdx.x + 256 * p;
-        const int row = x & 31, c = x >> 5;
-        const int gg = row >> 3, rr = (row >> 1) & 3, tt = row & 1, ii = c & 15, cc = c >> 4;
-        const double* src = lds + ((tt * NT + cc) * 4 + rr) * 65 + ii + 16 * gg;
-        const double v = ((src[0] + src[RS3_QSTRIDE]) + src[2 * RS3_QSTRIDE]) + src[3 * RS3_QSTRIDE];
-        if (r0 + row < n) out[(int64_t)c * n + row] = v;
+    for (int tt = 0; tt < 2; ++tt) {
+        __syncthreads();
+        if (tt == 0) rs_stamp(tr, 4);
+        double* mine = lds + (size_t)kq * RS3_QSTRIDE + lane;
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mine[(ct * 4 + r) * 65] = acc[tt][ct][r];      // (65: the readers' bank spread)
+        __syncthreads();
+        // lane (i, g) of a wave held acc[tt][ct][r] = row 8 g + 2 r + tt of the group, candidate 16 ct + i
+#pragma unroll
+        for (int p = 0; p < (16 * NT) / 16; ++p) {
+            const int x = threadIdx.x + 256 * p;
+            const int row = 2 * (x & 15) + tt, c = x >> 4;
+            const int gg = row >> 3, rr = (row >> 1) & 3, ii = c & 15, cc = c >> 4;
+            const double* src = lds + (cc * 4 + rr) * 65 + ii + 16 * gg;
+            const double v = ((src[0] + src[RS3_QSTRIDE]) + src[2 * RS3_QSTRIDE]) + src[3 * RS3_QSTRIDE];
+            if (r0 + row < n) out[(int64_t)c * n + row] = v;
+        }
     }
     rs_stamp(tr, 5);
 }
 
 // one work-group per unit of the table the sampler built (rs3_unit_table): full parts first, then the ragged ones.  The
 // anchor is ONE 32-byte record (item, start, end of Nrm): one scalar load, in flight together with the unit's.
-__global__ __launch_bounds__(256, 4) void rs3_products_kernel(Rs3Args a)
+__global__ __launch_bounds__(256, 5) void rs3_products_kernel(Rs3Args a)
 {
     __shared__ double lds[RS3_LDS_DOUBLES];
     const uint64_t item0 = a.anchor[0], base = a.anchor[1];   // (both scalar loads of the prologue go out together)
