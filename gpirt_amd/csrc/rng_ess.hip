@@ -352,6 +352,7 @@ __device__ __forceinline__ void rs3_product_full(const Rs3Args& a, const uint64_
     // Their loads go out together ...
     const uint64_t item_step = 2ull * (uint64_t)n + 2ull;
     double* W0 = lds; double* W1 = lds + RS_KC; double* W2 = W1 + 2 * RS_KC + 16;
+    static_assert(RS_KC % 256 == 0, "the slot-0 window is staged 256 entries at a time");
     constexpr int C0 = RS_KC / 256, C1 = (2 * RS_KC + 16 + 255) / 256, C2 = (2 * RS_KC + RS3_C2 + 255) / 256;
     const double* N0 = a.Nrm + base + 2ull * (uint64_t)k0;
     const double* N1 = N0 + item_step;
