@@ -449,7 +449,8 @@ def main():
                 # the default contract's draw_f: one pass over L per three items (rs3_products_kernel), HBM-bound
                 "replay_products": _roof_entry(replay_prof, "hbm", PEAK_HBM_GBS, "GB/s",
                                                "rs3_products_kernel (R-stream replay, gpirt_default_options): bytes = the lower triangle of L, "
-                                               "8 n (n + 1) / 2, per launch; timed in the reference_rng leg of this run"),
+                                               "8 n (n + 1) / 2, per launch; timed in the reference_rng leg of this run (an event pair spans the kernel and ONE "
+                                               "kernel boundary, ~2 us of a ~52 us pass: rocprofv3's per-kernel average is that much shorter)"),
                 "note": "HIP events around each launch on its own stream (main or look-ahead side stream) inside the timed region, on "
                         "a sample of the timed steps (the first and the middle one: bracketing every launch of every step costs 4 % "
                         "of the iteration rate); launches of the two streams overlap each other and the panel kernel, so "
