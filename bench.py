@@ -317,6 +317,25 @@ def main():
                                        "as written" + ("; theta_stabilise = 1 because the literal default (0) failed on this problem: "
                                                        + literal_error if stab else "; theta_stabilise = 0 (the literal default)")}
                 sr.close()
+                # the same contract's RNG -- R's stream, consumed exactly as the reference consumes it -- with the cheaper,
+                # algebraically identical forms of draw_fstar (R: options(gpirt.hip.fstar_fused = TRUE, gpirt.hip.kstar_rank = 64))
+                by_form = {"double_solve": ref_rng["value"]}
+                for name_, kw_ in (("fused", dict(fstar_fused=True)), ("lowrank", dict(fstar_fused=True, kstar_rank=64))):
+                    s2 = Sampler(handle, y, theta0, rng="reference", rstream=RStream(20240), theta_stabilise=stab, **kw_)
+                    try:
+                        s2.init(); s2.check(); s2.step(); s2.check()
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        for _ in range(2):
+                            s2.step()
+                        torch.cuda.synchronize()
+                        by_form[name_] = 2.0 / (time.perf_counter() - t0)
+                        s2.check()
+                    except Exception as exc2:
+                        by_form[name_] = None
+                        by_form[name_ + "_error"] = repr(exc2)
+                    s2.close()
+                ref_rng["iterations_per_s_by_fstar_form"] = by_form
                 break
             except Exception as exc:
                 literal_error = repr(exc)

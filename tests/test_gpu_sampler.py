@@ -50,6 +50,30 @@ def test_mcmc_item_rng_matches_oracle(handle, oracle, n, m, S, B, fused, rank):
     _check(res, ref)
 
 
+@pytest.mark.parametrize("fused,rank", [(True, 0), (True, 64)])
+def test_mcmc_reference_rng_with_the_cheaper_fstar_forms(handle, oracle, fused, rank):
+    """R's stream replayed (the default RNG contract) TOGETHER with the algebraically identical forms of draw_fstar
+    (options(gpirt.hip.fstar_fused = TRUE, gpirt.hip.kstar_rank = 64) under the default gpirt.hip.rng): the stream is consumed
+    exactly as the reference consumes it -- the 1001 x m predictive normals do not depend on how their means were computed --
+    so the chain is the oracle's (its `fused` wording of src/draw-fstar.cpp:17-25) to the stated tolerance and the
+    generator ends where the oracle's does."""
+    from gpirt_amd import gpirtMCMC
+    from gpirt_amd.ops import RStream
+    from gpirt_amd.synthetic import make_responses
+    n, m, S, B = 256, 14, 2, 2
+    y, _ = make_responses(n, m, seed=77, snap_theta=False)
+    rs = RStream(321)
+    res = gpirtMCMC(y, S, B, vote_codes=dict(yea=[1], nay=[-1], missing=[None]), rng="reference", rstream=rs,
+                    fstar_fused=fused, kstar_rank=rank)
+    r = oracle.RStream(321)
+    th0 = r.rnorm(n)
+    ref = oracle.gpirt_mcmc(r, y, th0, S, B, fstar_fused=True)
+    _check(res, ref)
+    mt, mti = rs.state()
+    mt_ref, mti_ref = r.mt_state()
+    assert mti == mti_ref and np.array_equal(mt, mt_ref)
+
+
 def test_mcmc_fast_preset_is_the_item_rng_rank64_chain(handle, oracle):
     """preset="fast" = gpirt_fast_options() through the drop-in (what bench.py times): the same draws as the options spelled
     out one by one, and the oracle's to the stated tolerance."""

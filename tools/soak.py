@@ -1,6 +1,8 @@
 """Repeatability soak for the flag-synchronised kernels: run the same chain twice in one process (fresh samplers) and
 require bit-identical state after every iteration -- a lost hand-off or a stale read would show up as a mismatch,
-NaN or the panel guard.  usage: python tools/soak.py [n=3000] [m=96] [iters=150] [load=0]
+NaN or the panel guard.  usage: python tools/soak.py [n=3000] [m=96] [iters=150] [load=0] [rng=item|reference]
+rng = reference: the default contract -- the R-stream replay's draw_f (rs3_slice_kernel: three meetings of up to 256
+work-groups per pass) under the same repeat / foreign-load regime.
 load = 1: the SECOND run has foreign work beside it -- a torch stream streaming 1 GiB copies and fp64 matmuls of changing
 size, unsynchronised with the sampler -- so the hand-offs are exercised under UNEVEN load (MI355X_MICROARCH.md: "test every
 hand-off under uneven load ... checking every word"): every checkpoint must still match the quiet first run bit for bit."""
@@ -15,6 +17,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 m = int(sys.argv[2]) if len(sys.argv) > 2 else 96
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 150
 load = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+rng = sys.argv[5] if len(sys.argv) > 5 else "item"
 y, th0 = make_responses(n, m, seed=7)
 h = Handle()
 bg = torch.cuda.Stream()
@@ -27,7 +30,11 @@ def disturb(it):
         a = src[: k * k].view(k, k)
         torch.mm(a, a, out=dst[: k * k].view(k, k))      # MFMA + LDS traffic of a size that changes every iteration
 def run(disturbed=False):
-    s = Sampler(h, y, th0, rng="item", seed=11, theta_stabilise=True, fstar_fused=True, kstar_rank=64)
+    if rng == "reference":
+        from gpirt_amd.ops import RStream
+        s = Sampler(h, y, th0, rng="reference", rstream=RStream(11), theta_stabilise=True)
+    else:
+        s = Sampler(h, y, th0, rng="item", seed=11, theta_stabilise=True, fstar_fused=True, kstar_rank=64)
     s.init()
     digs = []
     for it in range(iters):
@@ -44,5 +51,5 @@ def run(disturbed=False):
     return digs
 a = run(); b = run(disturbed=bool(load))
 bad = [i for i, (x, y_) in enumerate(zip(a, b)) if x != y_]
-print(f"n={n} m={m} iters={iters}: {len(a)} checkpoints, mismatches at {bad}" if bad else f"n={n} m={m} iters={iters}: {len(a)} checkpoints bit-identical across two runs" + (" (second run beside foreign load)" if load else ""))
+print(f"rng={rng} n={n} m={m} iters={iters}: {len(a)} checkpoints, mismatches at {bad}" if bad else f"rng={rng} n={n} m={m} iters={iters}: {len(a)} checkpoints bit-identical across two runs" + (" (second run beside foreign load)" if load else ""))
 sys.exit(1 if bad else 0)
