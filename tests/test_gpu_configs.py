@@ -223,7 +223,7 @@ def test_c5_full_size_iterations(handle, capsys):
     Two whole iterations in the fp64 build, `lowrank` and `fused` side by side: potrf info == 0, theta on the grid and
     identical between the forms, f identical, f* within 1e-9 x max|f*|; the factor of the second iteration's theta
     against LAPACK dpotrf on the host (src/gpirtMCMC.cpp:76-78) <= 1e-9.  Then the mixed-precision build of the config
-    (fp32 kernel build, gpirt_options.reserved[1], + fp64 factorisation; SURVEY H3: S perturbed by ~6e-8 relative, parity
+    (fp32 kernel build, gpirt_options.kernel_fp32, + fp64 factorisation; SURVEY H3: S perturbed by ~6e-8 relative, parity
     statistical only): one whole iteration, info == 0 (the jitter dominates), theta on the grid, L within 5e-3 of the
     fp64 build's."""
     from scipy.linalg import cholesky
