@@ -207,8 +207,8 @@ __global__ __launch_bounds__(256) void rs3_begin_kernel(Rs3Args a, uint64_t span
 // L in the order the candidate products read it: tile (row group rg of 32 rows, column quad kb) = 1 KiB, lane l's two rows of
 // column 4 kb + (l >> 4) at doubles 2 l, 2 l + 1 -- the MFMA A operand of one step, so a wave's step is ONE contiguous
 // kilobyte and its steps follow each other in memory.  From column-major L the same step touches four 256-byte pieces
-// 64 KiB apart (a quarter of a DRAM page each): 3.55 TB/s.  Built once per iteration (a pass over the triangle: ~0.2 ms
-// against 1024 passes that read it); rows and columns past the matrix are zeros; only the tiles a product reads exist.
+// 64 KiB apart (a quarter of a DRAM page each): 3.55 TB/s.  Built once per iteration (a pass over the triangle: ~0.1 ms
+// against the ~345 passes that read it); rows and columns past the matrix are zeros; only the tiles a product reads exist.
 __global__ __launch_bounds__(256) void rs_tile_kernel(const double* __restrict__ L, int64_t n, int64_t ldl, int64_t nkb, double* __restrict__ Lt)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
