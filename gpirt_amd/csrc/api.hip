@@ -27,6 +27,7 @@ const Config& env_config()
         d.panel = env_value("GPIRT_PANEL", d.panel);      d.defer = env_value("GPIRT_DEFER", d.defer);
         d.trsm_inv = env_value("GPIRT_TRSM_INV", d.trsm_inv);
         d.ll_exact = env_value("GPIRT_LL_EXACT", d.ll_exact);
+        d.ess_screen = env_value("GPIRT_ESS_SCREEN", d.ess_screen);
         d.bordered = env_value("GPIRT_BORDERED", d.bordered);
         d.early_inv = env_value("GPIRT_EARLY_INV", d.early_inv);
         d.prep_early = env_value("GPIRT_PREP_EARLY", d.prep_early);
@@ -281,7 +282,7 @@ static int* config_slot(gpirt_handle_t h, const char* name, bool* read_only)
         { "GPIRT_NBO", &h->cfg.nbo, true }, { "GPIRT_NBP", &h->cfg.nbp, true },
         { "GPIRT_LOOKAHEAD", &h->cfg.lookahead, false }, { "GPIRT_PANEL", &h->cfg.panel, false },
         { "GPIRT_DEFER", &h->cfg.defer, false }, { "GPIRT_TRSM_INV", &h->cfg.trsm_inv, false },
-        { "GPIRT_LL_EXACT", &h->cfg.ll_exact, false }, { "GPIRT_BORDERED", &h->cfg.bordered, false },
+        { "GPIRT_LL_EXACT", &h->cfg.ll_exact, false }, { "GPIRT_ESS_SCREEN", &h->cfg.ess_screen, false }, { "GPIRT_BORDERED", &h->cfg.bordered, false },
         { "GPIRT_EARLY_INV", &h->cfg.early_inv, false }, { "GPIRT_PREP_EARLY", &h->cfg.prep_early, false },
     };
     for (auto& e : tab)
@@ -520,7 +521,7 @@ int gpirt_debug_panel_trace(gpirt_handle_t h, int64_t k0, long long* host_out, i
 int gpirt_debug_ll_term(gpirt_handle_t h, const double* d_a, int64_t n, double* d_out, int fast)
 {
     GP_ARG(h && (n == 0 || (d_a && d_out)) && n >= 0);
-    return launch_ll_term_probe(h->stream, d_a, n, d_out, fast != 0);
+    return launch_ll_term_probe(h->stream, d_a, n, d_out, fast);
 }
 
 int gpirt_potrf_finish(gpirt_handle_t h)
@@ -589,6 +590,7 @@ int gpirt_draw_f(gpirt_handle_t h, double* d_f, const double* d_y, const double*
     EssArgs a{};
     a.f = d_f; a.nu = NU; a.y = d_y; a.mu = d_mu; a.n = n; a.m = m; a.k_out = d_k_out; a.err = err;
     a.seed = seed; a.iter = iter; a.item0 = 0; a.U = nullptr; a.pos = nullptr; a.cap = 0;
+    a.ll_exact = h->cfg.ll_exact; a.screen = h->cfg.ess_screen == 1;
     GP_TRY(launch_ess(h->stream, a));
     GP_HIP(hipMemcpyAsync(h->h_info, err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     GP_HIP(hipStreamSynchronize(h->stream));

@@ -94,6 +94,7 @@ struct EssArgs {
     // R-stream replay (U != null): one column per launch, uniforms from U[*pos + 2n ...]
     const double* U; uint64_t* pos; uint64_t cap;
     int ll_exact;         // 1: log(1 + exp(-a)) through the library's exp and log, as written (GPIRT_LL_EXACT)
+    int screen;           // 1: the register kernels decide a trial point by the single-precision screen where it can (ll_fast.h)
 };
 int launch_ess(hipStream_t stream, const EssArgs& a);
 // R-stream replay of draw_f, three items per pass over L (rng_ess.hip; sampler.hip, do_draw_f)
@@ -144,7 +145,7 @@ void rs3_unit_table(int64_t n, std::vector<uint32_t>& units, int* nfull);
 int rs3_slice_wgs(int64_t n);
 int rs3_slice_rows(int64_t n);
 int launch_rs3_slice(hipStream_t stream, const Rs3Args& a);
-int launch_ll_term_probe(hipStream_t stream, const double* a, int64_t n, double* out, bool fast);
+int launch_ll_term_probe(hipStream_t stream, const double* a, int64_t n, double* out, int fast);     // 0 written, 1 ll_fast, 2 screen
 int launch_ll_bar(hipStream_t stream, const double* f, const double* y, const double* mu, int64_t n,
                   int64_t m, double* out);
 

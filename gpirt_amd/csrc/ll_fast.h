@@ -58,3 +58,22 @@ GP_LL_HD inline double ll_term_fast(double a)
     if (big) l = 0.693147180369123816490 + (l + 1.90821492927058770002e-10);      // + ln 2 (hi + lo)
     return (a < 0.0 ? x : 0.0) + l;
 }
+
+// ---- a SCREEN for the slice loop's accept test (rng_ess.hip, ess_kernel_reg) ----------------------------------------------
+// The loop only needs the SIGN of  ll_bar(f') - log_y  (src/draw-f.cpp:45): the same term in single precision through the
+// hardware's exp2 / log2 (v_exp_f32, v_log_f32: ~12 instructions instead of 91) decides it whenever the sum is further from
+// log_y than the screen's error bound; only inside that band the pass is repeated with the full-precision term, so every
+// accept / reject decision -- and with it every draw -- is the full-precision one.  Error of one screened term against
+// ll_term_fast: the part max(-a, 0) is exact (fp64); t = -|a| -> float (2^-24 relative), exp(t) <= 1 with relative error
+// <= 1.2e-7 + 1.8e-7 |t| (argument product + 1 ulp), log(1 + e) with absolute error <= 3e-7: below 5e-7 absolute in all.
+// LL_SCREEN_ERR is eight times that; tests/test_ll_fast.py measures the actual maximum on the device (gpirt_debug_ll_term,
+// form 2) over four million points and holds it under LL_SCREEN_ERR / 4.
+#define LL_SCREEN_ERR 4.0e-6
+#if defined(__HIPCC__)
+__device__ __forceinline__ double ll_term_screen(double a)
+{
+    const double x = fabs(a);
+    const float e = __expf(-(float)x);
+    return (a < 0.0 ? x : 0.0) + (double)__logf(1.0f + e);
+}
+#endif

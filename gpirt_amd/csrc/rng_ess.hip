@@ -22,7 +22,7 @@ __device__ __forceinline__ double ll_t(double a) { return FAST ? ll_term_fast(a)
 __global__ void ll_term_probe_kernel(const double* __restrict__ a, int64_t n, double* __restrict__ out, int fast)
 {
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (int64_t)gridDim.x * blockDim.x)
-        out[g] = fast ? ll_term_fast(a[g]) : ll_term(a[g]);
+        out[g] = fast == 2 ? ll_term_screen(a[g]) : fast ? ll_term_fast(a[g]) : ll_term(a[g]);
 }
 
 __global__ void item_fill_kernel(uint64_t seed, uint32_t iter, uint32_t stage, uint32_t item0,
@@ -782,16 +782,33 @@ __global__ __launch_bounds__(NTH) void ess_kernel_reg(EssArgs a)
     int k = 0;
     bool bad = false;
     double c, s;
+    // the screen's error bound for this item's sum (ll_fast.h): every row could be off by LL_SCREEN_ERR
+    const double band = LL_SCREEN_ERR * (double)n;
     for (;;) {
         c = cos(eps);
         s = sin(eps);
-        acc = 0.0;
+        // :45 needs the sign of ll_bar(f') - log_y only: the single-precision screen decides it outside its error band,
+        // the full-precision pass (what every decision is measured by) runs only inside it
+        int verdict = 0;                                                   // +1 accept, -1 reject, 0 undecided
+        if (a.screen) {
+            acc = 0.0;
 #pragma unroll
-        for (int e = 0; e < EPT; ++e)
-            if (Y[e] == Y[e]) acc += ll_t<FAST>(Y[e] * ((F[e] * c + V[e] * s) + M[e]));   // :43
-        const double llp = -block_sum(acc);
-        if (llp > log_y) break;                                            // :45-47
-        if (llp != llp) { bad = true; break; }
+            for (int e = 0; e < EPT; ++e)
+                if (Y[e] == Y[e]) acc += ll_term_screen(Y[e] * ((F[e] * c + V[e] * s) + M[e]));
+            const double lls = -block_sum(acc);
+            if (lls - band > log_y) verdict = 1;
+            else if (lls + band < log_y) verdict = -1;
+        }
+        if (verdict == 0) {
+            acc = 0.0;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e)
+                if (Y[e] == Y[e]) acc += ll_t<FAST>(Y[e] * ((F[e] * c + V[e] * s) + M[e]));   // :43
+            const double llp = -block_sum(acc);
+            if (llp > log_y) verdict = 1;                                  // :45-47
+            else if (llp != llp) { bad = true; break; }
+        }
+        if (verdict > 0) break;
         if (eps < 0.0) eps_min = eps; else eps_max = eps;                  // :50-55
         if (eps_min == eps_max) eps = eps_min;
         else eps = eps_min + (eps_max - eps_min) * item_uniform(a.seed, a.iter, GPIRT_ST_F_ESS, item, uidx++);
@@ -935,12 +952,12 @@ int launch_rs3_slice(hipStream_t stream, const Rs3Args& a)
     return 0;
 }
 
-int launch_ll_term_probe(hipStream_t stream, const double* a, int64_t n, double* out, bool fast)
+int launch_ll_term_probe(hipStream_t stream, const double* a, int64_t n, double* out, int fast)
 {
     if (n <= 0) return 0;
     int64_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(ll_term_probe_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, n, out, fast ? 1 : 0);
+    hipLaunchKernelGGL(ll_term_probe_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, n, out, fast);
     GP_HIP(hipGetLastError());
     return 0;
 }

@@ -387,6 +387,7 @@ int do_draw_f(gpirt_sampler_s* s)
         a.f = s->f; a.nu = s->NU; a.y = s->y; a.mu = s->mu; a.n = n; a.m = m; a.k_out = s->ess_k;
         a.err = s->flags; a.seed = s->opt.seed; a.iter = iter; a.item0 = (uint32_t)s->opt.item0;
         a.ll_exact = h->cfg.ll_exact;
+        a.screen = h->cfg.ess_screen == 1;
         GP_TRY(launch_ess(st, a));
         if (prep) {
             // what the low-rank draw_fstar needs from L alone, on the sampler's own stream (see `early` above)

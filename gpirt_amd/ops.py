@@ -243,11 +243,12 @@ class Handle:
         check(self.lib.gpirt_ll_bar(self._h, _p(f), _p(y), _p(mu), n, m, _p(out)))
         return out
 
-    def ll_term(self, a, fast=True) -> torch.Tensor:
-        """log(1 + exp(-a)) elementwise: the slice kernel's form (csrc/ll_fast.h) or, fast=False, the formula as written."""
+    def ll_term(self, a, fast=True, screen=False) -> torch.Tensor:
+        """log(1 + exp(-a)) elementwise: the slice kernel's form (csrc/ll_fast.h) or, fast=False, the formula as written;
+        screen=True: the single-precision screen of the slice loop's accept test (ll_term_screen, same header)."""
         a = a.contiguous().to(torch.float64)
         out = torch.empty_like(a)
-        check(self.lib.gpirt_debug_ll_term(self._h, _p(a), a.numel(), _p(out), int(bool(fast))))
+        check(self.lib.gpirt_debug_ll_term(self._h, _p(a), a.numel(), _p(out), 2 if screen else int(bool(fast))))
         return out
 
     def item_normals(self, seed, it, stage, item0, n_items, n_index) -> torch.Tensor:

@@ -145,7 +145,10 @@ int gpirt_debug_streams_busy(gpirt_handle_t h, int* busy);
 /* One term of ll() (src/log-likelihood.cpp:20,34), log(1 + exp(-a)), elementwise for the n device values d_a:
  * fast = 0 the formula as written through the device library's exp and log (ll_bar, draw_beta, draw_theta and every
  * R-stream replay use it), fast = 1 the form of csrc/ll_fast.h that the elliptical-slice kernel of the item-keyed RNG
- * evaluates (within 3 ulp of the exact value; GPIRT_LL_EXACT=1 makes that kernel use the written form too). */
+ * evaluates (within 3 ulp of the exact value; GPIRT_LL_EXACT=1 makes that kernel use the written form too), fast = 2 the
+ * single-precision SCREEN that kernel tries first at every trial point: it only decides an accept test whose sum is
+ * further from the slice level than the screen's error bound (4e-6 per row), everything closer is repeated in full
+ * precision, so the decisions and the draws are the full-precision ones (GPIRT_ESS_SCREEN=2 switches the screen off). */
 /* In-kernel time stamps of ONE sub-panel launch of the factorisation as it runs inside the schedule (100 MHz wall clock:
  * [row block relative to the launch][step 0..39][slot 0..7], the layout tools/micro/panel_bench.hip prints).
  * host_out == NULL arms it for the launch that starts at column k0 (count = entries to allocate, >= 40 * 8 * row blocks;

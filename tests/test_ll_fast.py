@@ -104,3 +104,56 @@ def test_slice_sampler_with_the_written_form_agrees():
     assert np.array_equal(k0, k1)
     assert np.array_equal(t0, t1)
     assert np.abs(f0 - f1).max() < 1e-10 * max(1.0, np.abs(f1).max())
+
+
+@pytest.mark.gpu
+def test_screen_of_the_accept_test_stays_inside_its_error_bound():
+    """ll_term_screen (single precision through v_exp_f32 / v_log_f32) against long double: the bound the slice kernel
+    widens its decisions by is LL_SCREEN_ERR = 4e-6 per row (csrc/ll_fast.h); the measured maximum has to stay under a
+    quarter of it, at every magnitude (the part max(-a, 0) of a term is carried in fp64, so the error does not grow with |a|)."""
+    import re
+    import torch
+    from gpirt_amd.ops import Handle
+    hdr = open(os.path.join(ROOT, "gpirt_amd", "csrc", "ll_fast.h")).read()
+    bound = float(re.search(r"#define LL_SCREEN_ERR ([0-9.eE+-]+)", hdr).group(1))
+    h = Handle()
+    rng = np.random.default_rng(6)
+    a = np.concatenate([np.linspace(-60, 60, 1200001), rng.uniform(-745, 745, 1000000), rng.uniform(-3, 3, 1000000),
+                        rng.uniform(-20, 20, 1000000), rng.standard_normal(200000) * 1e-3,
+                        [0.0, -0.0, 37.0, 40.0, 87.0, 88.8, 104.0, 745.2, -745.2, -800.0, 1e-300, -1e-300, 1e30, -1e30, 1e300, -1e300]])
+    al = a.astype(np.longdouble)
+    ref = np.where(al < 0, -al, 0) + np.log1p(np.exp(-np.abs(al)))
+    got = h.ll_term(torch.from_numpy(a).cuda(), screen=True).cpu().numpy()
+    err = np.abs((got.astype(np.longdouble) - ref).astype(np.float64))
+    assert err.max() < bound / 4, (err.max(), a[err.argmax()])
+    sp = h.ll_term(torch.tensor([float("inf"), float("-inf"), float("nan")], dtype=torch.float64).cuda(), screen=True).cpu().numpy()
+    assert sp[0] == 0.0 and np.isinf(sp[1]) and sp[1] > 0 and np.isnan(sp[2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m", [(1024, 96), (2048, 64), (4096, 48), (8192, 40)])
+def test_slice_sampler_with_and_without_the_screen_is_bit_identical(n, m):
+    """The screen only decides what the full-precision sum would decide the same way: with GPIRT_ESS_SCREEN=2 (every trial
+    point in full precision) the chain is the same bit for bit -- rejection counts, f, theta -- in both register kernels
+    (n <= 2048: 8 rows per thread; above: 16) and with the written form of the term (GPIRT_LL_EXACT=1) as the referee too."""
+    import torch
+    from gpirt_amd.ops import Handle
+    from gpirt_amd.sampler import Sampler
+    from gpirt_amd.synthetic import make_responses
+    y, th0 = make_responses(n, m, seed=41)                   # (5% missing responses: skipped by both passes alike)
+    h = Handle()
+    for exact in (0, 1):
+        outs = []
+        for screen in (1, 2):
+            with h.config("GPIRT_LL_EXACT", exact), h.config("GPIRT_ESS_SCREEN", screen):
+                s = Sampler(h, y, th0, rng="item", seed=78, theta_stabilise=True, fstar_fused=True, kstar_rank=64)
+                s.init()
+                for _ in range(3):
+                    s.step()
+                outs.append((s.get("f"), s.get("ess_k"), s.get("theta")))
+                s.close()
+        (f0, k0, t0), (f1, k1, t1) = outs
+        assert k0.sum() > m                                  # (there were rejections to decide)
+        assert np.array_equal(k0, k1)
+        assert np.array_equal(f0, f1)
+        assert np.array_equal(t0, t1)
