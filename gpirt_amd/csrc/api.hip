@@ -28,6 +28,7 @@ const Config& env_config()
         d.trsm_inv = env_value("GPIRT_TRSM_INV", d.trsm_inv);
         d.ll_exact = env_value("GPIRT_LL_EXACT", d.ll_exact);
         d.ess_screen = env_value("GPIRT_ESS_SCREEN", d.ess_screen);
+        d.theta_fixed = env_value("GPIRT_THETA_FIXED", d.theta_fixed);
         d.bordered = env_value("GPIRT_BORDERED", d.bordered);
         d.early_inv = env_value("GPIRT_EARLY_INV", d.early_inv);
         d.prep_early = env_value("GPIRT_PREP_EARLY", d.prep_early);
@@ -282,7 +283,7 @@ static int* config_slot(gpirt_handle_t h, const char* name, bool* read_only)
         { "GPIRT_NBO", &h->cfg.nbo, true }, { "GPIRT_NBP", &h->cfg.nbp, true },
         { "GPIRT_LOOKAHEAD", &h->cfg.lookahead, false }, { "GPIRT_PANEL", &h->cfg.panel, false },
         { "GPIRT_DEFER", &h->cfg.defer, false }, { "GPIRT_TRSM_INV", &h->cfg.trsm_inv, false },
-        { "GPIRT_LL_EXACT", &h->cfg.ll_exact, false }, { "GPIRT_ESS_SCREEN", &h->cfg.ess_screen, false }, { "GPIRT_BORDERED", &h->cfg.bordered, false },
+        { "GPIRT_LL_EXACT", &h->cfg.ll_exact, false }, { "GPIRT_ESS_SCREEN", &h->cfg.ess_screen, false }, { "GPIRT_THETA_FIXED", &h->cfg.theta_fixed, false }, { "GPIRT_BORDERED", &h->cfg.bordered, false },
         { "GPIRT_EARLY_INV", &h->cfg.early_inv, false }, { "GPIRT_PREP_EARLY", &h->cfg.prep_early, false },
     };
     for (auto& e : tab)
@@ -636,28 +637,66 @@ int gpirt_draw_fstar(gpirt_handle_t h, const double* d_f, const double* d_theta,
     return 0;
 }
 
+// the log-posterior (N x n, without the prior) of draw_theta in the handle's workspace: src/draw-theta.cpp:15-19
+static int theta_logpost(gpirt_handle_t h, const double* d_y, const double* d_fstar, int64_t n, int64_t m, double** lp_out,
+                         const int** overflow_out)
+{
+    const int64_t N = GPIRT_NGRID;
+    // workspace: Ypm (n x 2m) | Gpm (N x 2m, padded) | logpost (N x n) | byte indicators, digit planes, scales (theta_fixed.hip)
+    const int64_t Np = (N + 127) / 128 * 128;     // rows of Gpm incl. padding to whole 128-row tiles
+    const TfDims tfd = tf_dims(n, m, N);
+    const size_t lp_doubles = ((size_t)N * n + 17) / 2 * 2;
+    const size_t fixed_doubles = tf_y8_bytes(tfd) / 8 + tf_gq_bytes(tfd) / 8 + tf_aux_bytes(tfd) / 8 + 8;
+    const size_t need = (size_t)n * 2 * m + (size_t)Np * 2 * m + lp_doubles + fixed_doubles;
+    GP_TRY(ensure_work(h, need * sizeof(double)));
+    double* Ypm = h->d_work;
+    double* Gpm = Ypm + (size_t)n * 2 * m;
+    double* lp = Gpm + (size_t)Np * 2 * m;
+    double* y8 = lp + lp_doubles;                  // (an even number of doubles from the base: 16-byte aligned)
+    double* gq = y8 + tf_y8_bytes(tfd) / 8;
+    double* aux = gq + tf_gq_bytes(tfd) / 8;
+    GP_HIP(hipMemsetAsync(Gpm, 0, sizeof(double) * (size_t)Np * 2 * m, h->stream));
+    GP_TRY(launch_indicators(h->stream, d_y, n, m, Ypm));
+    const int* only_if = nullptr;                  // (the product: sampler.hip do_theta_partial)
+    if (h->cfg.theta_fixed == 1) {
+        GP_TRY(launch_tf_indicators(h->stream, d_y, n, n, m, tfd, y8));
+        GP_TRY(launch_theta_fixed(h->stream, d_fstar, N, n, m, tfd, y8, gq, aux, lp, N));
+        only_if = tf_overflow(aux, tfd);
+    }
+    GP_TRY(launch_loglik_terms(h->stream, d_fstar, N, m, Gpm, Np, only_if));
+    GP_TRY(launch_gemm(h, h->stream, false, true, TRI_NONE, N, n, 2 * m, 1.0, Gpm, Np, Ypm, n, 0.0, lp, N, Np, only_if));
+    *lp_out = lp;
+    if (overflow_out) *overflow_out = only_if;
+    return 0;
+}
+
 int gpirt_draw_theta(gpirt_handle_t h, const double* d_y, const double* d_fstar, int64_t n,
                      int64_t m, uint64_t seed, uint32_t iter, int stabilise, double* d_theta_out,
                      int* d_degenerate)
 {
     GP_ARG(h && d_y && d_fstar && d_theta_out && n >= 0 && m >= 0);
-    const int64_t N = GPIRT_NGRID;
-    // workspace: Ypm (n x 2m) | Gpm (N x 2m, padded) | logpost (N x n)
-    const int64_t Np = (N + 127) / 128 * 128;     // rows of Gpm incl. padding to whole 128-row tiles
-    const size_t need = (size_t)n * 2 * m + (size_t)Np * 2 * m + 2 + (size_t)N * n + 16;
-    GP_TRY(ensure_work(h, need * sizeof(double)));
-    double* Ypm = h->d_work;
-    double* Gpm = Ypm + (size_t)n * 2 * m;
-    double* lp = Gpm + (size_t)Np * 2 * m;
-    GP_HIP(hipMemsetAsync(Gpm, 0, sizeof(double) * (size_t)Np * 2 * m, h->stream));
-    GP_TRY(launch_indicators(h->stream, d_y, n, m, Ypm));
-    GP_TRY(launch_loglik_terms(h->stream, d_fstar, N, m, Gpm, Np));
-    GP_TRY(launch_gemm(h, h->stream, false, true, TRI_NONE, N, n, 2 * m, 1.0, Gpm, Np, Ypm, n, 0.0, lp, N, Np));
+    double* lp = nullptr;
+    GP_TRY(theta_logpost(h, d_y, d_fstar, n, m, &lp, nullptr));
     if (d_degenerate) GP_HIP(hipMemsetAsync(d_degenerate, 0, sizeof(int), h->stream));
     ThetaArgs a{};
-    a.logpost = lp; a.N = N; a.n = n; a.stabilise = stabilise; a.seed = seed; a.iter = iter;
+    a.logpost = lp; a.N = GPIRT_NGRID; a.n = n; a.stabilise = stabilise; a.seed = seed; a.iter = iter;
     a.U = nullptr; a.theta_out = d_theta_out; a.degenerate = d_degenerate; a.err = nullptr;
     return launch_theta_sample(h->stream, a);
+}
+
+int gpirt_debug_theta_logpost(gpirt_handle_t h, const double* d_y, const double* d_fstar, int64_t n, int64_t m,
+                              double* d_logpost_out, int* fell_back)
+{
+    GP_ARG(h && d_y && d_fstar && d_logpost_out && n >= 0 && m >= 0);
+    double* lp = nullptr;
+    const int* ovf = nullptr;
+    GP_TRY(theta_logpost(h, d_y, d_fstar, n, m, &lp, &ovf));
+    GP_HIP(hipMemcpyAsync(d_logpost_out, lp, sizeof(double) * (size_t)GPIRT_NGRID * n, hipMemcpyDeviceToDevice, h->stream));
+    int flag = 0;
+    if (ovf) GP_HIP(hipMemcpyAsync(&flag, ovf, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    GP_HIP(hipStreamSynchronize(h->stream));
+    if (fell_back) *fell_back = flag;
+    return 0;
 }
 
 int gpirt_draw_beta(gpirt_handle_t h, double* d_beta, const double* d_theta, const double* d_y,

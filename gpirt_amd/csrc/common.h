@@ -70,6 +70,7 @@ struct Config {
                                   //   right-looking order, 0 = by size (3 up to n = 14336)
     int  trsm_inv = 1;            // GPIRT_TRSM_INV: 2 = every trsm leaf is a substitution (parity attribution)
     int  ll_exact = 0;            // GPIRT_LL_EXACT: 1 = the slice kernel evaluates log(1 + exp(-a)) as written
+    int  theta_fixed = 1;         // GPIRT_THETA_FIXED: 2 = draw_theta's log-posterior product as an fp64 GEMM (theta_fixed.hip)
     int  ess_screen = 1;          // GPIRT_ESS_SCREEN: 2 = every trial point of the slice kernel is evaluated in full precision
     int  bordered = 1;            // GPIRT_BORDERED: 2 = draw_fstar solves for L^-1 K(theta, c) / L^-1 k* explicitly
     int  early_inv = 1;           // GPIRT_EARLY_INV: 2 = no side work beside the factorisation's last outer panel

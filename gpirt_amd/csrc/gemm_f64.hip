@@ -57,6 +57,7 @@ struct GemmParams {
     int ksplit;           // > 0: blockIdx.y selects the K range [y * ksplit, (y + 1) * ksplit) of ONE product (split-K)
     // fused epilogue (FUSE kernels only): work-group 0 factors this 64 x 64 block after its tile
     double* fz_A; int64_t fz_lda; int fz_nb; int fz_k0; int* fz_info;
+    const int* run_if = nullptr;   // when set: the launch does nothing unless *run_if != 0 (a fallback product kept behind a device-side flag)
 };
 
 template <bool KCONTIG, int T>
@@ -476,6 +477,7 @@ template <bool TA, bool TB, int T, int PAD = 0, bool FUSE = false>
 __global__ __launch_bounds__(256, (T == 64 ? 3 : 2)) void gemm_f64_kernel(GemmParams p)
 {
     __shared__ __attribute__((aligned(16))) double smem[4 * Cfg<T>::TILE + PAD];
+    if (p.run_if != nullptr && *p.run_if == 0) return;
     p.A += (int64_t)blockIdx.y * p.sA;
     p.B += (int64_t)blockIdx.y * p.sB;
     p.C += (int64_t)blockIdx.y * p.sC;
@@ -764,10 +766,12 @@ static int t128_min_or_default() { return T128_MIN; }
 
 int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri, int64_t M,
                 int64_t N, int64_t K, double alpha, const double* A, int64_t lda, const double* B,
-                int64_t ldb, double beta, double* C, int64_t ldc, int64_t Mread)
+                int64_t ldb, double beta, double* C, int64_t ldc, int64_t Mread, const int* run_if)
 {
     if (M <= 0 || N <= 0) return 0;
+    if (run_if && tri != TRI_NONE) { set_error("a conditional product has to be a plain one"); return GPIRT_E_ARG; }
     GemmParams p;
+    p.run_if = run_if;
     p.A = A; p.B = B; p.C = C;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.M = (int)M; p.N = (int)N; p.K = (int)K;
@@ -833,7 +837,8 @@ int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri,
     // K-step against 0.43 us of MFMA), so the K range is cut into `split` parts computed side by side and added
     // in a fixed order .  Main stream only: the parts share one workspace.
     {
-        const int split = gemm_split_count(h, stream, tri, M, N, K);
+        // (a conditional product stays one launch of the kernel that reads its flag)
+        const int split = run_if ? 0 : gemm_split_count(h, stream, tri, M, N, K);
         if (split >= 2) {
             const size_t need = (size_t)split * (size_t)M * (size_t)N * sizeof(double);
             if (h->splitk_bytes < need) {

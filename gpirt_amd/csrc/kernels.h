@@ -14,7 +14,8 @@ int launch_gemm_update_potf2(hipStream_t stream, int64_t M, int64_t N, int64_t K
 // gemm_f64.hip
 int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri, int64_t M,
                 int64_t N, int64_t K, double alpha, const double* A, int64_t lda, const double* B,
-                int64_t ldb, double beta, double* C, int64_t ldc, int64_t Mread = 0);
+                int64_t ldb, double beta, double* C, int64_t ldc, int64_t Mread = 0, const int* run_if = nullptr);
+// run_if (plain products only): a device flag; the launch does nothing unless it is non-zero when the kernel starts.
 // Mread (> M, !ta only): rows of A beyond M that exist in memory (padding up to a tile multiple) -- lets the
 // last block row take the branch-free main loop; whatever those rows hold only reaches masked rows of C.
 
@@ -164,7 +165,18 @@ int launch_fstar_epilogue(hipStream_t stream, const FstarEpiArgs& a);
 
 // theta.hip
 int launch_indicators(hipStream_t stream, const double* y, int64_t n, int64_t m, double* Ypm /* n x 2m */);
-int launch_loglik_terms(hipStream_t stream, const double* fstar, int64_t N, int64_t m, double* Gpm /* ldg x 2m */, int64_t ldg);
+int launch_loglik_terms(hipStream_t stream, const double* fstar, int64_t N, int64_t m, double* Gpm /* ldg x 2m */, int64_t ldg,
+                        const int* run_if = nullptr);
+// theta_fixed.hip: the same product in exact fixed point on the int8 matrix cores
+struct TfDims { int64_t mp, ksteps, iblocks, gblocks; };
+TfDims tf_dims(int64_t n, int64_t m, int64_t N);
+size_t tf_y8_bytes(const TfDims& d);
+size_t tf_gq_bytes(const TfDims& d);
+size_t tf_aux_bytes(const TfDims& d);
+int* tf_overflow(void* aux, const TfDims& d);
+int launch_tf_indicators(hipStream_t stream, const double* y, int64_t n, int64_t ldy, int64_t m, const TfDims& d, void* Y8);
+int launch_theta_fixed(hipStream_t stream, const double* fstar, int64_t N, int64_t n, int64_t m, const TfDims& d,
+                       const void* Y8, void* Gq, void* aux, double* logpost, int64_t ldlp);
 struct ThetaArgs {
     const double* logpost;   // N x n (column i = respondent i0 + i), WITHOUT the prior
     int64_t N, n;

@@ -77,6 +77,9 @@ struct gpirt_sampler_s {
     // block of respondents with ALL items
     int64_t blk_i0 = 0, blk_n = 0, blk_m = 0;
     double *Ypm_blk = nullptr, *Gpm_full = nullptr, *logpost_blk = nullptr, *fstar_full = nullptr, *theta_stage = nullptr;
+    // the log-posterior product in fixed point (theta_fixed.hip): byte indicators (built once), digit planes of G, row scales
+    TfDims tfd{}, tfd_blk{};
+    double *tf_y8 = nullptr, *tf_gq = nullptr, *tf_aux = nullptr, *tf_y8_blk = nullptr, *tf_gq_blk = nullptr, *tf_aux_blk = nullptr;
     int *ess_k = nullptr, *flags = nullptr;    // flags[0] = err, flags[1] = degenerate theta count
     int *fstar_off = nullptr;                  // R-stream replay: consumption offsets of draw_fstar
     int *h_flags = nullptr;                    // pinned
@@ -569,9 +572,16 @@ int do_theta_partial(gpirt_sampler_s* s)
     hipStream_t st = s->h->stream;
     const int64_t n = s->n, m = s->m, N = s->N;
     const int64_t Np = (N + 127) / 128 * 128;     // Gpm is padded to whole 128-row tiles (zero rows)
-    GP_TRY(launch_loglik_terms(st, s->fstar, N, m, s->Gpm, Np));
-    // logpost (N x n) = G+ Y+^T + G- Y-^T   (draw-theta.cpp:15-19 summed over this rank's items)
-    return launch_gemm(s->h, st, false, true, TRI_NONE, N, n, 2 * m, 1.0, s->Gpm, Np, s->Ypm, n, 0.0, s->logpost, N, Np);
+    // logpost (N x n) = G+ Y+^T + G- Y-^T   (draw-theta.cpp:15-19 summed over this rank's items): in exact fixed point on the
+    // int8 matrix cores (theta_fixed.hip); the fp64 product runs behind it only under the device flag that says a row of G
+    // could not be scaled (|f*| beyond exp()'s range, non-finite), or instead of it with GPIRT_THETA_FIXED=2
+    const int* only_if = nullptr;
+    if (s->h->cfg.theta_fixed == 1) {
+        GP_TRY(launch_theta_fixed(st, s->fstar, N, n, m, s->tfd, s->tf_y8, s->tf_gq, s->tf_aux, s->logpost, N));
+        only_if = tf_overflow(s->tf_aux, s->tfd);
+    }
+    GP_TRY(launch_loglik_terms(st, s->fstar, N, m, s->Gpm, Np, only_if));
+    return launch_gemm(s->h, st, false, true, TRI_NONE, N, n, 2 * m, 1.0, s->Gpm, Np, s->Ypm, n, 0.0, s->logpost, N, Np, only_if);
 }
 
 int do_theta_finish(gpirt_sampler_s* s)
@@ -598,9 +608,14 @@ int do_theta_block(gpirt_sampler_s* s)
     const int64_t Np = (N + 127) / 128 * 128;
     GP_HIP(hipMemsetAsync(s->theta_stage, 0, sizeof(double) * (size_t)s->n, st));
     if (nb == 0) return 0;
-    GP_TRY(launch_loglik_terms(st, s->fstar_full, N, mt, s->Gpm_full, Np));
+    const int* only_if = nullptr;
+    if (s->h->cfg.theta_fixed == 1) {                       // (as do_theta_partial; exact sums: the same bits as one GPU's product)
+        GP_TRY(launch_theta_fixed(st, s->fstar_full, N, nb, mt, s->tfd_blk, s->tf_y8_blk, s->tf_gq_blk, s->tf_aux_blk, s->logpost_blk, N));
+        only_if = tf_overflow(s->tf_aux_blk, s->tfd_blk);
+    }
+    GP_TRY(launch_loglik_terms(st, s->fstar_full, N, mt, s->Gpm_full, Np, only_if));
     GP_TRY(launch_gemm(s->h, st, false, true, TRI_NONE, N, nb, 2 * mt, 1.0, s->Gpm_full, Np, s->Ypm_blk, nb, 0.0,
-                       s->logpost_blk, N, Np));
+                       s->logpost_blk, N, Np, only_if));
     ThetaArgs a{};
     a.logpost = s->logpost_blk; a.N = N; a.n = nb; a.i0 = s->blk_i0; a.stabilise = s->opt.theta_stabilise;
     a.seed = s->opt.seed; a.iter = (uint32_t)(s->iter + 1);
@@ -817,6 +832,8 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
     int rc = 0;
 #define GP_A(p, cnt) do { rc = dalloc(s, &(p), (size_t)(cnt)); if (rc) { gpirt_sampler_destroy(s); return rc; } } while (0)
     GP_A(s->y, n * m);       GP_A(s->Ypm, n * 2 * m);  GP_A(s->theta, n);       GP_A(s->theta_new, n);
+    s->tfd = tf_dims(n, m, N);
+    GP_A(s->tf_y8, tf_y8_bytes(s->tfd) / 8 + 2); GP_A(s->tf_gq, tf_gq_bytes(s->tfd) / 8 + 2); GP_A(s->tf_aux, tf_aux_bytes(s->tfd) / 8 + 2);
     GP_A(s->f, n * m);       GP_A(s->Z, n * m);        GP_A(s->NU, n * (m > 1 + TRMV_SPLIT ? m : 1 + TRMV_SPLIT));   GP_A(s->beta, 2 * m);   // (NU: >= 1 + TRMV_SPLIT columns, launch_trmv_lower's parts)
     s->kr = s->opt.kstar_rank;
     if (s->kr != 0 && (!s->opt.fstar_fused || s->kr < 16 || s->kr > 128 || (s->kr % 16) != 0)) {
@@ -955,6 +972,7 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
     hipMemsetAsync(s->flags, 0, 4 * sizeof(int), st);
     hipMemsetAsync(s->ess_k, 0, sizeof(int) * (size_t)m, st);
     launch_indicators(st, s->y, n, m, s->Ypm);
+    launch_tf_indicators(st, s->y, n, n, m, s->tfd, s->tf_y8);
     if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) {
         set_error("sampler upload failed"); gpirt_sampler_destroy(s); return GPIRT_E_HIP;
     }
@@ -1133,12 +1151,16 @@ int gpirt_sampler_set_theta_block(gpirt_sampler_t s, const double* y_block, int6
     GP_B(s->Ypm_blk, n_block * 2 * m_total + 2); GP_B(s->Gpm_full, Np * 2 * m_total + 2);
     GP_B(s->logpost_blk, N * n_block + 2);       GP_B(s->fstar_full, N * m_total + 2);
     GP_B(s->theta_stage, s->n + 1);              GP_B(yb, n_block * m_total + 1);
+    s->tfd_blk = tf_dims(n_block, m_total, N);
+    GP_B(s->tf_y8_blk, tf_y8_bytes(s->tfd_blk) / 8 + 2); GP_B(s->tf_gq_blk, tf_gq_bytes(s->tfd_blk) / 8 + 2);
+    GP_B(s->tf_aux_blk, tf_aux_bytes(s->tfd_blk) / 8 + 2);
 #undef GP_B
     hipStream_t st = s->h->stream;
     GP_HIP(hipMemsetAsync(s->Gpm_full, 0, sizeof(double) * (size_t)(Np * 2 * m_total + 2), st));   // padding rows stay zero
     if (n_block > 0) {
         GP_HIP(hipMemcpyAsync(yb, y_block, sizeof(double) * (size_t)(n_block * m_total), hipMemcpyHostToDevice, st));
         GP_TRY(launch_indicators(st, yb, n_block, m_total, s->Ypm_blk));
+        GP_TRY(launch_tf_indicators(st, yb, n_block, n_block, m_total, s->tfd_blk, s->tf_y8_blk));
     }
     GP_HIP(hipStreamSynchronize(st));
     s->blk_i0 = i0; s->blk_n = n_block; s->blk_m = m_total;

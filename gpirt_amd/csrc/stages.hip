@@ -120,8 +120,9 @@ __global__ void indicators_kernel(const double* __restrict__ y, int64_t total, d
 // G+[k,j] = -log(1+exp(-f*_kj))  (y = +1),  G-[k,j] = -log(1+exp(+f*_kj))  (y = -1)
 // Gpm has leading dimension ldg >= N (rows N .. ldg-1 are padding the GEMM may read but never uses)
 __global__ void loglik_terms_kernel(const double* __restrict__ fstar, int64_t N, int64_t m, double* __restrict__ Gpm,
-                                    int64_t ldg)
+                                    int64_t ldg, const int* __restrict__ run_if)
 {
+    if (run_if != nullptr && *run_if == 0) return;
     const int64_t total = N * m;
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total;
          g += (int64_t)gridDim.x * blockDim.x) {
@@ -360,9 +361,9 @@ int launch_indicators(hipStream_t stream, const double* y, int64_t n, int64_t m,
     return 0;
 }
 
-int launch_loglik_terms(hipStream_t stream, const double* fstar, int64_t N, int64_t m, double* Gpm, int64_t ldg)
+int launch_loglik_terms(hipStream_t stream, const double* fstar, int64_t N, int64_t m, double* Gpm, int64_t ldg, const int* run_if)
 {
-    hipLaunchKernelGGL(loglik_terms_kernel, dim3(grid_for(N * m)), dim3(256), 0, stream, fstar, N, m, Gpm, ldg);
+    hipLaunchKernelGGL(loglik_terms_kernel, dim3(grid_for(N * m)), dim3(256), 0, stream, fstar, N, m, Gpm, ldg, run_if);
     GP_HIP(hipGetLastError());
     return 0;
 }

@@ -1,0 +1,324 @@
+// theta_fixed.hip -- draw_theta's log-posterior product (src/draw-theta.cpp:15-19) in EXACT fixed point on the int8 matrix cores.
+//
+//   logpost[g, i] = sum_j [y_ij = +1] G+[g, j] + [y_ij = -1] G-[g, j],   G+- = -log(1 + exp(-+ f*[g, j]))          (N x n, N = 1001)
+//
+// is a product with a 0/1 operand: the only rounding an fp64 GEMM commits in it is in the ADDITIONS (2m of them per entry,
+// each rounded at the size of the running sum).  Fixed point has none: every row g of G is scaled by a power of two
+// 2^(54 - e_g) (2^e_g above everything the row holds) and rounded ONCE to a 54-bit integer, that integer is cut into seven
+// balanced base-256 digits (signed bytes), and
+//         sum_j Y[i, j] q[g, j] = sum_s 256^s * (sum_j Y[i, j] d_s[g, j])
+// is seven int8 products with int32 accumulators, exact (|d| <= 128, <= 2^11 non-zero terms per sum: 2^18), recombined in
+// two int64 halves and one fp64 addition.  What comes out is the correctly rounded sum of the once-rounded terms: the error
+// per entry is <= m 2^(e_g - 55) in the worst case (3e-13 for m = 1024 and a row maximum below 16; ~1e-14 typical) against
+// <= m^2 u max|G| for the fp64 chain -- tests/test_gpu_theta_fixed.py measures both against long double and holds the
+// fixed-point form to the SMALLER error.  It is also independent of the order of the items, so a respondent block of a
+// sharded run (do_theta_block) is bit-identical to the single-GPU product by construction.
+//
+// v_mfma_i32_32x32x32_i8 runs at 32x the fp64 MFMA's rate per clock, so seven digit planes cost less than a quarter of the
+// one fp64 product (0.54 ms at 8192 x 1024 -- already 91% of the fp64 MFMA peak, nothing left to tune there).
+//
+// When a row cannot be scaled -- |f*| beyond exp()'s range (the formula as written then yields -inf, stages.hip
+// loglik_terms_kernel) or a non-finite f* -- the quantiser raises a device-side flag: the int8 kernel returns at once and the
+// fp64 product, launched behind it under that flag, runs instead (and only then): same results as before this file existed.
+//
+// Layouts (K = the 2m indicator columns, padded: plus part [0, mp), minus part [mp, 2 mp), mp = m rounded up to 16, then zeros
+// up to a whole number of chunks).  The MFMA sums over k, exactly, so the order of k inside an instruction is free; both
+// operands are stored in "fragment order", the 1 KiB one wave instruction consumes:
+//     Y8 [i / 32][k / 32][lane = (i % 32) + 32 ((k % 32) / 16)][k % 16]           bytes 0 / 1      (built once: y is data)
+//     Gq [digit s][g / 32][k / 32][lane = (g % 32) + 32 ((k % 32) / 16)][k % 16]   signed bytes     (every iteration)
+// so global -> LDS is a lane-linear LDS-DMA (global_load_lds_dwordx4, no VGPR staging) and LDS -> operand one conflict-free
+// ds_read_b128.  A work-group owns 128 respondents x 64 grid points: four waves as 2 x 2, each 64 x 32 with all seven digit
+// planes = 14 accumulator tiles (224 registers, one work-group per CU); per k-step a wave reads 2 + 7 operands for 14 MFMAs.
+// Work-groups are dealt so that an XCD keeps two grid tiles (its 1.8 MB of Gq stay in its L2) and streams the respondents.
+#include "kernels.h"
+
+namespace gpirt {
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int TF_BITS = 54;          // bits of a row's fixed-point terms (the top digit then stays below 65 + a carry)
+constexpr int TF_DIGITS = 7;
+constexpr int TF_KS = 4;             // k-steps (of 32) per LDS stage
+constexpr int TF_STAGE = (4 + 2 * TF_DIGITS) * TF_KS * 1024;            // 4 respondent blocks + 7 x 2 grid blocks, bytes
+static_assert(TF_KS % 2 == 0, "the pieces of a stage are dealt to four waves in whole rounds");
+static_assert(2 * TF_STAGE <= 160 * 1024, "two stages have to fit the LDS");
+
+__device__ __forceinline__ uint32_t pack4(int b0, int b1, int b2, int b3)
+{
+    return (uint32_t)(b0 & 255) | ((uint32_t)(b1 & 255) << 8) | ((uint32_t)(b2 & 255) << 16) | ((uint32_t)(b3 & 255) << 24);
+}
+
+// the item and the sign an indicator column k stands for; false: padding
+__device__ __forceinline__ bool tf_column(int64_t k, int64_t m, int64_t mp, int64_t* j, double* sign)
+{
+    if (k < mp) { *j = k; *sign = 1.0; return k < m; }
+    if (k < 2 * mp) { *j = k - mp; *sign = -1.0; return k - mp < m; }
+    return false;
+}
+
+// Y8: one thread per (respondent, half k-step) = 16 bytes
+__global__ __launch_bounds__(256) void tf_y8_kernel(const double* __restrict__ y, int64_t n, int64_t ldy, int64_t m, TfDims d,
+                                                    uint4* __restrict__ Y8)
+{
+    const int64_t total = d.iblocks * d.ksteps * 64;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int lane = (int)(t & 63);
+        const int64_t ks = (t >> 6) % d.ksteps, ib = (t >> 6) / d.ksteps;
+        const int64_t i = ib * 32 + (lane & 31);
+        int b[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            int64_t j; double sign;
+            const bool real = tf_column(ks * 32 + 16 * (lane >> 5) + q, m, d.mp, &j, &sign);
+            b[q] = (real && i < n && y[i + j * ldy] == sign) ? 1 : 0;                  // (NaN compares false: skipped, :16)
+        }
+        Y8[t] = make_uint4(pack4(b[0], b[1], b[2], b[3]), pack4(b[4], b[5], b[6], b[7]), pack4(b[8], b[9], b[10], b[11]),
+                           pack4(b[12], b[13], b[14], b[15]));
+    }
+}
+
+// max_j |f*[g, j]| as the bits of a non-negative double (they order like the values; NaN sorts above everything)
+__global__ __launch_bounds__(256) void tf_rowmax_kernel(const double* __restrict__ fstar, int64_t N, int64_t m,
+                                                        unsigned long long* __restrict__ amax)
+{
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= N) return;
+    const int64_t j0 = (int64_t)blockIdx.y * 16, j1 = (j0 + 16 < m) ? j0 + 16 : m;
+    unsigned long long best = 0;
+    for (int64_t j = j0; j < j1; ++j) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(fabs(fstar[g + j * N]));
+        best = bits > best ? bits : best;
+    }
+    atomicMax(amax + g, best);
+}
+
+// one thread per (grid point, half k-step): 16 terms -> 7 x 16 digit bytes
+__global__ __launch_bounds__(256) void tf_quant_kernel(const double* __restrict__ fstar, int64_t N, int64_t m, TfDims d,
+                                                       const unsigned long long* __restrict__ amax, uint4* __restrict__ Gq,
+                                                       double* __restrict__ scale, int* __restrict__ ovf)
+{
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t kg = blockIdx.y;                          // half k-step
+    if (g >= d.gblocks * 32) return;
+    const int64_t ks = kg >> 1;
+    const int lane = (int)(g & 31) + 32 * (int)(kg & 1);
+    const int64_t piece = ((g >> 5) * d.ksteps + ks) * 64 + lane;           // within one digit plane
+    const int64_t plane = d.gblocks * d.ksteps * 64;
+    int64_t q[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) q[t] = 0;
+    if (g < N) {
+        const double fmax = __longlong_as_double((long long)amax[g]);
+        // log(1 + exp(x)) <= x + log 2: 2^e is above every term of the row.  Beyond exp()'s range the formula as written
+        // overflows to -inf (and NaN / inf are not numbers to scale): leave the product to the fp64 form
+        const bool ok = fmax <= 709.0;
+        if (!ok) { if (kg == 0) atomicOr(ovf, 1); }
+        const int e = ok ? ilogb(fmax + 0.6931471805599453) + 1 : 0;
+        if (kg == 0) scale[g] = ok ? ldexp(1.0, e - TF_BITS) : 0.0;
+        if (ok) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                int64_t j; double sign;
+                if (tf_column(kg * 16 + t, m, d.mp, &j, &sign)) {
+                    const double term = ll_term(sign * fstar[g + j * N]);              // = -G+ / -G- (stages.hip), >= 0
+                    q[t] = (int64_t)rint(ldexp(term, TF_BITS - e));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < TF_DIGITS; ++s) {
+        int b[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int dg = (s + 1 < TF_DIGITS) ? (int)(int8_t)(q[t] & 255) : (int)q[t];    // balanced digit; the last takes the rest
+            b[t] = dg;
+            q[t] = (q[t] - dg) >> 8;
+        }
+        Gq[(int64_t)s * plane + piece] = make_uint4(pack4(b[0], b[1], b[2], b[3]), pack4(b[4], b[5], b[6], b[7]),
+                                                    pack4(b[8], b[9], b[10], b[11]), pack4(b[12], b[13], b[14], b[15]));
+    }
+}
+
+struct TfMfmaArgs {
+    const unsigned char* Y8; const unsigned char* Gq; const double* scale; const int* ovf;
+    double* logpost; int64_t ldlp; int64_t n, N; int64_t ksteps, gblocks; int itiles;
+};
+
+__global__ __launch_bounds__(256, 1) void tf_mfma_kernel(TfMfmaArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char tf_lds[];
+    if (*a.ovf) return;
+    constexpr int KS = TF_KS;
+    // an XCD (work-group id mod 8) keeps grid tiles 2 x, 2 x + 1 and walks the respondent tiles
+    const int id = (int)blockIdx.x, xcd = id & 7, local = id >> 3;
+    const int gt = 2 * xcd + (local & 1), it = local >> 1;
+    const int lane = (int)(threadIdx.x & 63);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wi = wave & 1, wg = wave >> 1;
+    const int64_t ksteps = a.ksteps;
+    const int nchunks = (int)(ksteps / KS);
+
+    // the pieces of a stage (1 KiB each): A piece pa = ibl * KS + ksl at pa KiB, B piece pb = (s * 2 + gbl) * KS + ksl at (4 KS + pb) KiB;
+    // wave w issues A pieces 4 q + w (q < KS) and B pieces 4 q + w (q < 3.5 KS)
+    // (wave-uniform 64-bit bases + one per-lane 32-bit offset: the addresses stay in scalar registers)
+    int64_t offA[KS], offB[(14 * KS) / 4];
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+        const int pa = 4 * q + wave, ibl = pa / KS, ksl = pa % KS;
+        offA[q] = ((((int64_t)(it * 4 + ibl)) * ksteps + ksl) * 64) * 16;
+    }
+#pragma unroll
+    for (int q = 0; q < (14 * KS) / 4; ++q) {
+        const int pb = 4 * q + wave, ksl = pb % KS, sg = pb / KS, s = sg >> 1, gbl = sg & 1;
+        offB[q] = ((((int64_t)s * a.gblocks + (gt * 2 + gbl)) * ksteps + ksl) * 64) * 16;
+    }
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+    auto issue = [&](int c, int buf) {
+        unsigned char* base = tf_lds + buf * TF_STAGE;
+        const int64_t adv = (int64_t)c * KS * 1024;
+#pragma unroll
+        for (int q = 0; q < KS; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) uint32_t*)(a.Y8 + (offA[q] + adv) + lane16),
+                                             (__attribute__((address_space(3))) uint32_t*)(base + (4 * q + wave) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int q = 0; q < (14 * KS) / 4; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) uint32_t*)(a.Gq + (offB[q] + adv) + lane16),
+                                             (__attribute__((address_space(3))) uint32_t*)(base + (4 * KS + 4 * q + wave) * 1024), 16, 0, 0);
+    };
+
+    v16i acc[2][TF_DIGITS];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int s = 0; s < TF_DIGITS; ++s)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[r][s][v] = 0;
+
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        if (c + 1 < nchunks) issue(c + 1, (c + 1) & 1);
+        const unsigned char* sb = tf_lds + (c & 1) * TF_STAGE + lane * 16;
+        // the operands of k-step ksl + 1 are read while the 14 MFMAs of k-step ksl run (one wave per SIMD: nothing else hides
+        // the LDS latency)
+        v4i fa[2][2], fb[2][TF_DIGITS];
+        auto fetch = [&](int ksl, int slot) {
+            fa[slot][0] = *reinterpret_cast<const v4i*>(sb + ((2 * wi) * KS + ksl) * 1024);
+            fa[slot][1] = *reinterpret_cast<const v4i*>(sb + ((2 * wi + 1) * KS + ksl) * 1024);
+#pragma unroll
+            for (int s = 0; s < TF_DIGITS; ++s)
+                fb[slot][s] = *reinterpret_cast<const v4i*>(sb + (4 * KS + (s * 2 + wg) * KS + ksl) * 1024);
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int ksl = 0; ksl < KS; ++ksl) {
+            if (ksl + 1 < KS) fetch(ksl + 1, (ksl + 1) & 1);
+#pragma unroll
+            for (int s = 0; s < TF_DIGITS; ++s) {
+                acc[0][s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ksl & 1][0], fb[ksl & 1][s], acc[0][s], 0, 0, 0);
+                acc[1][s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ksl & 1][1], fb[ksl & 1][s], acc[1][s], 0, 0, 0);
+            }
+        }
+        // the order the scheduler has to keep (left alone it reads each operand right before its use, into one register set):
+        // the nine reads of k-step 0, then per k-step nine (read of the next k-step, MFMA) pairs and the five MFMAs left
+        __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+#pragma unroll
+        for (int ksl = 0; ksl + 1 < KS; ++ksl) {
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 14, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // register v of lane l: respondent (v & 3) + 8 (v >> 2) + 4 (l >> 5) of the block, grid point l & 31
+    const int64_t g = (int64_t)gt * 64 + wg * 32 + (lane & 31);
+    if (g >= a.N) return;
+    const double sc = a.scale[g];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int64_t i0 = (int64_t)it * 128 + (2 * wi + r) * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int64_t i = i0 + (v & 3) + 8 * (v >> 2);
+            if (i >= a.n) continue;
+            const int64_t hi = (((int64_t)acc[r][6][v] * 256 + acc[r][5][v]) * 256 + acc[r][4][v]) * 256 + acc[r][3][v];
+            const int64_t lo = ((int64_t)acc[r][2][v] * 256 + acc[r][1][v]) * 256 + acc[r][0][v];
+            // |hi| < 2^45, |lo| < 2^36: both exact in fp64; one rounding in the addition, the scale is a power of two
+            a.logpost[g + i * a.ldlp] = -(((double)hi * 16777216.0 + (double)lo) * sc);
+        }
+    }
+}
+
+}  // namespace
+
+TfDims tf_dims(int64_t n, int64_t m, int64_t N)
+{
+    TfDims d;
+    d.mp = (m + 15) / 16 * 16;
+    const int64_t steps = (2 * d.mp + 31) / 32;
+    d.ksteps = (steps + TF_KS - 1) / TF_KS * TF_KS;
+    if (d.ksteps == 0) d.ksteps = TF_KS;
+    d.iblocks = (n + 127) / 128 * 4;
+    d.gblocks = (N + 63) / 64 * 2;
+    return d;
+}
+size_t tf_y8_bytes(const TfDims& d) { return (size_t)d.iblocks * d.ksteps * 1024; }
+size_t tf_gq_bytes(const TfDims& d) { return (size_t)TF_DIGITS * d.gblocks * d.ksteps * 1024; }
+// amax (gblocks * 32 u64) | scale (gblocks * 32 doubles) | ovf (int, padded to 16 bytes)
+size_t tf_aux_bytes(const TfDims& d) { return (size_t)d.gblocks * 32 * 16 + 16; }
+
+int launch_tf_indicators(hipStream_t stream, const double* y, int64_t n, int64_t ldy, int64_t m, const TfDims& d, void* Y8)
+{
+    const int64_t total = d.iblocks * d.ksteps * 64;
+    if (total <= 0) return 0;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(tf_y8_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, y, n, ldy, m, d, reinterpret_cast<uint4*>(Y8));
+    GP_HIP(hipGetLastError());
+    return 0;
+}
+
+// logpost (N x n, leading dimension ldlp) from f* (N x m) and the prepared indicators; *tf_overflow(aux) != 0 afterwards means
+// the product was NOT formed (see the header): the caller's fp64 product, launched under that flag, does it instead
+int launch_theta_fixed(hipStream_t stream, const double* fstar, int64_t N, int64_t n, int64_t m, const TfDims& d,
+                       const void* Y8, void* Gq, void* aux, double* logpost, int64_t ldlp)
+{
+    if (n <= 0 || N <= 0) return 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tf_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TF_STAGE));
+        attr_set = true;
+    }
+    unsigned long long* amax = reinterpret_cast<unsigned long long*>(aux);
+    double* scale = reinterpret_cast<double*>(amax + d.gblocks * 32);
+    int* ovf = tf_overflow(aux, d);
+    GP_HIP(hipMemsetAsync(aux, 0, tf_aux_bytes(d), stream));
+    if (m > 0) {
+        hipLaunchKernelGGL(tf_rowmax_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)((m + 15) / 16)), dim3(256), 0, stream, fstar, N, m, amax);
+        GP_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(tf_quant_kernel, dim3((unsigned)((d.gblocks * 32 + 255) / 256), (unsigned)(d.ksteps * 2)), dim3(256), 0, stream,
+                       fstar, N, m, d, amax, reinterpret_cast<uint4*>(Gq), scale, ovf);
+    GP_HIP(hipGetLastError());
+    TfMfmaArgs a;
+    a.Y8 = reinterpret_cast<const unsigned char*>(Y8); a.Gq = reinterpret_cast<const unsigned char*>(Gq); a.scale = scale; a.ovf = ovf;
+    a.logpost = logpost; a.ldlp = ldlp; a.n = n; a.N = N; a.ksteps = d.ksteps; a.gblocks = d.gblocks; a.itiles = (int)(d.iblocks / 4);
+    if (d.gblocks != 32) { set_error("theta_fixed: the work-group map is laid out for the reference's 1001-point grid"); return GPIRT_E_ARG; }
+    hipLaunchKernelGGL(tf_mfma_kernel, dim3((unsigned)(16 * a.itiles)), dim3(256), 2 * TF_STAGE, stream, a);
+    GP_HIP(hipGetLastError());
+    return 0;
+}
+
+int* tf_overflow(void* aux, const TfDims& d) { return reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(aux) + (size_t)d.gblocks * 32 * 16); }
+
+}  // namespace gpirt

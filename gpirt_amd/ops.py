@@ -286,6 +286,15 @@ class Handle:
         check(self.lib.gpirt_draw_theta(self._h, _p(y), _p(fstar), n, m, seed, it, int(stabilise), _p(out), _p(deg)))
         return out, int(deg.item())
 
+    def theta_logpost(self, y, fstar):
+        """The log-posterior of draw_theta before the prior (NGRID x n): src/draw-theta.cpp:15-19 as the product the sampler
+        forms (csrc/theta_fixed.hip, or the fp64 GEMM under GPIRT_THETA_FIXED=2).  Returns (logpost, fell_back)."""
+        n, m = y.shape
+        out = colmajor(NGRID, n, y.device)
+        fb = C.c_int(0)
+        check(self.lib.gpirt_debug_theta_logpost(self._h, _p(y), _p(fstar), n, m, _p(out), C.byref(fb)))
+        return out, fb.value
+
     def draw_beta(self, beta, theta, y, f, pm, ps, step, seed: int, it: int):
         """draw_beta(): src/draw-beta.cpp:3-41 (item RNG).  In place on beta (2 x m)."""
         n, m = y.shape

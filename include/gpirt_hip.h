@@ -155,6 +155,13 @@ int gpirt_debug_streams_busy(gpirt_handle_t h, int* busy);
  * count = 0 disarms and frees); otherwise copies `count` entries out.  tools/panel_trace_insitu.py. */
 int gpirt_debug_panel_trace(gpirt_handle_t h, int64_t k0, long long* host_out, int64_t count);
 int gpirt_debug_ll_term(gpirt_handle_t h, const double* d_a, int64_t n, double* d_out, int fast);
+/* The log-posterior of draw_theta before the prior (GPIRT_NGRID x n, column i = respondent i): the product
+ * sum_j [y_ij = +-1] -log(1 + exp(-+ f*_gj)) as gpirt_draw_theta and the sampler form it -- in exact fixed point on the int8
+ * matrix cores (csrc/theta_fixed.hip; every term rounded once to 54 bits of its grid row's range, the sums exact), or with
+ * GPIRT_THETA_FIXED=2 as the fp64 GEMM.  *fell_back = 1 when the fixed-point form handed over to the fp64 product on its
+ * own (|f*| > 709 or non-finite somewhere: the formula as written overflows there).  Synchronises the handle's stream. */
+int gpirt_debug_theta_logpost(gpirt_handle_t h, const double* d_y, const double* d_fstar, int64_t n, int64_t m,
+                              double* d_logpost_out, int* fell_back);
 
 /* rmvnorm()'s product `cholS * res` (src/mvnormal.h:10) for all item columns at once:
  * d_out (n x m) = L * Z with L lower triangular; the strict upper triangle of d_L must hold zeros
