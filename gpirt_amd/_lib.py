@@ -82,6 +82,7 @@ SIGNATURES = {
     "gpirt_debug_streams_busy": (_i32, [_vp, C.POINTER(_i32)]),
     "gpirt_debug_ll_term": (_i32, [_vp, _vp, _i64, _vp, _i32]),
     "gpirt_debug_theta_logpost": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
+    "gpirt_debug_theta_clock": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i64]),
     "gpirt_debug_panel_trace": (_i32, [_vp, _i64, _vp, _i64]),
     "gpirt_trmm_lz": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64]),
     "gpirt_trsm_lower": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _i32]),

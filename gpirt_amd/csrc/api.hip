@@ -639,7 +639,7 @@ int gpirt_draw_fstar(gpirt_handle_t h, const double* d_f, const double* d_theta,
 
 // the log-posterior (N x n, without the prior) of draw_theta in the handle's workspace: src/draw-theta.cpp:15-19
 static int theta_logpost(gpirt_handle_t h, const double* d_y, const double* d_fstar, int64_t n, int64_t m, double** lp_out,
-                         const int** overflow_out)
+                         const int** overflow_out, long long** trace_out = nullptr)
 {
     const int64_t N = GPIRT_NGRID;
     // workspace: Ypm (n x 2m) | Gpm (N x 2m, padded) | logpost (N x n) | byte indicators, digit planes, scales (theta_fixed.hip)
@@ -660,8 +660,9 @@ static int theta_logpost(gpirt_handle_t h, const double* d_y, const double* d_fs
     const int* only_if = nullptr;                  // (the product: sampler.hip do_theta_partial)
     if (h->cfg.theta_fixed == 1) {
         GP_TRY(launch_tf_indicators(h->stream, d_y, n, n, m, tfd, y8));
-        GP_TRY(launch_theta_fixed(h->stream, d_fstar, N, n, m, tfd, y8, gq, aux, lp, N));
+        GP_TRY(launch_theta_fixed(h->stream, d_fstar, N, n, m, tfd, y8, gq, aux, lp, N, trace_out != nullptr));
         only_if = tf_overflow(aux, tfd);
+        if (trace_out) *trace_out = tf_trace(aux, tfd);
     }
     GP_TRY(launch_loglik_terms(h->stream, d_fstar, N, m, Gpm, Np, only_if));
     GP_TRY(launch_gemm(h, h->stream, false, true, TRI_NONE, N, n, 2 * m, 1.0, Gpm, Np, Ypm, n, 0.0, lp, N, Np, only_if));
@@ -696,6 +697,20 @@ int gpirt_debug_theta_logpost(gpirt_handle_t h, const double* d_y, const double*
     if (ovf) GP_HIP(hipMemcpyAsync(&flag, ovf, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     GP_HIP(hipStreamSynchronize(h->stream));
     if (fell_back) *fell_back = flag;
+    return 0;
+}
+
+int gpirt_debug_theta_clock(gpirt_handle_t h, const double* d_y, const double* d_fstar, int64_t n, int64_t m,
+                            long long* host_stamps, int64_t count)
+{
+    GP_ARG(h && d_y && d_fstar && host_stamps && n >= 0 && m >= 0 && count >= 0);
+    if (h->cfg.theta_fixed != 1) { set_error("the stamps are those of the fixed-point product"); return GPIRT_E_ARG; }
+    double* lp = nullptr;
+    long long* tr = nullptr;
+    GP_TRY(theta_logpost(h, d_y, d_fstar, n, m, &lp, nullptr, &tr));
+    const int64_t have = (int64_t)tf_trace_wgs() * 6;
+    GP_HIP(hipMemcpyAsync(host_stamps, tr, sizeof(long long) * (size_t)(count < have ? count : have), hipMemcpyDeviceToHost, h->stream));
+    GP_HIP(hipStreamSynchronize(h->stream));
     return 0;
 }
 

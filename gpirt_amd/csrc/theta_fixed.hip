@@ -26,10 +26,11 @@
 // operands are stored in "fragment order", the 1 KiB one wave instruction consumes:
 //     Y8 [i / 32][k / 32][lane = (i % 32) + 32 ((k % 32) / 16)][k % 16]           bytes 0 / 1      (built once: y is data)
 //     Gq [digit s][g / 32][k / 32][lane = (g % 32) + 32 ((k % 32) / 16)][k % 16]   signed bytes     (every iteration)
-// so global -> LDS is a lane-linear LDS-DMA (global_load_lds_dwordx4, no VGPR staging) and LDS -> operand one conflict-free
-// ds_read_b128.  A work-group owns 128 respondents x 64 grid points: four waves as 2 x 2, each 64 x 32 with all seven digit
-// planes = 14 accumulator tiles (224 registers, one work-group per CU); per k-step a wave reads 2 + 7 operands for 14 MFMAs.
-// Work-groups are dealt so that an XCD keeps two grid tiles (its 1.8 MB of Gq stay in its L2) and streams the respondents.
+// so global -> LDS is a lane-linear 16-byte copy and LDS -> operand one conflict-free ds_read_b128.  A work-group owns 256
+// respondents x 32 grid points: wave w the respondent blocks 2 w, 2 w + 1 with all seven digit planes = 14 accumulator tiles
+// (224 registers, one work-group per CU).  Only the digit planes are shared between the waves and go through the LDS (7 reads
+// per k-step and wave for 14 MFMAs); a wave's indicators go from global memory straight into its registers.  Work-groups are
+// dealt so that an XCD keeps four grid blocks (their 1.8 MB of Gq stay in its L2) and streams the respondents.
 #include "kernels.h"
 
 namespace gpirt {
@@ -41,9 +42,10 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 constexpr int TF_BITS = 54;          // bits of a row's fixed-point terms (the top digit then stays below 65 + a carry)
 constexpr int TF_DIGITS = 7;
 constexpr int TF_KS = 4;             // k-steps (of 32) per LDS stage
-constexpr int TF_STAGE = (4 + 2 * TF_DIGITS) * TF_KS * 1024;            // 4 respondent blocks + 7 x 2 grid blocks, bytes
-static_assert(TF_KS % 2 == 0, "the pieces of a stage are dealt to four waves in whole rounds");
-static_assert(2 * TF_STAGE <= 160 * 1024, "two stages have to fit the LDS");
+constexpr int TF_STAGE = TF_DIGITS * TF_KS * 1024;                       // the seven digit planes of one grid block, bytes
+constexpr int TF_TRACE_WGS = 1024;   // work-groups that leave stamps in a traced launch
+static_assert((TF_DIGITS * TF_KS) % 4 == 0 && TF_KS % 2 == 0, "the pieces of a stage are dealt to four waves in whole rounds");
+static_assert(2 * TF_STAGE <= 64 * 1024, "two stages in the static LDS allowance");
 
 __device__ __forceinline__ uint32_t pack4(int b0, int b1, int b2, int b3)
 {
@@ -145,49 +147,122 @@ __global__ __launch_bounds__(256) void tf_quant_kernel(const double* __restrict_
 struct TfMfmaArgs {
     const unsigned char* Y8; const unsigned char* Gq; const double* scale; const int* ovf;
     double* logpost; int64_t ldlp; int64_t n, N; int64_t ksteps, gblocks; int itiles;
+    long long* trace;     // debug (gpirt_debug_theta_clock): six stamps per work-group, shader clock and 100 MHz wall clock
 };
+
+// A work-group owns 256 respondents x 32 grid points; wave w the respondent blocks 2 w, 2 w + 1 with all seven digit planes
+// (14 accumulator tiles).  The digit planes of the grid block are shared by the four waves and go through the LDS, a
+// respondent block's indicators are used by ONE wave and go from global memory straight into its registers; both one chunk
+// (TF_KS k-steps) ahead.  Everything a chunk issues besides its 56 MFMAs sits in the gaps between them, in a pinned order
+// (one wave per SIMD: nothing else hides a latency, and a burst of loads ahead of the MFMAs costs more than the MFMAs did --
+// 143 us with LDS-DMA pieces issued at the top of each chunk, 110 us like this):
+//     k-step 0   operands of k-step 1 (LDS)    the wave's 7 pieces of the next chunk's digit planes (global -> registers)
+//     k-step 1   operands of k-step 2          the next chunk's indicators, 8 loads
+//     k-step 2   operands of k-step 3          the 7 pieces registers -> the other LDS stage
+//     k-step 3   6 MFMAs (the LDS traffic above completes under them), barrier (every wave's pieces are in, everyone is done
+//                with this stage), the next chunk's first operands in one burst under the other 8 MFMAs
+// Chunks are taken in pairs so that both register sets are indexed statically; past the last chunk the loads repeat it
+// (into the stage and the registers nobody reads any more) instead of branching.
+template <int P>
+__device__ __forceinline__ void tf_chunk(const TfMfmaArgs& a, unsigned char* lds, int c, int nchunks, int lane, int wave,
+                                         const unsigned char* srcA0, const unsigned char* srcA1, const unsigned char* srcB,
+                                         v4i (&ya)[2][TF_KS][2], v4i (&fb)[2][TF_DIGITS], v16i (&acc)[2][TF_DIGITS])
+{
+    constexpr int KS = TF_KS;
+    static_assert(KS == 4, "the schedule below is written out for four k-steps");
+    constexpr int NP = (TF_DIGITS * KS) / 4;                // pieces per wave
+    const int64_t ksteps = a.ksteps;
+    const int cn = (c + 1 < nchunks) ? c + 1 : c;
+    const int64_t adv = (int64_t)cn * KS * 1024;
+    const unsigned char* sb = lds + P * TF_STAGE + lane * 16;
+    unsigned char* sn = lds + (P ^ 1) * TF_STAGE + lane * 16;
+    v4i bs[NP];
+    auto mfma = [&](int ksl, int slot, int s0, int s1) {
+#pragma unroll
+        for (int s = s0; s < s1; ++s) {
+            acc[0][s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ya[P][ksl][0], fb[slot][s], acc[0][s], 0, 0, 0);
+            acc[1][s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ya[P][ksl][1], fb[slot][s], acc[1][s], 0, 0, 0);
+        }
+    };
+    auto fetch = [&](const unsigned char* stage, int ksl, int slot) {
+#pragma unroll
+        for (int s = 0; s < TF_DIGITS; ++s) fb[slot][s] = *reinterpret_cast<const v4i*>(stage + (s * KS + ksl) * 1024);
+    };
+    // k-step 0
+    fetch(sb, 1, 1);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int pb = 4 * q + wave, ksl = pb % KS, s = pb / KS;
+        bs[q] = *reinterpret_cast<const v4i*>(srcB + ((int64_t)s * a.gblocks * ksteps + ksl) * 1024 + adv);
+    }
+    mfma(0, 0, 0, TF_DIGITS);
+#pragma unroll
+    for (int r = 0; r < TF_DIGITS; ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    // k-step 1
+    fetch(sb, 2, 0);
+#pragma unroll
+    for (int ksl = 0; ksl < KS; ++ksl) {
+        ya[P ^ 1][ksl][0] = *reinterpret_cast<const v4i*>(srcA0 + adv + ksl * 1024);
+        ya[P ^ 1][ksl][1] = *reinterpret_cast<const v4i*>(srcA1 + adv + ksl * 1024);
+    }
+    mfma(1, 1, 0, TF_DIGITS);
+#pragma unroll
+    for (int r = 0; r < TF_DIGITS; ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    // k-step 2
+    fetch(sb, 3, 1);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) *reinterpret_cast<v4i*>(sn + (4 * q + wave) * 1024) = bs[q];
+    mfma(2, 0, 0, TF_DIGITS);
+#pragma unroll
+    for (int r = 0; r < TF_DIGITS; ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < TF_DIGITS; ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    }
+    // k-step 3
+    mfma(3, 1, 0, 3);
+    __builtin_amdgcn_sched_barrier(0);                      // (the six MFMAs stay AHEAD of the barrier's wait for the LDS traffic)
+    __syncthreads();
+    fetch(sn, 0, 0);
+    mfma(3, 1, 3, TF_DIGITS);
+    __builtin_amdgcn_sched_group_barrier(0x100, TF_DIGITS, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+}
 
 __global__ __launch_bounds__(256, 1) void tf_mfma_kernel(TfMfmaArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char tf_lds[];
     if (*a.ovf) return;
     constexpr int KS = TF_KS;
-    // an XCD (work-group id mod 8) keeps grid tiles 2 x, 2 x + 1 and walks the respondent tiles
+    // an XCD (work-group id mod 8) keeps the grid blocks 4 x .. 4 x + 3 (their digit planes, 1.8 MB at m = 1024, stay in its
+    // L2) and walks the respondent tiles
     const int id = (int)blockIdx.x, xcd = id & 7, local = id >> 3;
-    const int gt = 2 * xcd + (local & 1), it = local >> 1;
+    const int gb = 4 * xcd + (local & 3), it = local >> 2;
     const int lane = (int)(threadIdx.x & 63);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int wi = wave & 1, wg = wave >> 1;
     const int64_t ksteps = a.ksteps;
     const int nchunks = (int)(ksteps / KS);
-
-    // the pieces of a stage (1 KiB each): A piece pa = ibl * KS + ksl at pa KiB, B piece pb = (s * 2 + gbl) * KS + ksl at (4 KS + pb) KiB;
-    // wave w issues A pieces 4 q + w (q < KS) and B pieces 4 q + w (q < 3.5 KS)
-    // (wave-uniform 64-bit bases + one per-lane 32-bit offset: the addresses stay in scalar registers)
-    int64_t offA[KS], offB[(14 * KS) / 4];
-#pragma unroll
-    for (int q = 0; q < KS; ++q) {
-        const int pa = 4 * q + wave, ibl = pa / KS, ksl = pa % KS;
-        offA[q] = ((((int64_t)(it * 4 + ibl)) * ksteps + ksl) * 64) * 16;
-    }
-#pragma unroll
-    for (int q = 0; q < (14 * KS) / 4; ++q) {
-        const int pb = 4 * q + wave, ksl = pb % KS, sg = pb / KS, s = sg >> 1, gbl = sg & 1;
-        offB[q] = ((((int64_t)s * a.gblocks + (gt * 2 + gbl)) * ksteps + ksl) * 64) * 16;
-    }
     const uint32_t lane16 = (uint32_t)lane * 16u;
-    auto issue = [&](int c, int buf) {
-        unsigned char* base = tf_lds + buf * TF_STAGE;
-        const int64_t adv = (int64_t)c * KS * 1024;
-#pragma unroll
-        for (int q = 0; q < KS; ++q)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) uint32_t*)(a.Y8 + (offA[q] + adv) + lane16),
-                                             (__attribute__((address_space(3))) uint32_t*)(base + (4 * q + wave) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int q = 0; q < (14 * KS) / 4; ++q)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) uint32_t*)(a.Gq + (offB[q] + adv) + lane16),
-                                             (__attribute__((address_space(3))) uint32_t*)(base + (4 * KS + 4 * q + wave) * 1024), 16, 0, 0);
-    };
+    const unsigned char* srcA0 = a.Y8 + ((int64_t)(it * 8 + 2 * wave) * ksteps) * 1024 + lane16;
+    const unsigned char* srcA1 = srcA0 + ksteps * 1024;
+    const unsigned char* srcB = a.Gq + ((int64_t)gb * ksteps) * 1024 + lane16;
+    long long* tr = (a.trace && blockIdx.x < TF_TRACE_WGS && threadIdx.x == 0) ? a.trace + 6 * blockIdx.x : nullptr;
+    if (tr) { tr[0] = (long long)__builtin_amdgcn_s_memtime(); tr[1] = (long long)__builtin_amdgcn_s_memrealtime(); }
 
     v16i acc[2][TF_DIGITS];
 #pragma unroll
@@ -196,57 +271,37 @@ __global__ __launch_bounds__(256, 1) void tf_mfma_kernel(TfMfmaArgs a)
         for (int s = 0; s < TF_DIGITS; ++s)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[r][s][v] = 0;
+    v4i ya[2][KS][2], fb[2][TF_DIGITS];
 
-    issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        if (c + 1 < nchunks) issue(c + 1, (c + 1) & 1);
-        const unsigned char* sb = tf_lds + (c & 1) * TF_STAGE + lane * 16;
-        // the operands of k-step ksl + 1 are read while the 14 MFMAs of k-step ksl run (one wave per SIMD: nothing else hides
-        // the LDS latency)
-        v4i fa[2][2], fb[2][TF_DIGITS];
-        auto fetch = [&](int ksl, int slot) {
-            fa[slot][0] = *reinterpret_cast<const v4i*>(sb + ((2 * wi) * KS + ksl) * 1024);
-            fa[slot][1] = *reinterpret_cast<const v4i*>(sb + ((2 * wi + 1) * KS + ksl) * 1024);
+    // chunk 0: as tf_chunk sends chunk c + 1
 #pragma unroll
-            for (int s = 0; s < TF_DIGITS; ++s)
-                fb[slot][s] = *reinterpret_cast<const v4i*>(sb + (4 * KS + (s * 2 + wg) * KS + ksl) * 1024);
-        };
-        fetch(0, 0);
-#pragma unroll
-        for (int ksl = 0; ksl < KS; ++ksl) {
-            if (ksl + 1 < KS) fetch(ksl + 1, (ksl + 1) & 1);
-#pragma unroll
-            for (int s = 0; s < TF_DIGITS; ++s) {
-                acc[0][s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ksl & 1][0], fb[ksl & 1][s], acc[0][s], 0, 0, 0);
-                acc[1][s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ksl & 1][1], fb[ksl & 1][s], acc[1][s], 0, 0, 0);
-            }
-        }
-        // the order the scheduler has to keep (left alone it reads each operand right before its use, into one register set):
-        // the nine reads of k-step 0, then per k-step nine (read of the next k-step, MFMA) pairs and the five MFMAs left
-        __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
-#pragma unroll
-        for (int ksl = 0; ksl + 1 < KS; ++ksl) {
-#pragma unroll
-            for (int r = 0; r < 9; ++r) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 14, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+    for (int q = 0; q < (TF_DIGITS * KS) / 4; ++q) {
+        const int pb = 4 * q + wave, ksl = pb % KS, s = pb / KS;
+        *reinterpret_cast<v4i*>(tf_lds + lane16 + pb * 1024) =
+            *reinterpret_cast<const v4i*>(srcB + ((int64_t)s * a.gblocks * ksteps + ksl) * 1024);
     }
+#pragma unroll
+    for (int ksl = 0; ksl < KS; ++ksl) {
+        ya[0][ksl][0] = *reinterpret_cast<const v4i*>(srcA0 + ksl * 1024);
+        ya[0][ksl][1] = *reinterpret_cast<const v4i*>(srcA1 + ksl * 1024);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < TF_DIGITS; ++s) fb[0][s] = *reinterpret_cast<const v4i*>(tf_lds + lane16 + (s * KS) * 1024);
+
+    for (int c = 0; c < nchunks; c += 2) {                  // (tf_dims: an even number of chunks)
+        tf_chunk<0>(a, tf_lds, c, nchunks, lane, wave, srcA0, srcA1, srcB, ya, fb, acc);
+        tf_chunk<1>(a, tf_lds, c + 1, nchunks, lane, wave, srcA0, srcA1, srcB, ya, fb, acc);
+    }
+    if (tr) { tr[2] = (long long)__builtin_amdgcn_s_memtime(); tr[3] = (long long)__builtin_amdgcn_s_memrealtime(); }
 
     // register v of lane l: respondent (v & 3) + 8 (v >> 2) + 4 (l >> 5) of the block, grid point l & 31
-    const int64_t g = (int64_t)gt * 64 + wg * 32 + (lane & 31);
-    if (g >= a.N) return;
-    const double sc = a.scale[g];
+    const int64_t g = (int64_t)gb * 32 + (lane & 31);
+    const double sc = g < a.N ? a.scale[g] : 0.0;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        const int64_t i0 = (int64_t)it * 128 + (2 * wi + r) * 32 + 4 * (lane >> 5);
+        if (g >= a.N) break;
+        const int64_t i0 = (int64_t)it * 256 + (2 * wave + r) * 32 + 4 * (lane >> 5);
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int64_t i = i0 + (v & 3) + 8 * (v >> 2);
@@ -257,6 +312,7 @@ __global__ __launch_bounds__(256, 1) void tf_mfma_kernel(TfMfmaArgs a)
             a.logpost[g + i * a.ldlp] = -(((double)hi * 16777216.0 + (double)lo) * sc);
         }
     }
+    if (tr) { tr[4] = (long long)__builtin_amdgcn_s_memtime(); tr[5] = (long long)__builtin_amdgcn_s_memrealtime(); }
 }
 
 }  // namespace
@@ -266,16 +322,18 @@ TfDims tf_dims(int64_t n, int64_t m, int64_t N)
     TfDims d;
     d.mp = (m + 15) / 16 * 16;
     const int64_t steps = (2 * d.mp + 31) / 32;
-    d.ksteps = (steps + TF_KS - 1) / TF_KS * TF_KS;
-    if (d.ksteps == 0) d.ksteps = TF_KS;
-    d.iblocks = (n + 127) / 128 * 4;
-    d.gblocks = (N + 63) / 64 * 2;
+    d.ksteps = (steps + 2 * TF_KS - 1) / (2 * TF_KS) * (2 * TF_KS);      // an even number of chunks (tf_mfma_kernel)
+    if (d.ksteps == 0) d.ksteps = 2 * TF_KS;
+    d.iblocks = (n + 255) / 256 * 8;
+    d.gblocks = (N + 31) / 32;
     return d;
 }
 size_t tf_y8_bytes(const TfDims& d) { return (size_t)d.iblocks * d.ksteps * 1024; }
 size_t tf_gq_bytes(const TfDims& d) { return (size_t)TF_DIGITS * d.gblocks * d.ksteps * 1024; }
-// amax (gblocks * 32 u64) | scale (gblocks * 32 doubles) | ovf (int, padded to 16 bytes)
-size_t tf_aux_bytes(const TfDims& d) { return (size_t)d.gblocks * 32 * 16 + 16; }
+// amax (gblocks * 32 u64) | scale (gblocks * 32 doubles) | ovf (int, padded to 16 bytes) | debug stamps
+size_t tf_aux_bytes(const TfDims& d) { return (size_t)d.gblocks * 32 * 16 + 16 + (size_t)TF_TRACE_WGS * 6 * 8; }
+long long* tf_trace(void* aux, const TfDims& d) { return reinterpret_cast<long long*>(reinterpret_cast<unsigned char*>(aux) + (size_t)d.gblocks * 32 * 16 + 16); }
+int tf_trace_wgs() { return TF_TRACE_WGS; }
 
 int launch_tf_indicators(hipStream_t stream, const double* y, int64_t n, int64_t ldy, int64_t m, const TfDims& d, void* Y8)
 {
@@ -291,7 +349,7 @@ int launch_tf_indicators(hipStream_t stream, const double* y, int64_t n, int64_t
 // logpost (N x n, leading dimension ldlp) from f* (N x m) and the prepared indicators; *tf_overflow(aux) != 0 afterwards means
 // the product was NOT formed (see the header): the caller's fp64 product, launched under that flag, does it instead
 int launch_theta_fixed(hipStream_t stream, const double* fstar, int64_t N, int64_t n, int64_t m, const TfDims& d,
-                       const void* Y8, void* Gq, void* aux, double* logpost, int64_t ldlp)
+                       const void* Y8, void* Gq, void* aux, double* logpost, int64_t ldlp, bool trace)
 {
     if (n <= 0 || N <= 0) return 0;
     static bool attr_set = false;
@@ -302,7 +360,7 @@ int launch_theta_fixed(hipStream_t stream, const double* fstar, int64_t N, int64
     unsigned long long* amax = reinterpret_cast<unsigned long long*>(aux);
     double* scale = reinterpret_cast<double*>(amax + d.gblocks * 32);
     int* ovf = tf_overflow(aux, d);
-    GP_HIP(hipMemsetAsync(aux, 0, tf_aux_bytes(d), stream));
+    GP_HIP(hipMemsetAsync(aux, 0, trace ? tf_aux_bytes(d) : (size_t)d.gblocks * 32 * 16 + 16, stream));
     if (m > 0) {
         hipLaunchKernelGGL(tf_rowmax_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)((m + 15) / 16)), dim3(256), 0, stream, fstar, N, m, amax);
         GP_HIP(hipGetLastError());
@@ -312,9 +370,10 @@ int launch_theta_fixed(hipStream_t stream, const double* fstar, int64_t N, int64
     GP_HIP(hipGetLastError());
     TfMfmaArgs a;
     a.Y8 = reinterpret_cast<const unsigned char*>(Y8); a.Gq = reinterpret_cast<const unsigned char*>(Gq); a.scale = scale; a.ovf = ovf;
-    a.logpost = logpost; a.ldlp = ldlp; a.n = n; a.N = N; a.ksteps = d.ksteps; a.gblocks = d.gblocks; a.itiles = (int)(d.iblocks / 4);
+    a.logpost = logpost; a.ldlp = ldlp; a.n = n; a.N = N; a.ksteps = d.ksteps; a.gblocks = d.gblocks; a.itiles = (int)(d.iblocks / 8);
+    a.trace = trace ? tf_trace(aux, d) : nullptr;
     if (d.gblocks != 32) { set_error("theta_fixed: the work-group map is laid out for the reference's 1001-point grid"); return GPIRT_E_ARG; }
-    hipLaunchKernelGGL(tf_mfma_kernel, dim3((unsigned)(16 * a.itiles)), dim3(256), 2 * TF_STAGE, stream, a);
+    hipLaunchKernelGGL(tf_mfma_kernel, dim3((unsigned)(32 * a.itiles)), dim3(256), 2 * TF_STAGE, stream, a);
     GP_HIP(hipGetLastError());
     return 0;
 }

@@ -162,6 +162,11 @@ int gpirt_debug_ll_term(gpirt_handle_t h, const double* d_a, int64_t n, double* 
  * own (|f*| > 709 or non-finite somewhere: the formula as written overflows there).  Synchronises the handle's stream. */
 int gpirt_debug_theta_logpost(gpirt_handle_t h, const double* d_y, const double* d_fstar, int64_t n, int64_t m,
                               double* d_logpost_out, int* fell_back);
+/* The same product with in-kernel stamps: six 64-bit words per work-group of the int8 kernel (the first 1024 of them) --
+ * shader clock (s_memtime) and 100 MHz wall clock (s_memrealtime) at its start, after its main loop and at its end; what the
+ * clock the chip holds under this kernel and the share of its prologue and epilogue are read from (tools/theta_clock.py). */
+int gpirt_debug_theta_clock(gpirt_handle_t h, const double* d_y, const double* d_fstar, int64_t n, int64_t m,
+                            long long* host_stamps, int64_t count);
 
 /* rmvnorm()'s product `cholS * res` (src/mvnormal.h:10) for all item columns at once:
  * d_out (n x m) = L * Z with L lower triangular; the strict upper triangle of d_L must hold zeros

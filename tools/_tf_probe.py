@@ -1,5 +1,5 @@
 import sys, numpy as np, torch
-sys.path.insert(0, "tests")
+import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 from gpirt_amd.ops import Handle, to_device
 import test_gpu_theta_fixed as T
 h = Handle()
