@@ -363,7 +363,9 @@ int launch_indicators(hipStream_t stream, const double* y, int64_t n, int64_t m,
 
 int launch_loglik_terms(hipStream_t stream, const double* fstar, int64_t N, int64_t m, double* Gpm, int64_t ldg, const int* run_if)
 {
-    hipLaunchKernelGGL(loglik_terms_kernel, dim3(grid_for(N * m)), dim3(256), 0, stream, fstar, N, m, Gpm, ldg, run_if);
+    // (a conditional launch almost never runs: a small grid keeps what it costs to find that out at a couple of microseconds)
+    const unsigned blocks = run_if ? (grid_for(N * m) < 256u ? grid_for(N * m) : 256u) : grid_for(N * m);
+    hipLaunchKernelGGL(loglik_terms_kernel, dim3(blocks), dim3(256), 0, stream, fstar, N, m, Gpm, ldg, run_if);
     GP_HIP(hipGetLastError());
     return 0;
 }

@@ -155,7 +155,9 @@ struct TfMfmaArgs {
 // respondent block's indicators are used by ONE wave and go from global memory straight into its registers; both one chunk
 // (TF_KS k-steps) ahead.  Everything a chunk issues besides its 56 MFMAs sits in the gaps between them, in a pinned order
 // (one wave per SIMD: nothing else hides a latency, and a burst of loads ahead of the MFMAs costs more than the MFMAs did --
-// 143 us with LDS-DMA pieces issued at the top of each chunk, 110 us like this):
+// 143 us with LDS-DMA pieces issued at the top of each chunk, 105 us like this; tools/theta_clock.py: 2400 shader cycles
+// per chunk against the MFMAs' 1792 at the 1.8 GHz the chip holds under this kernel -- taking out the digit-plane staging
+// gives back 210 of them, the indicator loads 95, the barrier 50):
 //     k-step 0   operands of k-step 1 (LDS)    the wave's 7 pieces of the next chunk's digit planes (global -> registers)
 //     k-step 1   operands of k-step 2          the next chunk's indicators, 8 loads
 //     k-step 2   operands of k-step 3          the 7 pieces registers -> the other LDS stage
@@ -352,11 +354,6 @@ int launch_theta_fixed(hipStream_t stream, const double* fstar, int64_t N, int64
                        const void* Y8, void* Gq, void* aux, double* logpost, int64_t ldlp, bool trace)
 {
     if (n <= 0 || N <= 0) return 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tf_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TF_STAGE));
-        attr_set = true;
-    }
     unsigned long long* amax = reinterpret_cast<unsigned long long*>(aux);
     double* scale = reinterpret_cast<double*>(amax + d.gblocks * 32);
     int* ovf = tf_overflow(aux, d);
