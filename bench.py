@@ -38,6 +38,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP64_MFMA_TFLOPS = 78.6      # MI355X fp64 matrix peak (public spec; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
+PEAK_INT8_MFMA_TOPS = 5000.0      # dense int8 matrix peak: twice the bf16 rate per clock (MI355X_MICROARCH.md: ~2.5 PF bf16 dense)
 PEAK_HBM_GBS = 8000.0             # HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec, 6.29 TB/s measured for a copy)
 
 
@@ -238,6 +239,28 @@ def main():
         else:
             del chk, c
 
+    # ---- the log-posterior product of draw_theta on the state the timed steps ended in, both ways: in fixed point on the
+    # int8 matrix cores (what the timed steps ran, csrc/theta_fixed.hip) and as the fp64 GEMM it replaces (GPIRT_THETA_FIXED=2)
+    theta_product_check = None
+    if world == 1:
+        from gpirt_amd.ops import to_device
+        e = ss.engine
+        yd = to_device(y)
+        fd = e.device_tensor("fstar")
+        with handle.config("GPIRT_THETA_FIXED", 1):
+            lp_fx, fell_back = handle.theta_logpost(yd, fd)
+        with handle.config("GPIRT_THETA_FIXED", 2):
+            lp_ge, _ = handle.theta_logpost(yd, fd)
+        theta_product_check = {
+            "max_abs_fixed_minus_fp64_gemm": float((lp_fx - lp_ge).abs().max().item()),
+            "max_abs_logpost": float(lp_ge.abs().max().item()),
+            "fixed_point_handed_over_to_fp64": bool(fell_back),
+            "what": "N x n log-posterior of draw_theta from this run's last f*: seven int8 digit planes with exact int32 sums (every "
+                    "term rounded once to 54 bits of its grid row's range) against the fp64 MFMA GEMM; tests/test_gpu_theta_fixed.py "
+                    "holds the fixed-point form to the SMALLER error against long double",
+        }
+        del lp_fx, lp_ge, yd
+
     # per-stage device times of two extra (untimed) iterations, device events on the launch stream
     evs = []
 
@@ -425,6 +448,8 @@ def main():
                                   "(two backward-stable evaluations of k*^T S^-1 f differ by ~cond(S) eps |f*|, DESIGN.md section 5)",
                     "state": f"after {args.warmup + args.steps} iterations of this run, theta on the grid: {theta_on_grid}",
                     "passed": bool(lowrank_gap <= FSTAR_TOL and lowrank_gap_aw <= FSTAR_TOL * fstar_scale)},
+                "theta_product": "exact fixed point on the int8 matrix cores (csrc/theta_fixed.hip; GPIRT_THETA_FIXED=2: fp64 GEMM)",
+                "theta_product_check": theta_product_check,
                 "headline_note": headline_note,
                 "iterations_per_s_by_form": alt,
                 "reference_rng_iterations_per_s": None if ref_rng is None else ref_rng["value"],
@@ -465,6 +490,12 @@ def main():
                 # nu = L Z of draw_f (src/mvnormal.h:10 for all m columns as ONE triangular product, gemm_f64_kernel<false, false, ...>)
                 "draw_f_trmm": _roof_entry(prof_other.get("draw_f_trmm"), "mfma", PEAK_FP64_MFMA_TFLOPS, "TFLOP/s",
                                            "gemm_f64_kernel<false, false, 128, 0, false>: n^2 m flops (the zero triangle skipped)"),
+                # draw_theta's log-posterior product in fixed point: seven int8 digit planes against the 0/1 indicators
+                "theta_int8_product": _roof_entry(prof_other.get("theta_int8_product"), "mfma", PEAK_INT8_MFMA_TOPS, "TOP/s",
+                                                  "tf_mfma_kernel (csrc/theta_fixed.hip), v_mfma_i32_32x32x32_i8: 7 x 2 x 1001 x n x 2m integer "
+                                                  "operations per launch, exact int32 sums; peak = twice the dense bf16 rate "
+                                                  "(MI355X_MICROARCH.md, matrix cores) at the nominal 2.4 GHz -- the chip holds ~1.8 GHz under this "
+                                                  "kernel (tools/theta_clock.py).  The fp64 GEMM it replaces ran 0.52 ms at 0.91 of the fp64 MFMA peak"),
                 # the default contract's draw_f: one pass over L per three items (rs3_products_kernel), HBM-bound
                 "replay_products": _roof_entry(replay_prof, "hbm", PEAK_HBM_GBS, "GB/s",
                                                "rs3_products_kernel (R-stream replay, gpirt_default_options): bytes = the lower triangle of L, "

@@ -46,7 +46,10 @@ void set_error(const char* fmt, ...);
 // ... and, with the same instrument, two kernels of draw_f:
 //   3  nu = L Z, the triangular product of the item-keyed draw_f (src/mvnormal.h:10 for all m columns)
 //   4  rs3_products_kernel, the pass over L of the R-stream replay's draw_f (bytes: the lower triangle of L)
-constexpr int PROF_CLASSES = 5;
+// ... and on draw_theta's product:
+//   5  tf_mfma_kernel, the log-posterior product in fixed point (theta_fixed.hip; "flops" = int8 multiply-adds x 2 of the
+//      seven digit planes, 7 x 2 x 1001 x n x 2m)
+constexpr int PROF_CLASSES = 6;
 struct ProfPair { hipEvent_t e0, e1; double flops; int cls; double bytes; };
 struct Prof {
     bool        enabled = false;

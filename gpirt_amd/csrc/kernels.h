@@ -176,7 +176,8 @@ size_t tf_aux_bytes(const TfDims& d);
 int* tf_overflow(void* aux, const TfDims& d);
 int launch_tf_indicators(hipStream_t stream, const double* y, int64_t n, int64_t ldy, int64_t m, const TfDims& d, void* Y8);
 int launch_theta_fixed(hipStream_t stream, const double* fstar, int64_t N, int64_t n, int64_t m, const TfDims& d,
-                       const void* Y8, void* Gq, void* aux, double* logpost, int64_t ldlp, bool trace = false);
+                       const void* Y8, void* Gq, void* aux, double* logpost, int64_t ldlp, bool trace = false,
+                       gpirt_handle_t prof = nullptr);   // prof: the handle whose event-pair profiler brackets the int8 kernel (class 5)
 long long* tf_trace(void* aux, const TfDims& d);            // (a traced launch: six stamps per work-group, tf_trace_wgs() of them)
 int tf_trace_wgs();
 struct ThetaArgs {

@@ -577,7 +577,7 @@ int do_theta_partial(gpirt_sampler_s* s)
     // could not be scaled (|f*| beyond exp()'s range, non-finite), or instead of it with GPIRT_THETA_FIXED=2
     const int* only_if = nullptr;
     if (s->h->cfg.theta_fixed == 1) {
-        GP_TRY(launch_theta_fixed(st, s->fstar, N, n, m, s->tfd, s->tf_y8, s->tf_gq, s->tf_aux, s->logpost, N));
+        GP_TRY(launch_theta_fixed(st, s->fstar, N, n, m, s->tfd, s->tf_y8, s->tf_gq, s->tf_aux, s->logpost, N, false, s->h));
         only_if = tf_overflow(s->tf_aux, s->tfd);
     }
     GP_TRY(launch_loglik_terms(st, s->fstar, N, m, s->Gpm, Np, only_if));
@@ -610,7 +610,7 @@ int do_theta_block(gpirt_sampler_s* s)
     if (nb == 0) return 0;
     const int* only_if = nullptr;
     if (s->h->cfg.theta_fixed == 1) {                       // (as do_theta_partial; exact sums: the same bits as one GPU's product)
-        GP_TRY(launch_theta_fixed(st, s->fstar_full, N, nb, mt, s->tfd_blk, s->tf_y8_blk, s->tf_gq_blk, s->tf_aux_blk, s->logpost_blk, N));
+        GP_TRY(launch_theta_fixed(st, s->fstar_full, N, nb, mt, s->tfd_blk, s->tf_y8_blk, s->tf_gq_blk, s->tf_aux_blk, s->logpost_blk, N, false, s->h));
         only_if = tf_overflow(s->tf_aux_blk, s->tfd_blk);
     }
     GP_TRY(launch_loglik_terms(st, s->fstar_full, N, mt, s->Gpm_full, Np, only_if));

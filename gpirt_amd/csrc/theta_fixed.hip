@@ -351,7 +351,7 @@ int launch_tf_indicators(hipStream_t stream, const double* y, int64_t n, int64_t
 // logpost (N x n, leading dimension ldlp) from f* (N x m) and the prepared indicators; *tf_overflow(aux) != 0 afterwards means
 // the product was NOT formed (see the header): the caller's fp64 product, launched under that flag, does it instead
 int launch_theta_fixed(hipStream_t stream, const double* fstar, int64_t N, int64_t n, int64_t m, const TfDims& d,
-                       const void* Y8, void* Gq, void* aux, double* logpost, int64_t ldlp, bool trace)
+                       const void* Y8, void* Gq, void* aux, double* logpost, int64_t ldlp, bool trace, gpirt_handle_t prof)
 {
     if (n <= 0 || N <= 0) return 0;
     unsigned long long* amax = reinterpret_cast<unsigned long long*>(aux);
@@ -370,8 +370,13 @@ int launch_theta_fixed(hipStream_t stream, const double* fstar, int64_t N, int64
     a.logpost = logpost; a.ldlp = ldlp; a.n = n; a.N = N; a.ksteps = d.ksteps; a.gblocks = d.gblocks; a.itiles = (int)(d.iblocks / 8);
     a.trace = trace ? tf_trace(aux, d) : nullptr;
     if (d.gblocks != 32) { set_error("theta_fixed: the work-group map is laid out for the reference's 1001-point grid"); return GPIRT_E_ARG; }
+    ProfPair pp;
+    if (prof) GP_TRY(prof_pair_begin(prof, stream, pp));
     hipLaunchKernelGGL(tf_mfma_kernel, dim3((unsigned)(32 * a.itiles)), dim3(256), 2 * TF_STAGE, stream, a);
     GP_HIP(hipGetLastError());
+    // (class 5; bytes: both operands and the result once)
+    if (prof) GP_TRY(prof_pair_end(prof, stream, pp, 5, (double)TF_DIGITS * 2.0 * (double)N * (double)n * 2.0 * (double)m,
+                                   (double)tf_y8_bytes(d) + (double)tf_gq_bytes(d) + 8.0 * (double)N * (double)n));
     return 0;
 }
 

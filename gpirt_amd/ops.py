@@ -326,10 +326,11 @@ class Handle:
             out[name] = (ms.value, n.value, fl.value, by.value)
         return out
 
-    OTHER_CLASSES = {3: "draw_f_trmm", 4: "replay_products"}
+    OTHER_CLASSES = {3: "draw_f_trmm", 4: "replay_products", 5: "theta_int8_product"}
 
     def prof_other(self, reset: bool = False) -> dict:
-        """The same instrument on two kernels of draw_f (include/gpirt_hip.h, gpirt_prof_syrk classes 3 and 4):
+        """The same instrument on two kernels of draw_f and on draw_theta's product (include/gpirt_hip.h, gpirt_prof_syrk
+        classes 3, 4 and 5):
         {name: (ms, launches, algorithmic flops, algorithmic bytes)}."""
         out = {}
         for cls, name in self.OTHER_CLASSES.items():

@@ -368,7 +368,9 @@ int gpirt_prof_trailing(gpirt_handle_t h, int reset, double* total_ms, int64_t* 
  * algorithmic ones of the lower trapezoid, 2 K (M N - N (N - 1) / 2).
  * The same instrument on two kernels of draw_f: cls 3 = nu = L Z of the item-keyed draw_f (src/mvnormal.h:10 for all m
  * columns as one triangular product: n^2 m flops), 4 = the R-stream replay's pass over L (rs3_products_kernel: bytes = the
- * lower triangle of L, 8 n (n + 1) / 2, flops = 2 x 32 candidate columns x n (n + 1) / 2). */
+ * lower triangle of L, 8 n (n + 1) / 2, flops = 2 x 32 candidate columns x n (n + 1) / 2).
+ * And on draw_theta: cls 5 = the log-posterior product in fixed point on the int8 matrix cores (csrc/theta_fixed.hip:
+ * "flops" = the int8 multiply-adds x 2 of its seven digit planes, 7 x 2 x 1001 x n x 2m). */
 int gpirt_prof_syrk(gpirt_handle_t h, int cls, int reset, double* total_ms, int64_t* launches, double* flops);
 /* algorithmic bytes of the same launches (call before the resetting gpirt_prof_syrk): the C trapezoid read and
  * written once, the M x K panel operand read once -- what the launch must move if nothing is re-read */
