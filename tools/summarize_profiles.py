@@ -113,7 +113,8 @@ with open(f"profiles/{tag}_summary.md", "a") as f:
     if os.path.exists(raw + "/stats_ref.log"):
         lines = [l for l in open(raw + "/stats_ref.log") if l.startswith("{")]
         bench_ref = json.loads(lines[-1]) if lines else None
-    for name, key in (("draw_f_trmm", "gemm_f64_kernel<false, false, 128, 0"), ("replay_products", "rs3_products_kernel")):
+    for name, key in (("draw_f_trmm", "gemm_f64_kernel<false, false, 128, 0"), ("theta_int8_product", "tf_mfma_kernel"),
+                      ("replay_products", "rs3_products_kernel")):
         if name == "replay_products":
             # from the run WITH the default-contract leg; rocprofv3's average over the REAL passes of that run (spare passes,
             # which find every item done and leave at once, are not passes over L -- bench.py's events leave them out too)
