@@ -354,6 +354,8 @@ int launch_theta_fixed(hipStream_t stream, const double* fstar, int64_t N, int64
                        const void* Y8, void* Gq, void* aux, double* logpost, int64_t ldlp, bool trace, gpirt_handle_t prof)
 {
     if (n <= 0 || N <= 0) return 0;
+    // (the recombination's int64 halves are exact doubles while a plane sum stays below 2^27: a million items)
+    if (m > (1 << 20)) { set_error("theta_fixed: m = %lld is beyond the fixed-point product's range (GPIRT_THETA_FIXED=2 selects the fp64 product)", (long long)m); return GPIRT_E_ARG; }
     unsigned long long* amax = reinterpret_cast<unsigned long long*>(aux);
     double* scale = reinterpret_cast<double*>(amax + d.gblocks * 32);
     int* ovf = tf_overflow(aux, d);
