@@ -7,6 +7,7 @@ tag = sys.argv[2] if len(sys.argv) > 2 else "r05"
 SYRK = {"gemm_f64_kernel<false, true, 128, 8": "128-tile", "gemm_f64_kernel<false, true, 64, 8": "64-tile",
         "gemm_f64_kernel<false, true, 64, 16": "in-panel 64-tile"}
 PANEL = "panel_ll_kernel"
+TF = "tf_mfma_kernel"
 
 
 def newest(pattern):
@@ -27,7 +28,7 @@ def pmc(name):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(newest(f"{raw}/{name}/**/*counter_collection.csv"))):
         k = short(r["Kernel_Name"])
-        for key in list(SYRK) + [PANEL]:
+        for key in list(SYRK) + [PANEL, TF]:
             if key in k:
                 agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: (sum(v) / len(v), len(v)) for c, v in d.items()} for k, d in agg.items()}
@@ -93,6 +94,15 @@ with open(f"profiles/{tag}_summary.md", "w") as f:
                 f"{d['traffic_over_algorithmic'] if d['traffic_over_algorithmic'] else float('nan'):.2f} | {d['mfma_busy_frac']:.3f} |\n")
     f.write("\n(algorithmic = C trapezoid read + written once + the M x K panel operand read once; FETCH_SIZE counts Infinity-Cache hits, "
             "so `traffic` is an upper bound on HBM bytes.)\n\n")
+    if TF in fe and TF in wr and TF in mf:
+        e = rl.get("theta_int8_product") or {}
+        tf_traffic = (2 * fe[TF]["FETCH_SIZE"][0] + wr[TF]["WRITE_SIZE"][0]) * 1024
+        alg = e.get("algorithmic_bytes_per_launch")
+        f.write(f"`tf_mfma_kernel` (draw_theta's log-posterior product in fixed point, int8 MFMA): FETCH_SIZE {fe[TF]['FETCH_SIZE'][0]:.0f} KB raw "
+                f"(x2 = {2 * fe[TF]['FETCH_SIZE'][0] * 1024 / 1e6:.1f} MB), WRITE_SIZE {wr[TF]['WRITE_SIZE'][0] * 1024 / 1e6:.1f} MB per launch = "
+                f"{tf_traffic / 1e6:.1f} MB of traffic" + (f" against {alg / 1e6:.1f} MB algorithmic (both operands once + the fp64 result: {tf_traffic / alg:.2f}x; "
+                f"the digit planes are re-read by the 32 respondent tiles out of the L2s / the Infinity Cache, which FETCH_SIZE counts)" if alg else "") +
+                f"; MFMA busy {mf[TF]['SQ_VALU_MFMA_BUSY_CYCLES'][0] / ((mf[TF]['GRBM_GUI_ACTIVE'][0] / 8) * 1024):.3f} of the chip's SIMDs.\n\n")
     if PANEL in fe:
         f.write(f"`panel_ll_kernel`: FETCH_SIZE {fe[PANEL]['FETCH_SIZE'][0]:.0f} KB raw, WRITE_SIZE {wr[PANEL]['WRITE_SIZE'][0]:.0f} KB per launch; "
                 f"MFMA busy {mf[PANEL]['SQ_VALU_MFMA_BUSY_CYCLES'][0] / ((mf[PANEL]['GRBM_GUI_ACTIVE'][0] / 8) * 1024):.3f} of the chip's SIMDs (latency-bound pivot chain).\n\n")
