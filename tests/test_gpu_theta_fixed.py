@@ -129,3 +129,23 @@ def test_chain_with_either_product_draws_the_same_theta():
             s.close()
     assert np.array_equal(outs[0][0], outs[1][0])
     assert np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_a_block_of_respondents_and_a_shard_of_items_get_the_same_bits():
+    """What the sharded hosts rely on: the product for a block of respondents is the matching columns
+    of the whole product bit for bit; and the exact partial sums of two item shards -- each with its own row scales -- add up
+    to the whole product within the two roundings the partial results carry."""
+    import torch
+    from gpirt_amd.ops import Handle, to_device
+    h = Handle()
+    n, m = 700, 96
+    y, fstar = _inputs(n, m, seed=17)
+    with h.config("GPIRT_THETA_FIXED", 1):
+        full, fb = h.theta_logpost(to_device(y), to_device(fstar))
+        blk, _ = h.theta_logpost(to_device(np.asfortranarray(y[37:333])), to_device(fstar))
+        lo, _ = h.theta_logpost(to_device(np.asfortranarray(y[:, :40])), to_device(np.asfortranarray(fstar[:, :40])))
+        hi, _ = h.theta_logpost(to_device(np.asfortranarray(y[:, 40:])), to_device(np.asfortranarray(fstar[:, 40:])))
+    full, blk, lo, hi = (t.cpu().numpy() for t in (full, blk, lo, hi))
+    assert fb == 0
+    assert np.array_equal(full[:, 37:333], blk)
+    assert np.abs(lo + hi - full).max() <= 4 * np.spacing(np.abs(full).max())
