@@ -459,7 +459,11 @@ int launch_trsm_lower(gpirt_handle_t h, hipStream_t stream, const double* L, int
     const double* winv = nullptr;
     const int64_t nfull = n / NL4, npair = nfull / 2;
     const bool odd = (nfull & 1) != 0;
-    const bool thin = nrhs <= 256;
+    // "thin": the 1024 x 1024 inverses are built too and a 1024-aligned leaf is ONE product with them where launch_gemm would
+    // split that product over K (trsm_rec: up to 1280 right-hand sides) -- half the leaves and one recursion level less.
+    // Round 5: not only for the rank-r draw_fstar's 64 columns but for the m item columns of the other forms too
+    // (8192 x 1024: fused 9.30 -> 9.16 ms per iteration, as written 10.96 -> 10.66)
+    const bool thin = nrhs <= 1280;
     const bool have = reuse_inverses && h->trsm_winv_L == L && h->trsm_winv_n == n && h->trsm_winv_ld == ldl;
     if (use_inv && nfull >= 2 && nrhs >= 64 && have) {
         winv = h->d_trsm_winv;
