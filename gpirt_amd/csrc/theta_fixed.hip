@@ -9,9 +9,9 @@
 //         sum_j Y[i, j] q[g, j] = sum_s 256^s * (sum_j Y[i, j] d_s[g, j])
 // is seven int8 products with int32 accumulators, exact (|d| <= 128, <= 2^11 non-zero terms per sum: 2^18), recombined in
 // two int64 halves and one fp64 addition.  What comes out is the correctly rounded sum of the once-rounded terms: the error
-// per entry is <= m 2^(e_g - 55) in the worst case (3e-13 for m = 1024 and a row maximum below 16; ~1e-14 typical) against
-// <= m^2 u max|G| for the fp64 chain -- tests/test_gpu_theta_fixed.py measures both against long double and holds the
-// fixed-point form to the SMALLER error.  It is also independent of the order of the items, so a respondent block of a
+// per entry is <= m 2^(e_g - 55) in the worst case (4.5e-13 for m = 1024 and a row maximum below 16; ~1e-14 typical) against
+// <= m^2 u max|G| for the fp64 chain -- tests/test_theta_fixed_scheme.py restates the scheme in Python integers,
+// tests/test_gpu_theta_fixed.py measures both products against long double and holds the fixed-point form to the SMALLER error.  It is also independent of the order of the items, so a respondent block of a
 // sharded run (do_theta_block) is bit-identical to the single-GPU product by construction.
 //
 // v_mfma_i32_32x32x32_i8 runs at 32x the fp64 MFMA's rate per clock, so seven digit planes cost less than a quarter of the
