@@ -66,6 +66,8 @@ GP_LL_HD inline double ll_term_fast(double a)
 // accept / reject decision -- and with it every draw -- is the full-precision one.  Error of one screened term against
 // ll_term_fast: the part max(-a, 0) is exact (fp64); t = -|a| -> float (2^-24 relative), exp(t) <= 1 with relative error
 // <= 1.2e-7 + 1.8e-7 |t| (argument product + 1 ulp), log(1 + e) with absolute error <= 3e-7: below 5e-7 absolute in all.
+// (ess_kernel_reg screens BOTH sums of the test -- the trial point's and the current state's -- and decides by their
+// difference against log(u) with twice the band; the full-precision pair runs only inside it.)
 // LL_SCREEN_ERR is eight times that; tests/test_ll_fast.py measures the actual maximum on the device (gpirt_debug_ll_term,
 // form 2) over four million points (1.2e-7) and holds it under LL_SCREEN_ERR / 4.
 #define LL_SCREEN_ERR 4.0e-6

@@ -770,25 +770,45 @@ __global__ __launch_bounds__(NTH) void ess_kernel_reg(EssArgs a)
     }
     uint32_t uidx = 0;
     double acc = 0.0;
+    // ll(f) of the current state, the other half of the slice level (:28-29) -- in full precision when it is needed: with the
+    // screen on, a trial point is decided by the DIFFERENCE of two screened sums wherever that difference is further from
+    // log(u) than both error bands together, and only a trial point inside that band costs the two full-precision passes
+    // (this one at most once per item).  The decision taken there is the expression below, bit for bit.
+    auto exact_ll0 = [&]() {
+        double t = 0.0;
 #pragma unroll
-    for (int e = 0; e < EPT; ++e)
-        if (Y[e] == Y[e]) acc += ll_t<FAST>(Y[e] * (F[e] + M[e]));
-    const double ll0 = -block_sum(acc);
+        for (int e = 0; e < EPT; ++e)
+            if (Y[e] == Y[e]) t += ll_t<FAST>(Y[e] * (F[e] + M[e]));
+        return -block_sum(t);
+    };
+    // the screen's error bound for this item's sums (ll_fast.h): every row could be off by LL_SCREEN_ERR
+    const double band = LL_SCREEN_ERR * (double)n;
+    double ll0 = 0.0, lls0 = 0.0;
+    bool have_ll0 = false;
+    // (the written form of the term overflows to +inf beyond |a| = 709.8 where the screen does not: with it, ll(f) is always
+    // taken in full precision, so that an infinite slice level stays one)
+    const bool lazy = a.screen && FAST;
+    if (lazy) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e)
+            if (Y[e] == Y[e]) acc += ll_term_screen(Y[e] * (F[e] + M[e]));
+        lls0 = -block_sum(acc);
+    } else {
+        ll0 = exact_ll0();
+        have_ll0 = true;
+    }
     const double u = item_uniform(a.seed, a.iter, GPIRT_ST_F_ESS, item, uidx++);
-    const double log_y = ll0 + log(u);                                     // draw-f.cpp:28-29
+    const double log_u = log(u);
     double eps_min = 0.0, eps_max = GP_2PI;
     double eps = eps_min + (eps_max - eps_min) * item_uniform(a.seed, a.iter, GPIRT_ST_F_ESS, item, uidx++);
     eps_min = eps - GP_2PI;                                                // :36
     int k = 0;
     bool bad = false;
     double c, s;
-    // the screen's error bound for this item's sum (ll_fast.h): every row could be off by LL_SCREEN_ERR
-    const double band = LL_SCREEN_ERR * (double)n;
     for (;;) {
         c = cos(eps);
         s = sin(eps);
-        // :45 needs the sign of ll_bar(f') - log_y only: the single-precision screen decides it outside its error band,
-        // the full-precision pass (what every decision is measured by) runs only inside it
+        // :45 needs the sign of ll_bar(f') - log_y only
         int verdict = 0;                                                   // +1 accept, -1 reject, 0 undecided
         if (a.screen) {
             acc = 0.0;
@@ -796,17 +816,26 @@ __global__ __launch_bounds__(NTH) void ess_kernel_reg(EssArgs a)
             for (int e = 0; e < EPT; ++e)
                 if (Y[e] == Y[e]) acc += ll_term_screen(Y[e] * ((F[e] * c + V[e] * s) + M[e]));
             const double lls = -block_sum(acc);
-            if (lls - band > log_y) verdict = 1;
-            else if (lls + band < log_y) verdict = -1;
+            if (!have_ll0) {
+                const double d = lls - lls0;
+                if (d - 2.0 * band > log_u) verdict = 1;
+                else if (d + 2.0 * band < log_u) verdict = -1;
+            } else {
+                const double log_y = ll0 + log_u;
+                if (lls - band > log_y) verdict = 1;
+                else if (lls + band < log_y) verdict = -1;
+            }
         }
         if (verdict == 0) {
+            if (!have_ll0) { ll0 = exact_ll0(); have_ll0 = true; }
+            const double log_y = ll0 + log_u;                              // draw-f.cpp:28-29
             acc = 0.0;
 #pragma unroll
             for (int e = 0; e < EPT; ++e)
                 if (Y[e] == Y[e]) acc += ll_t<FAST>(Y[e] * ((F[e] * c + V[e] * s) + M[e]));   // :43
             const double llp = -block_sum(acc);
             if (llp > log_y) verdict = 1;                                  // :45-47
-            else if (llp != llp) { bad = true; break; }
+            else if (llp != llp || ll0 != ll0) { bad = true; break; }
         }
         if (verdict > 0) break;
         if (eps < 0.0) eps_min = eps; else eps_max = eps;                  // :50-55
