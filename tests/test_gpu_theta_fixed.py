@@ -66,7 +66,7 @@ def test_fixed_point_product_against_long_double(n, m):
         assert np.sqrt((err_fx ** 2).mean()) < np.sqrt((err_ge ** 2).mean())
 
 
-@pytest.mark.parametrize("n,m", [(1, 1), (33, 5), (128, 16), (129, 17), (257, 48), (1000, 130)])
+@pytest.mark.parametrize("n,m", [(1, 1), (33, 5), (128, 16), (129, 17), (257, 48), (1000, 130), (33024, 3), (4100, 1300)])
 def test_shapes_against_the_fp64_product(n, m):
     """ragged respondent tiles, item counts off the 16-column padding, a single item: every entry written, equal to rounding"""
     from gpirt_amd.ops import Handle
