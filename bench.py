@@ -463,7 +463,7 @@ def main():
             },
             "roofline": {
                 "kernel": "gemm_f64_kernel<false, true, T, 8, false>, T = 128 and 64: every syrk-lower launch of the factorisation "
-                          "(trailing updates + the K = 512 update inside each outer panel), v_mfma_f64_16x16x4_f64",
+                          "(trailing updates + the update between the two sub-panels of each outer panel, K = the first sub-panel's width: 704 at this size, class `in_panel_k512`), v_mfma_f64_16x16x4_f64",
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": PEAK_FP64_MFMA_TFLOPS,

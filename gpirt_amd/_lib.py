@@ -75,7 +75,7 @@ SIGNATURES = {
     "gpirt_potrf_panel_update": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64]),
     "gpirt_potrf_panel_copy": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i32]),
     "gpirt_potrf_finish": (_i32, [_vp]),
-    "gpirt_potrf_subpanel_width": (_i64, []),
+    "gpirt_potrf_subpanel_width": (_i64, [_i64]),
     "gpirt_potrf_panel_factor_part": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32]),
     "gpirt_potrf_panel_update_part": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _i32]),
     "gpirt_potrf_panel_copy_part": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _vp, _i64, _i32]),

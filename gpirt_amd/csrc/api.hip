@@ -34,7 +34,7 @@ const Config& env_config()
         d.prep_early = env_value("GPIRT_PREP_EARLY", d.prep_early);
         d.guard_verbose = env_value("GPIRT_GUARD_VERBOSE", d.guard_verbose);
         if (d.nbo < 64) d.nbo = 1024;
-        if (d.nbp < 64) d.nbp = 512;
+        if (d.nbp != 0 && d.nbp < 64) d.nbp = 512;          // (0 = by size: potrf_subpanel_width)
         return d;
     }();
     return c;
@@ -107,7 +107,7 @@ int report_panel_guard(gpirt_handle_t h, const int* w, hipStream_t stream)
 int potrf_panel_copy(hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t p, double* buf, bool to_buf,
                      int64_t extra_rows, int half, int64_t capacity)
 {
-    const int64_t W = potrf_panel_width(), H = potrf_subpanel_width(), P0 = p * W;
+    const int64_t W = potrf_panel_width(), H = potrf_subpanel_width(n), P0 = p * W;
     if (p < 0 || P0 >= n || half < 0 || half > 2) { set_error("panel %lld / half %d out of range", (long long)p, half); return GPIRT_E_ARG; }
     const int64_t P1 = (P0 + W < n) ? P0 + W : n;
     const int64_t mid = (P0 + H < P1) ? P0 + H : P1;
@@ -462,7 +462,7 @@ int gpirt_potrf_panel_copy(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda
 }
 
 // the same three pieces by halves of an outer panel (its first sub-panel / the rest): the pipeline of a distributing host
-int64_t gpirt_potrf_subpanel_width(void) { return potrf_subpanel_width(); }
+int64_t gpirt_potrf_subpanel_width(int64_t n) { return potrf_subpanel_width(n); }
 
 int gpirt_potrf_panel_factor_part(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda, int64_t p, int half)
 {

@@ -42,7 +42,7 @@ void set_error(const char* fmt, ...);
 // ---------------------------------------------------------------- handle -------------------
 // Event-pair profiler for the syrk launches of the factorisation (the MFMA work of arma::chol): pairs are recorded
 // on the launch stream without synchronising and resolved later by gpirt_prof_syrk().  Classes:
-//   0  trailing update, 128-tile kernel   1  trailing update, 64-tile kernel   2  update inside an outer panel (K = 512)
+//   0  trailing update, 128-tile kernel   1  trailing update, 64-tile kernel   2  update inside an outer panel (K = the first sub-panel's width)
 // ... and, with the same instrument, two kernels of draw_f:
 //   3  nu = L Z, the triangular product of the item-keyed draw_f (src/mvnormal.h:10 for all m columns)
 //   4  rs3_products_kernel, the pass over L of the R-stream replay's draw_f (bytes: the lower triangle of L)
@@ -65,7 +65,7 @@ struct Prof {
 // creation; the non-geometry ones can be changed per handle through gpirt_config_set (tests do, instead of editing the
 // environment between calls).  Defaults are the measured optimum at n = 8192 (README.md has the table).
 struct Config {
-    int  nbo = 1024, nbp = 512;   // GPIRT_NBO / GPIRT_NBP: outer panel width (K of a trailing update) / sub-panel width
+    int  nbo = 1024, nbp = 0;     // GPIRT_NBO / GPIRT_NBP: outer panel width (K of a trailing update) / sub-panel width (0: by size, potrf_subpanel_width)
     int  lookahead = 1;           // GPIRT_LOOKAHEAD: 1 = the next panel is factored on a side stream beside the updates, 2 = off
     int  panel = 1;               // GPIRT_PANEL: 1 = persistent sub-panel kernel (panel.hip), 2 = launch-per-step panel (the
                                   //   fallback a hang-guard expiry refactors with)
@@ -129,6 +129,7 @@ struct gpirt_handle_s {
     int          live_samplers = 0;
     bool         zombie = false;
     int          guard_fallbacks = 0;
+    int64_t      cur_nbp = 512;           // sub-panel width of the factorisation being enqueued (potrf_subpanel_width(n))
     long long    factor_count = 0;        // factorisations enqueued on this handle (launch_potrf_lower)
     int          rs_trace_pass = -1;      // debug (gpirt_debug_rs_trace): the pass of every replayed draw_f whose kernels stamp their phases
     int          rs_cand_limit = 0;       // debug (gpirt_debug_rs_cand_limit): candidates the replay's draw_f may use (0: all)

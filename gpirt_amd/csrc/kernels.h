@@ -49,7 +49,7 @@ int potrf_guard_reset(gpirt_handle_t h, hipStream_t stream);      // hang-guard 
 
 // the same factorisation in pieces (distributed hosts): outer panel p = columns [p W, (p + 1) W)
 int64_t potrf_panel_width();
-int64_t potrf_subpanel_width();
+int64_t potrf_subpanel_width(int64_t n);     // first sub-panel of an outer panel of an n x n factorisation (GPIRT_NBP, or by size)
 // half: 0 = the panel's first sub-panel, 1 = the rest of it, 2 = the whole panel (persistent panel kernel for 0 / 1)
 int potrf_panel_factor(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int64_t lda, int64_t p, int64_t extra_rows = 0,
                        int half = 2);

@@ -138,7 +138,7 @@ int factor_panel(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int
         // the persistent kernel is chain-bound up to ~512 columns and GEMM-bound beyond (one work-group per
         // row block does all of that block's left-looking products): wider outer panels are cut into
         // sub-panels of NBP columns with an MFMA update of the remaining columns in between
-        const int64_t nbp = round64(h->cfg.nbp, NBP);
+        const int64_t nbp = h->cur_nbp;
         for (int64_t k0 = K0; k0 < c1; k0 += nbp) {
             const int64_t k1 = (k0 + nbp < c1) ? k0 + nbp : c1;
             if (!(part == 2 && k0 == K0)) GP_TRY(launch_panel_ll(h, stream, A, n, lda, k0, k1));
@@ -152,7 +152,7 @@ int factor_panel(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int
     }
     // launch-per-step panel.  part 1 / 2 (the halves of a distributing host): the first sub-panel's columns / the rest --
     // the same launches as the whole panel, cut at the sub-panel boundary
-    const int64_t nbp = round64(h->cfg.nbp, NBP);
+    const int64_t nbp = h->cur_nbp;
     const int64_t mid = (K0 + nbp < c1) ? K0 + nbp : c1;
     const int64_t kb = (part == 2) ? mid : K0, ke = (part == 1) ? mid : c1;
     for (int64_t k0 = kb; k0 < ke; k0 += NBI) {
@@ -232,7 +232,17 @@ int crit_update(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int6
 // rank applies it to the block columns it owns.  The pieces are exactly the launches of launch_potrf_lower -- same
 // sub-panel split, same K = 1024 products applied to every block in ascending panel order -- so the assembled L is
 // bit-identical to the single-GPU factor.
-int64_t potrf_subpanel_width() { return round64(env_config().nbp, NBP); }
+// The first sub-panel of an outer panel.  GPIRT_NBP fixes it; otherwise by size: 512 of the 1024 columns, but 704 from
+// n = 6144 to 10240 -- measured round 5 on whole iterations at n = 8192 (all three draw_fstar forms, m = 512 ... 2048):
+// 6.46 -> 6.38 ms with 576 ... 768 (the factorisation ALONE is unchanged at 4.64 ms: what gains is the sampler's iteration,
+// where the side work beside the last outer panel meets a shorter second sub-panel); 2 % slower at 4096, 2.5 - 3 % at
+// 12288 and 16384.  One rule for launch_potrf_lower and for the pieces of the distributing hosts (same n, same widths).
+int64_t potrf_subpanel_width(int64_t n)
+{
+    const int set = env_config().nbp;
+    if (set > 0) return round64(set, NBP);
+    return (n >= 6144 && n <= 10240) ? 704 : NBP;
+}
 int64_t potrf_panel_width() { return round64(env_config().nbo, NBO); }
 
 // half: 0 = the panel's first sub-panel, 1 = the rest of it, 2 = the whole panel
@@ -241,6 +251,7 @@ int potrf_panel_factor(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
 {
     const int64_t W = potrf_panel_width(), K0 = p * W;
     if (p < 0 || K0 >= n || half < 0 || half > 2) { set_error("panel %lld / half %d out of range", (long long)p, half); return GPIRT_E_ARG; }
+    h->cur_nbp = potrf_subpanel_width(n);
     return factor_panel(h, stream, A, n + extra_rows, lda, K0, (K0 + W < n) ? K0 + W : n, false, half == 2 ? 0 : half + 1);
 }
 
@@ -255,7 +266,7 @@ int potrf_panel_update(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
     const int64_t hi = (lo + W < n) ? lo + W : n;
     if (part < 0 || part > 2) { set_error("panel update part %d", part); return GPIRT_E_ARG; }
     if (c == p + 1 && h->cfg.panel != 2)        // the next panel's block column: the same products as launch_potrf_lower
-        return crit_update(h, stream, A, n + extra_rows, lda, K0, K0 + W, lo, hi, potrf_subpanel_width(), part == 2 ? 7 : (part == 0 ? 1 : 6));
+        return crit_update(h, stream, A, n + extra_rows, lda, K0, K0 + W, lo, hi, potrf_subpanel_width(n), part == 2 ? 7 : (part == 0 ? 1 : 6));
     if (part == 0) return 0;
     return trailing(h, stream, A, n + extra_rows, lda, K0, K0 + W, lo, hi);
 }
@@ -274,7 +285,7 @@ int launch_potrf_lower(gpirt_handle_t h, hipStream_t stream, double* A, int64_t 
     if (extra_rows > 0 && (n % NBI) != 0) { set_error("bordered factorisation needs n %% 64 == 0"); return GPIRT_E_ARG; }
     const int64_t nr = n + extra_rows;          // rows of every panel / update; column limits stay n
     const int64_t nbo = potrf_panel_width();
-    const int64_t nbp_la = round64(h->cfg.nbp, NBP);
+    const int64_t nbp_la = h->cur_nbp = potrf_subpanel_width(n);
     const bool persistent = h->cfg.panel != 2;
     if (reset_info) GP_HIP(hipMemsetAsync(h->d_info, 0, sizeof(int), stream));
     h->prelast_cols = 0;

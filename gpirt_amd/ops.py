@@ -183,9 +183,9 @@ class Handle:
         check(self.lib.gpirt_potrf_panel_copy(self._h, _p(A), A.shape[0], _ld(A), int(p), _p(buf), int(bool(to_buf))))
 
     # ... by halves of an outer panel (half: 0 first sub-panel, 1 the rest, 2 whole; part: 0 needs only the first sub-panel)
-    @property
-    def subpanel_width(self) -> int:
-        return int(self.lib.gpirt_potrf_subpanel_width())
+    def subpanel_width(self, n: int) -> int:
+        """first sub-panel of an outer panel of an n x n factorisation (GPIRT_NBP, or by size: csrc/potrf.hip)"""
+        return int(self.lib.gpirt_potrf_subpanel_width(int(n)))
 
     def potrf_panel_factor_part(self, A: torch.Tensor, p: int, half: int):
         check(self.lib.gpirt_potrf_panel_factor_part(self._h, _p(A), A.shape[0], _ld(A), int(p), int(half)))

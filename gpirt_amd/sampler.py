@@ -220,7 +220,7 @@ class Sampler:
     # sub-panel, 1 the rest, 2 all): what the pipelined distributed factorisation drives (gpirt_amd/distributed.py)
     @property
     def subpanel_width(self) -> int:
-        return int(self.lib.gpirt_potrf_subpanel_width())
+        return int(self.lib.gpirt_potrf_subpanel_width(int(self.n)))
 
     def panel_factor_part(self, p: int, half: int):
         check(self.lib.gpirt_sampler_panel_factor_part(self._s, int(p), int(half)))

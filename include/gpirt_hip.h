@@ -125,7 +125,7 @@ int gpirt_potrf_panel_update(gpirt_handle_t h, double* d_A, int64_t n, int64_t l
 int gpirt_potrf_panel_copy(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda, int64_t p, double* d_buf, int to_buf);
 int gpirt_potrf_finish(gpirt_handle_t h);
 /* The same pieces by HALVES of an outer panel, for a host that pipelines its broadcasts: an outer panel is factored as a
- * first sub-panel of gpirt_potrf_subpanel_width() columns and the rest, and the next panel's first columns take the panel's
+ * first sub-panel of gpirt_potrf_subpanel_width(n) columns (GPIRT_NBP, or chosen by the order n of the matrix) and the rest, and the next panel's first columns take the panel's
  * update as two products (first sub-panel, then the rest -- the same rule launch_potrf_lower follows on one GPU), so
  *   half: 0 = the panel's first sub-panel, 1 = the rest of it, 2 = the whole panel        (factor / copy)
  *   part: 0 = what needs only panel p's first sub-panel, 1 = everything else, 2 = all     (update)
@@ -134,7 +134,7 @@ int gpirt_potrf_finish(gpirt_handle_t h);
  * bit for bit.  copy_part moves the part's columns, rows from the part's first row down (dense, ld = that row count);
  * buf_doubles is the capacity of d_buf in doubles: a part that does not fit is refused (GPIRT_E_ARG), never truncated
  * (half 1 is W - H columns wide, wider than half 0 whenever GPIRT_NBP < GPIRT_NBO / 2). */
-int64_t gpirt_potrf_subpanel_width(void);
+int64_t gpirt_potrf_subpanel_width(int64_t n);
 int gpirt_potrf_panel_factor_part(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda, int64_t p, int half);
 int gpirt_potrf_panel_update_part(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda, int64_t p, int64_t c, int part);
 int gpirt_potrf_panel_copy_part(gpirt_handle_t h, double* d_A, int64_t n, int64_t lda, int64_t p, int half, double* d_buf,
@@ -364,7 +364,7 @@ int gpirt_prof_trailing(gpirt_handle_t h, int reset, double* total_ms, int64_t* 
                         double* flops);
 /* The same per class of syrk launch inside arma::chol's replacement (src/gpirtMCMC.cpp:17,78,97):
  * cls 0 = trailing update on the 128-tile kernel (what gpirt_prof_trailing reports), 1 = trailing update on the
- * 64-tile kernel, 2 = the K = 512 update between the two sub-panels of an outer panel.  flops are the
+ * 64-tile kernel, 2 = the update between the two sub-panels of an outer panel (K = gpirt_potrf_subpanel_width(n)).  flops are the
  * algorithmic ones of the lower trapezoid, 2 K (M N - N (N - 1) / 2).
  * The same instrument on two kernels of draw_f: cls 3 = nu = L Z of the item-keyed draw_f (src/mvnormal.h:10 for all m
  * columns as one triangular product: n^2 m flops), 4 = the R-stream replay's pass over L (rs3_products_kernel: bytes = the

@@ -166,7 +166,7 @@ def test_potrf_in_half_panels_is_bit_identical(handle, oracle, n, G, panel):
 def _half_panels_body(handle, oracle, n, G, th, th0):
     import torch
     ref = handle.factor(th)
-    W, H = handle.panel_width, handle.subpanel_width
+    W, H = handle.panel_width, handle.subpanel_width(n)
     NP = (n + W - 1) // W
     ranks = [handle.se_kernel(th, th, jitter=0.001) for _ in range(G)]
     buf = torch.empty(n * min(H, n), dtype=torch.float64, device="cuda")
