@@ -157,7 +157,8 @@ int prof_pair_end(gpirt_handle_t h, hipStream_t stream, ProfPair& pp, int cls, d
 
 extern "C" {
 
-int gpirt_version(void) { return 101; }     // 101: gpirt_options names kernel_fp32 / kstar_rank, gpirt_fast_options
+int gpirt_version(void) { return 102; }     // 101: gpirt_options names kernel_fp32 / kstar_rank, gpirt_fast_options;
+                                            // 102: gpirt_potrf_subpanel_width takes the order of the matrix, gpirt_debug_theta_*
 
 const char* gpirt_last_error(void) { return g_err; }
 

@@ -60,7 +60,7 @@ typedef struct gpirt_handle_s*  gpirt_handle_t;
 typedef struct gpirt_sampler_s* gpirt_sampler_t;
 
 /* ---------------------------------------------------------------- library / handle ------ */
-int         gpirt_version(void);
+int         gpirt_version(void);    /* 102: gpirt_potrf_subpanel_width(n) takes the order of the matrix; 101: named gpirt_options fields, gpirt_fast_options */
 const char* gpirt_last_error(void);
 int         gpirt_device_count(int* count);
 /* device < 0: current device.  stream is a hipStream_t; NULL is HIP's default (null) stream. */
