@@ -43,8 +43,10 @@ PEAK_HBM_GBS = 8000.0             # HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec
 
 
 def cpu_baseline(n, m, sampler, y):
-    """the CPU restatement of the reference on this host, one thread (reference-shaped, unblocked
-    potrf) and all cores (blocked OpenMP potrf at full size + item-parallel stages), on a bounded sample."""
+    """the CPU restatement of the reference on this host.  Top-level value: ALL host cores, one whole
+    iteration at the full size (blocked OpenMP potrf + item-parallel stages), measured, nothing extrapolated; the
+    reference-shaped single-thread figure (unblocked potrf, stretched from samples) is the sub-object
+    `single_thread_reference_shaped`."""
     from oracle import cpu_baseline as CB          # checker / baseline only; never the product path
     return CB.run(n, m, y, sampler.get("theta"), sampler.get("L"), sampler.get("f"), sampler.get("beta"),
                   sampler.get("mu"), sampler.get("fstar"))
@@ -463,7 +465,7 @@ def main():
             },
             "roofline": {
                 "kernel": "gemm_f64_kernel<false, true, T, 8, false>, T = 128 and 64: every syrk-lower launch of the factorisation "
-                          "(trailing updates + the update between the two sub-panels of each outer panel, K = the first sub-panel's width: 704 at this size, class `in_panel_k512`), v_mfma_f64_16x16x4_f64",
+                          "(trailing updates + the update between the two sub-panels of each outer panel, K = the first sub-panel's width: 704 at this size, class `in_panel_update`), v_mfma_f64_16x16x4_f64",
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": PEAK_FP64_MFMA_TFLOPS,

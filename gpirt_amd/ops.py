@@ -313,7 +313,7 @@ class Handle:
         check(self.lib.gpirt_prof_trailing(self._h, int(reset), C.byref(ms), C.byref(n), C.byref(fl)))
         return ms.value, n.value, fl.value
 
-    SYRK_CLASSES = ("trailing_128tile", "trailing_64tile", "in_panel_k512")
+    SYRK_CLASSES = ("trailing_128tile", "trailing_64tile", "in_panel_update")
 
     def prof_syrk(self, reset: bool = False) -> dict:
         """Event-timed syrk launches of the factorisation per class:

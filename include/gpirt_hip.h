@@ -85,8 +85,11 @@ int         gpirt_guard_fallbacks(gpirt_handle_t h, int* count);
  * word raised, result unfinished -- without spinning any kernel.  h == NULL arms the handle the NEXT gpirt_mcmc call
  * creates for itself (that call reports its fallbacks through gpirt_debug_last_mcmc_fallbacks). */
 int         gpirt_debug_trip_guard(gpirt_handle_t h, int nth);
-/* Tests only: the R-stream replay's speculative draw_f uses candidates for rejection counts < limit only (0: all 32; see
- * DESIGN.md section 2), so the fallback of an item whose predecessor's slice loop ran longer is exercised. */
+/* Tests only: a pass of the R-stream replay's draw_f resolves up to three items: the anchor, the next
+ * item at one of 15 places its predecessor's uniform count selects, the one after at one of 16.  limit > 0 clamps both
+ * candidate counts to min(15 | 16, limit) (0: the full 15 / 16), so that passes which end early -- a predecessor's slice loop
+ * consumed more than the slot holds candidates for, the next pass starts at the first unresolved item -- are exercised at
+ * will.  There is no host fallback: the anchor is device-side state. */
 int         gpirt_debug_rs_cand_limit(gpirt_handle_t h, int limit);
 /* Debug: pass number `pass` (0-based; < 0: none) of every R-stream draw_f on this handle leaves the in-kernel time stamps of
  * its two kernels in the sampler's "rs_trace" array (gpirt_sampler_get, 128 64-bit words, 100 MHz): tools/rs_trace.py. */

@@ -36,7 +36,7 @@ def pmc(name):
 
 fe, wr, mf = pmc("pmc_fetch"), pmc("pmc_write"), pmc("pmc_mfma")
 rl = bench["roofline"]
-cls_of = {"128-tile": ["trailing_128tile"], "64-tile": ["trailing_64tile"], "in-panel 64-tile": ["in_panel_k512"]}
+cls_of = {"128-tile": ["trailing_128tile"], "64-tile": ["trailing_64tile"], "in-panel 64-tile": ["in_panel_update"]}
 commit = open(raw + "/commit.txt").read().strip() if os.path.exists(raw + "/commit.txt") else "unknown"
 per_kernel = {}
 tot_traffic = tot_launch = 0.0
