@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--fstar", default="lowrank", choices=["double_solve", "fused", "lowrank"],
                     help="double_solve: src/draw-fstar.cpp as written; fused: mean = (L^-1 k*)^T (L^-1 f); lowrank: fused + the "
                          "rank-64 Chebyshev factorisation of K(theta, theta*) (exact to 1e-15), 64 + m right-hand sides")
+    ap.add_argument("--kernel-fp32", action="store_true",
+                    help="BASELINE config C5: build K(theta, theta) in single precision (gpirt_options.kernel_fp32), factor in fp64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-rng", action="store_true",
                     help="skip the (untimed for `value`) two iterations under the literal default contract (R-stream replay)")
@@ -135,9 +137,10 @@ def main():
     def make(form, single=False):
         def factory(y_loc, th, pm, ps, st, item0, m_total):
             if form == "lowrank":       # the headline: the library's throughput preset, gpirt_fast_options() (include/gpirt_hip.h)
-                return Sampler(handle, y_loc, th, pm, ps, st, preset="fast", seed=20240, item0=item0, m_total=m_total)
+                return Sampler(handle, y_loc, th, pm, ps, st, preset="fast", seed=20240, item0=item0, m_total=m_total,
+                               kernel_fp32=args.kernel_fp32)
             return Sampler(handle, y_loc, th, pm, ps, st, rng="item", seed=20240, theta_stabilise=True,
-                           item0=item0, m_total=m_total, **FORMS[form])
+                           item0=item0, m_total=m_total, kernel_fp32=args.kernel_fp32, **FORMS[form])
         if single:      # the FULL problem on this rank alone (rank 0's single-GPU reference inside a sharded run)
             return ShardedSampler(factory, y, theta0, dist=None)
         return ShardedSampler(factory, y, theta0, dist=dist if world > 1 else None, chol=args.chol, theta=args.theta)
@@ -429,6 +432,7 @@ def main():
                              "RNG, theta_stabilise, fused + rank-64 draw_fstar); draw_fstar[lowrank] is checked in this run against the "
                              "full solve and the as-written form (lowrank_check)" if form == "lowrank" else ""),
                 "options_preset": "gpirt_fast_options" if form == "lowrank" else None,
+                "kernel_fp32": bool(args.kernel_fp32),
                 "parallelism": (f"items sharded over {world} GPU(s); chol {args.chol}; draw_theta: " +
                                 (f"all-gather of f* ({1001}x{m}), theta drawn per block of respondents, {n} draws combined"
                                  if args.theta == "gather" else

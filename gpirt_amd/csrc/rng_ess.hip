@@ -812,9 +812,16 @@ __global__ __launch_bounds__(NTH) void ess_kernel_reg(EssArgs a)
         int verdict = 0;                                                   // +1 accept, -1 reject, 0 undecided
         if (a.screen) {
             acc = 0.0;
+            // (the written form of the term, !FAST, is +inf below a = -709.78 where the screen stays finite: a trial point
+            // with such a row is rejected by the formula as written, so the screen may not decide it)
+            int overflows = 0;
 #pragma unroll
             for (int e = 0; e < EPT; ++e)
-                if (Y[e] == Y[e]) acc += ll_term_screen(Y[e] * ((F[e] * c + V[e] * s) + M[e]));
+                if (Y[e] == Y[e]) {
+                    const double arg = Y[e] * ((F[e] * c + V[e] * s) + M[e]);
+                    acc += ll_term_screen(arg);
+                    if (!FAST && arg < -709.0) overflows = 1;
+                }
             const double lls = -block_sum(acc);
             if (!have_ll0) {
                 const double d = lls - lls0;
@@ -825,6 +832,7 @@ __global__ __launch_bounds__(NTH) void ess_kernel_reg(EssArgs a)
                 if (lls - band > log_y) verdict = 1;
                 else if (lls + band < log_y) verdict = -1;
             }
+            if (!FAST) { if (__syncthreads_or(overflows)) verdict = 0; }
         }
         if (verdict == 0) {
             if (!have_ll0) { ll0 = exact_ll0(); have_ll0 = true; }
