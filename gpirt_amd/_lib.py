@@ -64,6 +64,7 @@ SIGNATURES = {
     "gpirt_guard_fallbacks": (_i32, [_vp, C.POINTER(_i32)]),
     "gpirt_debug_trip_guard": (_i32, [_vp, _i32]),
     "gpirt_debug_rs_cand_limit": (_i32, [_vp, _i32]),
+    "gpirt_debug_rs_mispredict": (_i32, [_vp, _i32]),
     "gpirt_debug_rs_trace": (_i32, [_vp, _i32]),
     "gpirt_debug_last_mcmc_fallbacks": (_i32, []),
     "gpirt_se_kernel": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _dbl]),

@@ -33,6 +33,7 @@ const Config& env_config()
         d.early_inv = env_value("GPIRT_EARLY_INV", d.early_inv);
         d.prep_early = env_value("GPIRT_PREP_EARLY", d.prep_early);
         d.guard_verbose = env_value("GPIRT_GUARD_VERBOSE", d.guard_verbose);
+        d.rs_predict = env_value("GPIRT_RS_PREDICT", d.rs_predict);
         if (d.nbo < 64) d.nbo = 1024;
         if (d.nbp != 0 && d.nbp < 64) d.nbp = 512;          // (0 = by size: potrf_subpanel_width)
         return d;
@@ -286,6 +287,7 @@ static int* config_slot(gpirt_handle_t h, const char* name, bool* read_only)
         { "GPIRT_DEFER", &h->cfg.defer, false }, { "GPIRT_TRSM_INV", &h->cfg.trsm_inv, false },
         { "GPIRT_LL_EXACT", &h->cfg.ll_exact, false }, { "GPIRT_ESS_SCREEN", &h->cfg.ess_screen, false }, { "GPIRT_THETA_FIXED", &h->cfg.theta_fixed, false }, { "GPIRT_BORDERED", &h->cfg.bordered, false },
         { "GPIRT_EARLY_INV", &h->cfg.early_inv, false }, { "GPIRT_PREP_EARLY", &h->cfg.prep_early, false },
+        { "GPIRT_RS_PREDICT", &h->cfg.rs_predict, false },
     };
     for (auto& e : tab)
         if (strcmp(e.k, name) == 0) { if (read_only) *read_only = e.ro; return e.p; }
@@ -412,6 +414,16 @@ int gpirt_debug_rs_cand_limit(gpirt_handle_t h, int limit)
 {
     GP_ARG(h != nullptr && limit >= 0);
     h->rs_cand_limit = limit;
+    return 0;
+}
+
+// Tests only: the predictor of the R-stream replay's draw_f (rs_predict.hip) reports one uniform too many for every
+// every-th item (0: never), so that the verification's discard-and-resume path, which a real chain takes about once in
+// 1e5 trial points, runs at will.  The committed draws must not change.
+int gpirt_debug_rs_mispredict(gpirt_handle_t h, int every)
+{
+    GP_ARG(h != nullptr && every >= 0);
+    h->rs_mispredict = every;
     return 0;
 }
 

@@ -78,6 +78,7 @@ struct Config {
     int  bordered = 1;            // GPIRT_BORDERED: 2 = draw_fstar solves for L^-1 K(theta, c) / L^-1 k* explicitly
     int  early_inv = 1;           // GPIRT_EARLY_INV: 2 = no side work beside the factorisation's last outer panel
     int  prep_early = 1;          // GPIRT_PREP_EARLY: 2 = the factor-only part of the rank-r draw_fstar waits for nu = L z
+    int  rs_predict = 1;          // GPIRT_RS_PREDICT: 2 = the R-stream replay's draw_f runs every pass over L in fp64 (one phase, rng_ess.hip)
     int  guard_verbose = 0;       // GPIRT_GUARD_VERBOSE: 1 = a hang-guard fallback prints the guard record to stderr
 };
 const Config& env_config();
@@ -132,6 +133,7 @@ struct gpirt_handle_s {
     int64_t      cur_nbp = 512;           // sub-panel width of the factorisation being enqueued (potrf_subpanel_width(n))
     long long    factor_count = 0;        // factorisations enqueued on this handle (launch_potrf_lower)
     int          rs_trace_pass = -1;      // debug (gpirt_debug_rs_trace): the pass of every replayed draw_f whose kernels stamp their phases
+    int          rs_mispredict = 0;       // debug (gpirt_debug_rs_mispredict): the replay's predictor is off by one at every n-th item
     int          rs_cand_limit = 0;       // debug (gpirt_debug_rs_cand_limit): candidates the replay's draw_f may use (0: all)
     long long    trip_guard_at = -1;      // debug (gpirt_debug_trip_guard): the factorisation with this count raises the
                                           //   guard word and poisons its result behind itself, as an expiry would leave it

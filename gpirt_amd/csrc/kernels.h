@@ -135,6 +135,11 @@ struct Rs3Args {
     // launch a range of 2^20 tags above all earlier ones, so nothing is ever reset
     double* partial; unsigned long long* flags; uint64_t tag;
     long long* trace;                // debug (gpirt_debug_rs_trace): in-kernel time stamps of this pass, or null
+    // the predicted replay (rs_predict.hip): the predictor's passes work on single-precision tiles of L and leave
+    // single-precision parts; anchor[3] != 0 = the predictor has stalled
+    const float* Lt32; int64_t nk8;  // L in 1 KiB tiles of 32 rows x 8 columns of floats (launch_rs32_tiles), nk8 = rs32_tile_octs(n) per row group
+    float* part32;                   // [parts][RS3_CAND][n]; non-null selects the predictor's form of the slice kernel
+    int mispredict;                  // debug (gpirt_debug_rs_mispredict): the predictor is off by one at every mispredict-th item
 };
 inline int64_t rs_tile_quads(int64_t n) { return (n + 3) / 4 + 1; }
 inline size_t rs_tile_doubles(int64_t n) { return (size_t)((n + RS_ROWS - 1) / RS_ROWS) * (size_t)rs_tile_quads(n) * 128; }
@@ -146,6 +151,26 @@ void rs3_unit_table(int64_t n, std::vector<uint32_t>& units, int* nfull);
 int rs3_slice_wgs(int64_t n);
 int rs3_slice_rows(int64_t n);
 int launch_rs3_slice(hipStream_t stream, const Rs3Args& a);
+// rs_predict.hip: the predicted replay (phase A on single-precision tiles of L, phase B = one fp64 product + all slice loops
+// side by side + an in-order commit)
+inline int64_t rs32_tile_octs(int64_t n) { return (n + 7) / 8 + 1; }
+inline size_t rs32_tile_floats(int64_t n) { return (size_t)((n + RS_ROWS - 1) / RS_ROWS) * (size_t)rs32_tile_octs(n) * 256; }
+struct RsVerifyArgs {
+    const double* f; double* nu; const double* y; const double* mu;    // n x m; nu = the product's columns for items j0 .. (n x (m - j0)), f' on return
+    int64_t n, m, j0;
+    const double* U; uint64_t cap;
+    uint64_t* posv;                  // [m + 1] predicted starts; the commit corrects the entry behind a misprediction
+    const uint64_t* anchorP;         // [0] = first item the predictor has NOT reached
+    int* kv; int* used; int* ierr;   // [m]: rejections, uniforms consumed behind the normals, error code of each verified item
+};
+int launch_rs32_tiles(hipStream_t stream, const double* L, int64_t n, int64_t ldl, float* Lt);
+int launch_rs3p_products(hipStream_t stream, const Rs3Args& a);
+int launch_rs_pred_start(hipStream_t stream, const uint64_t* anchor, uint64_t* anchorP);
+int launch_rs_gather(hipStream_t stream, const double* Nrm, const uint64_t* posv, const uint64_t* anchorP, int64_t n, int64_t j0,
+                     int64_t m, double* Z);
+int launch_rs_verify(hipStream_t stream, const RsVerifyArgs& a);
+int launch_rs_commit(hipStream_t stream, const RsVerifyArgs& a, uint64_t* anchor, uint64_t* pos, uint64_t* ctl, int* err, double* f,
+                     int* k_out);
 int launch_ll_term_probe(hipStream_t stream, const double* a, int64_t n, double* out, int fast);     // 0 written, 1 ll_fast, 2 screen
 int launch_ll_bar(hipStream_t stream, const double* f, const double* y, const double* mu, int64_t n,
                   int64_t m, double* out);

@@ -112,6 +112,11 @@ struct gpirt_sampler_s {
     double *Nrm = nullptr, *rs_part = nullptr;
     uint32_t* rs_units = nullptr; int rs_nunits = 0, rs_nfull = 0;
     long long* rs_trace = nullptr;    // debug stamps of one pass (gpirt_debug_rs_trace)
+    // the predicted replay (rs_predict.hip): single-precision tiles of L and parts, the predictor's own anchor / cursor / error
+    // word, what the verification leaves per item, ctl = [first item not committed, mispredictions, predictor stalls, passes]
+    float *Lt32 = nullptr, *rs_part32 = nullptr;
+    uint64_t *anchorP = nullptr, *rs_ctl = nullptr, *rs_posP = nullptr;
+    int *rs_kpred = nullptr, *rs_kv = nullptr, *rs_used = nullptr, *rs_ierr = nullptr, *rs_errP = nullptr;
     // bookkeeping
     int iter = 0;                     // completed iterations
     bool initialised = false;
@@ -440,10 +445,42 @@ int do_draw_f(gpirt_sampler_s* s)
     GP_TRY(launch_rs3_begin(st, a, (uint64_t)m * (2ull * (uint64_t)n + 2ull) + 512ull * (uint64_t)m + 4096ull));
     int64_t pass = 0, done = 0;
     bool topped = false;
+    // Predict + verify (rs_predict.hip; GPIRT_RS_PREDICT=2: every pass in fp64, the one-phase replay).  The predictor's
+    // passes leave predicted starts; phase B computes every item at its predicted start exactly and commits, in order, what
+    // the prediction did not break.  A round that commits nothing (the predictor stalled on its first item) hands the rest
+    // of the draw to the one-phase replay, which always makes progress and reports genuine errors.
+    bool predict = h->cfg.rs_predict != 2;
+    if (predict) GP_TRY(launch_rs32_tiles(st, s->L, n, s->ldl, s->Lt32));
     while (done < m) {
         const int64_t left = m - done;
         int64_t count = (left + RS3_SLOTS - 1) / RS3_SLOTS + left / 40 + 2;
-        if (pass > 2 * m + 64) { set_error("R-stream replay: draw_f made no progress"); return GPIRT_E_NUMERIC; }   // (a pass resolves >= 1 item)
+        if (pass > 4 * m + 64) { set_error("R-stream replay: draw_f made no progress"); return GPIRT_E_NUMERIC; }   // (a pass resolves >= 1 item)
+        if (predict) {
+            Rs3Args ap = a;
+            ap.anchor = s->anchorP; ap.pos = s->rs_posP; ap.k_out = s->rs_kpred; ap.err = s->rs_errP;
+            ap.Lt32 = s->Lt32; ap.nk8 = rs32_tile_octs(n); ap.part32 = s->rs_part32; ap.mispredict = h->rs_mispredict;
+            GP_TRY(launch_rs_pred_start(st, s->anchor, s->anchorP));
+            for (int64_t q = 0; q < count; ++q, ++pass) {
+                s->rs_tag += 1ull << 20;
+                ap.tag = s->rs_tag;
+                ap.trace = (h->rs_trace_pass >= 0 && pass == h->rs_trace_pass) ? s->rs_trace : nullptr;
+                ProfPair pp;                                      // (bench.py's roofline: class 4, the lower triangle as floats)
+                GP_TRY(prof_pair_begin(h, st, pp));
+                GP_TRY(launch_rs3p_products(st, ap));
+                GP_TRY(prof_pair_end(h, st, pp, 4, 2.0 * RS3_CAND * 0.5 * (double)n * (double)(n + 1), 4.0 * 0.5 * (double)n * (double)(n + 1)));
+                GP_TRY(launch_rs3_slice(st, ap));
+            }
+            // phase B: the items [done, predicted) at their predicted starts, exactly
+            const int64_t mc = m - done;
+            GP_TRY(launch_rs_gather(st, s->Nrm, s->posv, s->anchorP, n, done, m, s->Z));
+            GP_TRY(launch_gemm(h, st, false, false, TRI_A_LOWER, n, mc, n, 1.0, s->L, s->ldl, s->Z, n, 0.0, s->NU, n));
+            RsVerifyArgs v{};
+            v.f = s->f; v.nu = s->NU; v.y = s->y; v.mu = s->mu; v.n = n; v.m = m; v.j0 = done;
+            v.U = s->U; v.cap = s->U_cap; v.posv = s->posv; v.anchorP = s->anchorP;
+            v.kv = s->rs_kv; v.used = s->rs_used; v.ierr = s->rs_ierr;
+            GP_TRY(launch_rs_verify(st, v));
+            GP_TRY(launch_rs_commit(st, v, s->anchor, s->pos, s->rs_ctl, s->flags, s->f, s->ess_k));
+        } else
         for (int64_t q = 0; q < count; ++q, ++pass) {
             s->rs_tag += 1ull << 20;
             a.tag = s->rs_tag;
@@ -459,7 +496,10 @@ int do_draw_f(gpirt_sampler_s* s)
         if (s->stream_open && !topped) { GP_TRY(ahead_topup(s, stream_window(s))); topped = true; }     // the next window's uniforms, while the items run
         GP_HIP(hipStreamSynchronize(st));
         if ((int)s->h_next[1] != 0) break;                    // (an error flag: stream_end / check report it)
-        if ((int64_t)s->h_next[0] <= done) { set_error("R-stream replay: draw_f made no progress"); return GPIRT_E_NUMERIC; }
+        if ((int64_t)s->h_next[0] <= done) {
+            if (predict) { predict = false; continue; }       // the predictor stalled on its first item: the one-phase replay goes on
+            set_error("R-stream replay: draw_f made no progress"); return GPIRT_E_NUMERIC;
+        }
         done = (int64_t)s->h_next[0];
     }
     return 0;
@@ -894,6 +934,13 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
             hipMemsetAsync(s->Nrm, 0, sizeof(double) * nrm, st);              // (positions no draw has filled are read, never used)
             hipMemsetAsync(s->rs_part, 0, sizeof(double) * parts * RS3_CAND * (size_t)n, st);
             hipMemsetAsync(s->anchor, 0, 4 * sizeof(uint64_t), st);
+            GP_A(s->Lt32, rs32_tile_floats(n));   GP_A(s->rs_part32, parts * RS3_CAND * (size_t)n);
+            GP_A(s->anchorP, 4);     GP_A(s->rs_ctl, 8);     GP_A(s->rs_posP, 2);
+            GP_A(s->rs_kpred, m);    GP_A(s->rs_kv, m);      GP_A(s->rs_used, m);     GP_A(s->rs_ierr, m);    GP_A(s->rs_errP, 4);
+            hipMemsetAsync(s->rs_part32, 0, sizeof(float) * parts * RS3_CAND * (size_t)n, st);
+            hipMemsetAsync(s->anchorP, 0, 4 * sizeof(uint64_t), st);
+            hipMemsetAsync(s->rs_ctl, 0, 8 * sizeof(uint64_t), st);
+            hipMemsetAsync(s->rs_errP, 0, 4 * sizeof(int), st);
             std::vector<uint32_t> units;
             rs3_unit_table(n, units, &s->rs_nfull);
             s->rs_nunits = (int)units.size();
@@ -1303,6 +1350,7 @@ static int lookup(gpirt_sampler_t s, const char* name, void** p, int64_t* count)
         { "logpost", s->logpost, N * n }, { "irf_sum", s->irf_sum, N * m }, { "ess_k", s->ess_k, m },
         { "s", s->s, N }, { "mean", s->mean, N * m }, { "nu", s->NU, n * m }, { "z", s->Z, n * m },
         { "y", s->y, n * m }, { "rs_trace", s->rs_trace, s->rs_trace ? 128 : 0 },
+        { "rs_stats", s->rs_ctl, s->rs_ctl ? 8 : 0 },     // 64-bit words: [first item not committed, mispredictions found, ...]
         { "fstar_full", s->fstar_full, s->fstar_full ? N * s->blk_m : 0 }, { "theta_stage", s->theta_stage, s->theta_stage ? n : 0 },
     };
     for (auto& e : tab)

@@ -266,6 +266,10 @@ class Sampler:
             out = np.empty(self.m, dtype=np.int32)
             check(self.lib.gpirt_sampler_get(self._s, b"ess_k", C.c_void_p(out.ctypes.data), self.m))
             return out
+        if name == "rs_stats":      # the predicted replay's counters (64-bit words; R-stream samplers only)
+            out = np.zeros(8, dtype=np.int64)
+            check(self.lib.gpirt_sampler_get(self._s, b"rs_stats", C.c_void_p(out.ctypes.data), 8))
+            return out
         shape = self._shape(name)
         out = np.empty(shape, order="F")
         check(self.lib.gpirt_sampler_get(self._s, name.encode(), C.c_void_p(out.ctypes.data), out.size))

@@ -91,6 +91,10 @@ int         gpirt_debug_trip_guard(gpirt_handle_t h, int nth);
  * consumed more than the slot holds candidates for, the next pass starts at the first unresolved item -- are exercised at
  * will.  There is no host fallback: the anchor is device-side state. */
 int         gpirt_debug_rs_cand_limit(gpirt_handle_t h, int limit);
+/* Tests only: the R-stream replay's draw_f predicts every item's start in R's stream on a single-precision copy of L and
+ * verifies all items exactly afterwards; every > 0 makes the predictor wrong on purpose at every
+ * every-th item, so the verification's discard-and-resume path runs.  The draws must not change. */
+int         gpirt_debug_rs_mispredict(gpirt_handle_t h, int every);
 /* Debug: pass number `pass` (0-based; < 0: none) of every R-stream draw_f on this handle leaves the in-kernel time stamps of
  * its two kernels in the sampler's "rs_trace" array (gpirt_sampler_get, 128 64-bit words, 100 MHz): tools/rs_trace.py. */
 int         gpirt_debug_rs_trace(gpirt_handle_t h, int pass);

@@ -599,6 +599,70 @@ def test_r_stream_draw_f_redoes_an_item_whose_candidates_ran_out(handle, oracle,
     assert state[1] == mti_ref and np.array_equal(state[0], mt_ref)
 
 
+@pytest.mark.parametrize("n,m,every", [(100, 17, 1), (512, 23, 3), (1030, 14, 4), (2048, 40, 7)])
+def test_r_stream_predicted_replay_survives_a_wrong_predictor(handle, oracle, n, m, every):
+    """The replay's draw_f predicts every item's start in R's stream on a single-precision copy of L and then computes all
+    items exactly at those starts, committing in order what the prediction did not break (rs_predict.hip).  With
+    gpirt_debug_rs_mispredict the predictor is off by one at every `every`-th item (every = 1: at EVERY item, so each round
+    commits one item): the verification must find each of them, keep the item whose own start was right, correct the next
+    start and resume -- every draw the oracle's, the generator handed back at the oracle's position."""
+    from gpirt_amd import Sampler, _lib
+    from gpirt_amd.ops import RStream
+    from gpirt_amd.synthetic import make_responses
+    lib = _lib.load()
+    y, th0 = make_responses(n, m, seed=n + m)
+    _lib.check(lib.gpirt_debug_rs_mispredict(handle._h, every))
+    try:
+        rs = RStream(4242)
+        s = Sampler(handle, y, th0, rng="reference", rstream=rs)
+        s.init()
+        for _ in range(2):
+            s.step()
+        s.check()
+        got = {k: s.get(k) for k in ("theta", "f", "beta")}
+        ks = s.get("ess_k")
+        stats = s.get("rs_stats")
+        state = rs.state()
+        s.close()
+    finally:
+        _lib.check(lib.gpirt_debug_rs_mispredict(handle._h, 0))
+    assert stats[1] >= 2 * (m // every) - 2               # (mispredictions found by the verification: the path under test ran)
+    r = oracle.RStream(4242)
+    ref = oracle.gpirt_mcmc(r, y, th0, 2, 0)
+    assert np.array_equal(got["theta"], ref["theta"][2])
+    assert np.abs(got["f"] - ref["f"][:, :, 2]).max() <= 1e-9
+    assert np.abs(got["beta"] - ref["beta"][:, :, 2]).max() <= 1e-9
+    mt_ref, mti_ref = r.mt_state()
+    assert state[1] == mti_ref and np.array_equal(state[0], mt_ref)
+
+
+@pytest.mark.parametrize("n,m", [(257, 9), (1024, 33), (3000, 12)])
+def test_r_stream_predicted_replay_agrees_with_the_one_phase_replay(handle, n, m):
+    """GPIRT_RS_PREDICT=2 runs every pass over L in fp64 (the one-phase replay of rng_ess.hip); the default predicts in single
+    precision and verifies in fp64.  Same rejection counts, same theta, same stream position; f to rounding (nu = L z is summed
+    in another order: one triangular product instead of 512-column parts)."""
+    from gpirt_amd import Sampler
+    from gpirt_amd.ops import RStream
+    from gpirt_amd.synthetic import make_responses
+    y, th0 = make_responses(n, m, seed=7 * n + m)
+    outs = []
+    for mode in (1, 2):
+        with handle.config("GPIRT_RS_PREDICT", mode):
+            rs = RStream(31)
+            s = Sampler(handle, y, th0, rng="reference", rstream=rs)
+            s.init()
+            for _ in range(3):
+                s.step()
+            s.check()
+            outs.append((s.get("f"), s.get("ess_k"), s.get("theta"), s.get("beta"), rs.state(), s.get("rs_stats")))
+            s.close()
+    (f1, k1, t1, b1, st1, q1), (f2, k2, t2, b2, st2, q2) = outs
+    assert np.array_equal(k1, k2) and np.array_equal(t1, t2)
+    assert st1[1] == st2[1] and np.array_equal(st1[0], st2[0])
+    assert np.abs(f1 - f2).max() <= 1e-10 and np.abs(b1 - b2).max() <= 1e-10
+    assert q1[1] == 0                                     # (no misprediction on these chains: the predictor earns its keep)
+
+
 @pytest.mark.parametrize("n,m", [(97, 11), (1025, 7), (640, 40)])
 def test_r_stream_draw_f_three_items_per_pass_odd_shapes(handle, oracle, n, m):
     """The replay's draw_f resolves up to three items per pass over L (rng_ess.hip): odd n (rows and columns past the last
