@@ -117,7 +117,8 @@ static_assert(5 * RS_KC + 16 + RS3_C2 <= RS3_LDS_DOUBLES, "the windows must fit"
 struct Rs3Args {
     const double* U; uint64_t cap;   // the window of stream uniforms
     double* Nrm;                     // Nrm[r] = rnorm(U[r], U[r + 1]) for r in [cursor at the start of draw_f, *nrm_end)
-    uint64_t* anchor;                // [0] the first item no pass has resolved yet (m: all done, or the draw has failed)  [1] where
+    uint64_t* anchor;                // (8 words; [3] = the predictor has stalled, [4] = rounds of 16 trial points its anchor item has already lost, rs_predict.hip)
+                                     // [0] the first item no pass has resolved yet (m: all done, or the draw has failed)  [1] where
                                      //   its normals start  [2] the end of Nrm -- one 32-byte record, read once per work-group
     uint64_t* pos;                   // the cursor (start of the next unconsumed uniform)
     uint64_t* posv;                  // [m + 1]: where item j's normals start
@@ -140,6 +141,8 @@ struct Rs3Args {
     const float* Lt32; int64_t nk8;  // L in 1 KiB tiles of 32 rows x 8 columns of floats (launch_rs32_tiles), nk8 = rs32_tile_octs(n) per row group
     float* part32;                   // [parts][RS3_CAND][n]; non-null selects the predictor's form of the slice kernel
     int mispredict;                  // debug (gpirt_debug_rs_mispredict): the predictor is off by one at every mispredict-th item
+    // rs3p_decide_kernel: partial sums [work-group][17], the candidates' walk records [32][18], the ticket (monotonic)
+    double* dec_part; double* dec_rec; unsigned* dec_ticket;
 };
 inline int64_t rs_tile_quads(int64_t n) { return (n + 3) / 4 + 1; }
 inline size_t rs_tile_doubles(int64_t n) { return (size_t)((n + RS_ROWS - 1) / RS_ROWS) * (size_t)rs_tile_quads(n) * 128; }
@@ -165,6 +168,7 @@ struct RsVerifyArgs {
 };
 int launch_rs32_tiles(hipStream_t stream, const double* L, int64_t n, int64_t ldl, float* Lt);
 int launch_rs3p_products(hipStream_t stream, const Rs3Args& a);
+int launch_rs3p_decide(hipStream_t stream, const Rs3Args& a);
 int launch_rs_pred_start(hipStream_t stream, const uint64_t* anchor, uint64_t* anchorP);
 int launch_rs_gather(hipStream_t stream, const double* Nrm, const uint64_t* posv, const uint64_t* anchorP, int64_t n, int64_t j0,
                      int64_t m, double* Z);

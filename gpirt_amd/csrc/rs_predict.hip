@@ -25,6 +25,7 @@
 // the items a stalled predictor leaves over.
 #include "common.h"
 #include "kernels.h"
+#include "ll_fast.h"
 
 namespace gpirt {
 
@@ -158,7 +159,7 @@ __device__ __forceinline__ void rs3p_product_unit(const Rs3Args& a, const uint64
     }
 }
 
-__global__ __launch_bounds__(256, 4) void rs3p_products_kernel(Rs3Args a)
+__global__ __launch_bounds__(256, 5) void rs3p_products_kernel(Rs3Args a)
 {
     // windows: W0 RS_KC floats | W1 2 RS_KC + 16 | W2 2 RS_KC + 32; then the four waves' 32 x 32 accumulators (16 KB)
     __shared__ __attribute__((aligned(16))) float lds[4 * 1024 + 64];
@@ -170,10 +171,295 @@ __global__ __launch_bounds__(256, 4) void rs3p_products_kernel(Rs3Args a)
     else                           rs3p_product_unit<false>(a, base, bx, by, lds);
 }
 
+// ---- the predictor's slice loops: ONE meeting per pass -------------------------------------------------------------------
+// rs3_slice_kernel (rng_ess.hip) runs a pass's three slice loops one after the other, each a round of eight trial points and a
+// meeting of 256 work-groups: 31 us per pass, more than the predictor's products.  Nothing here has to follow the reference's
+// arithmetic to the letter -- only the COUNTS come out, and the exact phase verifies them -- so the predictor turns the loops
+// inside out: the trial points of a slice loop do not depend on the data (src/draw-f.cpp:50-56: a rejected point only moves the
+// bracket end of its own sign), hence the first PD_T points of EVERY candidate start of all three items can be evaluated side
+// by side before anything is decided.  Work-group (candidate c, row part p) of 32 x PD_PARTS: walks candidate c's bracket
+// sequence from R's uniforms at ITS position in the stream, takes cos / sin of the PD_T points, and sums, over its rows,
+// ll(f) and the PD_T trial log-likelihoods of the item the candidate belongs to -- the term in single precision through the
+// hardware's exp / log (ll_term_screen, ll_fast.h) -- on nu = the candidate's column of the predictor's products.  PD_T + 1
+// partial sums per work-group, stored write-through; a ticket; the work-group whose ticket comes last adds the parts in a
+// fixed order and runs the three decisions (accept = first point above the slice level, draw-f.cpp:45) in one thread:
+// counts, start positions, the next anchor.  A loop that rejects all PD_T points ends the pass there; the item becomes the
+// next anchor with round + 1, and a pass evaluates points round * PD_T .. of its anchor item (the products are recomputed:
+// one pass in ten at 8192 x 1024).
+constexpr int PD_T = 16;                 // trial points per candidate and pass
+constexpr int PD_PARTS = 8;              // row parts per candidate
+constexpr int PD_V = PD_T + 1;           // sums per work-group: ll(f), then the trial points
+constexpr int PD_MAXROUND = 14;          // 2 + PD_T * (PD_MAXROUND + 1) uniforms staged <= 256
+constexpr int PD_REC = PD_T + 2;         // per candidate: uniforms consumed when point t is the current one (-1: past the window), log(u), valid
+
+__global__ __launch_bounds__(256) void rs3p_decide_kernel(Rs3Args a)
+{
+    extern __shared__ double pd_pad[];    // (dynamic LDS only to keep these work-groups one per compute unit: the ticket's hand-off was measured that way)
+    __shared__ double uL[256];
+    __shared__ double rec[PD_REC];
+    __shared__ double cs[2 * PD_T];
+    __shared__ double tot[RS3_CAND][PD_V];
+    __shared__ double recs[RS3_CAND][PD_REC];
+    __shared__ unsigned s_old;
+    __shared__ int hitv[RS3_CAND], nanv[RS3_CAND];
+    const int tid = threadIdx.x;
+    const uint64_t item0 = a.anchor[0], start = a.anchor[1], nrm_end = a.anchor[2], stalled = a.anchor[3], round0 = a.anchor[4];
+    if (item0 >= (uint64_t)a.m || stalled != 0) return;       // every item is predicted, or the predictor has stalled
+    const int64_t n = a.n;
+    const int c = (int)blockIdx.x / PD_PARTS, p = (int)blockIdx.x % PD_PARTS;
+    const int g = (c == 0) ? 0 : (c < 16 ? 1 : 2);
+    const int64_t j = (int64_t)item0 + g;
+    const uint64_t item_step = 2ull * (uint64_t)n + 2ull;
+    const uint64_t start_c = start + (uint64_t)g * item_step + (uint64_t)(c == 0 ? 0 : c < 16 ? c - 1 : c - 16);
+    const uint64_t p0 = start_c + 2ull * (uint64_t)n;           // behind the n normals
+    const int rnd = (c == 0) ? (int)round0 : 0;
+    // the item's 2n uniforms (all its normals were built) and its first two slice uniforms lie inside the window
+    const bool valid = j < a.m && !(start_c + 2ull * (uint64_t)n + 2ull > a.cap || start_c + 2ull * (uint64_t)(n - 1) >= nrm_end);
+    long long* tr = (a.trace && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) ? a.trace + (blockIdx.x == 0 ? 0 : 16) : nullptr;
+    int ti = 0;
+    auto stamp = [&]() { if (tr && ti < 16) tr[ti] = (long long)wall_clock64(); ++ti; };
+    stamp();
+    const int nU = 2 + PD_T * (rnd + 1);
+    // wave 0 alone fetches the uniforms, walks the bracket sequence and takes the cos / sin (its row loads are in flight
+    // meanwhile); the other waves go straight to their rows and meet it at ONE barrier
+    const int wv = tid >> 6, lane = tid & 63;
+    double uval[4];
+    if (wv == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int x = lane + 64 * k;
+            const uint64_t q = p0 + (uint64_t)x;
+            uval[k] = (x < nU && valid && q < a.cap) ? a.U[q] : __builtin_nan("");
+        }
+    }
+    // this thread's rows: r_beg + tid + 256 e, PD_RB of them at a time
+    const int64_t rp = ((n + (int64_t)PD_PARTS * 256 - 1) / ((int64_t)PD_PARTS * 256)) * 256;
+    const int64_t r_beg = (int64_t)p * rp;
+    const int64_t r_end = (r_beg + rp < n) ? r_beg + rp : n;
+    const double* fj = a.f + (valid ? j : 0) * n; const double* mj = a.mu + (valid ? j : 0) * n; const double* yj = a.y + (valid ? j : 0) * n;
+    constexpr int PD_RB = 4;
+    float yv[PD_RB], fv[PD_RB], mv[PD_RB], nv[PD_RB];
+    int parts[PD_RB];
+    double yd[PD_RB], fd[PD_RB], md[PD_RB];
+    const int pmax = (int)((((r_end < n ? r_end : n) + RS_KC - 1) / RS_KC));               // (uniform bound: the part's last row)
+    auto issue_rows = [&](const int64_t i0) {
+#pragma unroll
+        for (int e = 0; e < PD_RB; ++e) {
+            const int64_t i = i0 + 256 * e;
+            const bool in = valid && i < r_end;
+            yd[e] = in ? yj[i] : __builtin_nan(""); fd[e] = in ? fj[i] : 0.0; md[e] = in ? mj[i] : 0.0;
+            parts[e] = 0;
+            if (in) {
+                const int64_t grp = (i / RS_ROWS) * RS_ROWS;
+                const int64_t kall = (grp + RS_ROWS < n) ? grp + RS_ROWS : n;
+                parts[e] = (int)((kall + RS_KC - 1) / RS_KC);
+            }
+        }
+    };
+    auto finish_rows = [&](const int64_t i0) {
+        const float* pb = a.part32 + (int64_t)c * n + i0;
+        const int64_t pstep = (int64_t)RS3_CAND * n;
+#pragma unroll
+        for (int e = 0; e < PD_RB; ++e) { yv[e] = (float)yd[e]; fv[e] = (float)fd[e]; mv[e] = (float)md[e]; nv[e] = 0.0f; }
+        for (int q0 = 0; q0 < pmax; q0 += 4) {                 // (sixteen loads in flight, not sixteen round trips)
+            float t4[PD_RB][4];
+#pragma unroll
+            for (int e = 0; e < PD_RB; ++e)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    t4[e][u] = (q0 + u < parts[e]) ? pb[(int64_t)(q0 + u) * pstep + 256 * e] : 0.0f;
+#pragma unroll
+            for (int e = 0; e < PD_RB; ++e)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) nv[e] += t4[e][u];
+        }
+    };
+    issue_rows(r_beg + tid);
+    if (wv == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) uL[lane + 64 * k] = uval[k];
+        // (one wave: its LDS accesses execute in order; the wait only keeps the compiler from moving them)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // The bracket walk (src/draw-f.cpp:33-36, 50-56) from the stream alone, every point as if all before it were rejected
+        // -- by EVERY lane of the wave alike (uniform control flow, LDS broadcasts), lane t keeping point t for its cos / sin.
+        int uidx = 1; bool bad = false;                              // (uL[0] = u of :28: its logarithm is wave 1's)
+        auto next_u = [&]() -> double { const double x = uL[uidx]; ++uidx; if (x != x) { bad = true; return 0.5; } return x; };
+        double eps_min = 0.0, eps_max = GP_2PI;
+        double eps = eps_min + (eps_max - eps_min) * next_u();
+        eps_min = eps - GP_2PI;
+        const int t_beg = rnd * PD_T;
+        for (int t = 0; t < t_beg; ++t) {                            // (rounds this item has already lost)
+            if (eps < 0.0) eps_min = eps; else eps_max = eps;
+            if (eps_min == eps_max) eps = eps_min; else eps = eps_min + (eps_max - eps_min) * next_u();
+        }
+        double my_eps = 0.0, my_rec = 0.0;
+#pragma unroll
+        for (int t = 0; t < PD_T; ++t) {
+            if (lane == t) { my_eps = eps; my_rec = bad ? -1.0 : (double)uidx; }
+            if (eps < 0.0) eps_min = eps; else eps_max = eps;       // :50-55
+            if (eps_min == eps_max) eps = eps_min;                  // R::runif(a, a) = a, nothing consumed
+            else eps = eps_min + (eps_max - eps_min) * next_u();    // :56
+        }
+        if (lane < PD_T) {
+            double sn, cn;
+            sincos(my_eps, &sn, &cn);
+            cs[lane] = cn; cs[PD_T + lane] = sn; rec[lane] = my_rec;
+        }
+        if (lane == 0) rec[PD_T + 1] = valid ? 1.0 : 0.0;
+    } else if (tid == 64) {
+        rec[PD_T] = (valid && p0 < a.cap) ? log(a.U[p0]) : 0.0;       // log(u), :28-29
+    }
+    finish_rows(r_beg + tid);
+    __syncthreads();
+    stamp();
+    // the terms: single precision throughout (argument, exp, log, and the sum over this thread's few rows) -- what comes out
+    // is a PREDICTION; per row 1e-7 relative, the same order as the single-precision nu
+    float acc[PD_V];
+#pragma unroll
+    for (int v = 0; v < PD_V; ++v) acc[v] = 0.0f;
+    {
+        float ct[PD_T], st[PD_T];
+#pragma unroll
+        for (int t = 0; t < PD_T; ++t) { ct[t] = (float)cs[t]; st[t] = (float)cs[PD_T + t]; }
+        auto term = [](float arg) -> float { const float x = fabsf(arg); return (arg < 0.0f ? x : 0.0f) + __logf(1.0f + __expf(-x)); };
+        for (int64_t i0 = r_beg + tid; i0 < r_end; i0 += 256 * PD_RB) {
+            if (i0 != r_beg + tid) { issue_rows(i0); finish_rows(i0); }
+#pragma unroll
+            for (int e = 0; e < PD_RB; ++e) {
+                if (yv[e] == yv[e]) {
+                    acc[0] += term(yv[e] * (fv[e] + mv[e]));
+#pragma unroll
+                    for (int t = 0; t < PD_T; ++t) acc[1 + t] += term(yv[e] * ((fv[e] * ct[t] + nv[e] * st[t]) + mv[e]));
+                }
+            }
+        }
+    }
+    stamp();
+    // the work-group's PD_V sums: through LDS (sred[v][thread]), 16 threads per sum, then one thread per sum -- fixed order
+    {
+        float* sred = reinterpret_cast<float*>(pd_pad);          // PD_V x 256 floats of the dynamic LDS
+#pragma unroll
+        for (int v = 0; v < PD_V; ++v) sred[v * 256 + tid] = acc[v];
+        __syncthreads();
+        double* sred2 = pd_pad + (PD_V * 256) / 2 + 8;           // PD_V x 16 doubles behind it
+        for (int x = tid; x < PD_V * 16; x += 256) {
+            const int v = x >> 4, ch = x & 15;
+            double r = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) r += (double)sred[v * 256 + 16 * ch + q];
+            sred2[x] = r;
+        }
+        __syncthreads();
+        if (tid < PD_V) {
+            double r = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) r += sred2[tid * 16 + q];
+            __hip_atomic_store(a.dec_part + (size_t)blockIdx.x * PD_V + tid, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (p == 0 && tid >= 64 && tid < 64 + PD_REC)
+        __hip_atomic_store(a.dec_rec + (size_t)c * PD_REC + (tid - 64), rec[tid - 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_old = __hip_atomic_fetch_add(a.dec_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    stamp();
+    if ((s_old % (unsigned)gridDim.x) != (unsigned)gridDim.x - 1u) return;      // not the last to arrive
+    long long* tr2 = (a.trace && tid == 0) ? a.trace + 32 : nullptr;             // (debug stamps of the LAST ARRIVER: absolute clock)
+    if (tr2) { tr2[0] = (long long)wall_clock64(); tr2[4] = blockIdx.x; }
+    // ---- the last work-group: every part is in memory (each storing wave waited for its write-through stores before its
+    // work-group's ticket)
+    // (MI355X_MICROARCH.md, hand-offs measured with sc1 loads in place of the acquire, first row: one lane of each storing
+    // work-group adds to ONE counter after every storing wave's vmcnt(0) wait and its barrier; the work-group whose add came
+    // last loads after that add has returned and a barrier; stores and loads all 8-byte sc1; hipMalloc memory; one work-group
+    // per compute unit -- which the dynamic LDS of this launch enforces)
+    {
+        // (all of this thread's loads in flight together: a write-through line of another XCD is a trip to memory)
+        constexpr int NX = (RS3_CAND * PD_V + 255) / 256, NR = (RS3_CAND * PD_REC + 255) / 256;
+        double pv[NX][PD_PARTS], rv[NR];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int x = tid + 256 * k, cc = x / PD_V, v = x % PD_V;
+#pragma unroll
+            for (int q = 0; q < PD_PARTS; ++q)
+                pv[k][q] = (x < RS3_CAND * PD_V) ? __hip_atomic_load(a.dec_part + ((size_t)(cc * PD_PARTS + q)) * PD_V + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int x = tid + 256 * k;
+            rv[k] = (x < RS3_CAND * PD_REC) ? __hip_atomic_load(a.dec_rec + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int x = tid + 256 * k;
+            double r = 0.0;
+#pragma unroll
+            for (int q = 0; q < PD_PARTS; ++q) r += pv[k][q];
+            if (x < RS3_CAND * PD_V) tot[x / PD_V][x % PD_V] = r;
+        }
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int x = tid + 256 * k;
+            if (x < RS3_CAND * PD_REC) recs[x / PD_REC][x % PD_REC] = rv[k];
+        }
+    }
+    __syncthreads();
+    if (tr2) tr2[1] = (long long)wall_clock64();
+    if (tid < RS3_CAND) { hitv[tid] = 99; nanv[tid] = 99; }
+    __syncthreads();
+    // every (candidate, point) comparison side by side: the first point above the slice level (:45-47), the first NaN
+    for (int x = tid; x < RS3_CAND * PD_T; x += 256) {
+        const int cc = x / PD_T, t = x % PD_T;
+        const double llp = -tot[cc][1 + t];
+        const double log_y = -tot[cc][0] + recs[cc][PD_T];                    // draw-f.cpp:28-29
+        if (llp > log_y) atomicMin(&hitv[cc], t);
+        else if (llp != llp) atomicMin(&nanv[cc], t);
+    }
+    __syncthreads();
+    stamp();
+    if (tid != 0) return;
+    const int ns = ((int64_t)a.m - (int64_t)item0 < RS3_SLOTS) ? (int)((int64_t)a.m - (int64_t)item0) : RS3_SLOTS;
+    int usum = 0, resolved = 0, stall = 0;
+    uint64_t cur = start, next_round = 0;
+    for (int gg = 0; gg < ns; ++gg) {
+        int col = 0;
+        if (gg == 1) { if (usum >= a.lim1) break; col = 1 + usum; }
+        if (gg == 2) { if (usum >= a.lim2) break; col = 16 + usum; }
+        const int64_t jj = (int64_t)item0 + gg;
+        if (recs[col][PD_T + 1] == 0.0) { stall = 1; break; }               // past the window: the exact phase reports it if it is real
+        const int rg = (gg == 0) ? (int)round0 : 0;
+        const int hv = hitv[col], nn = nanv[col];
+        const int hit = hv < PD_T ? hv : -1;
+        if (nn < (hit < 0 ? PD_T : hit)) { stall = 1; break; }                 // NaN state: never accepts
+        if (hit < 0) {                                                         // all PD_T points rejected: the next pass goes on from here
+            next_round = (uint64_t)(rg + 1);
+            if (rg + 1 > PD_MAXROUND) stall = 1;
+            break;
+        }
+        if (recs[col][hit] < 0.0) { stall = 1; break; }                       // a uniform past the window
+        int uacc = (int)recs[col][hit];
+        // (tests: gpirt_debug_rs_mispredict makes the predictor wrong on purpose at every mis-th item)
+        if (a.mispredict > 0 && (jj % a.mispredict) == a.mispredict - 1) uacc += 1;
+        cur = cur + 2ull * (uint64_t)n + (uint64_t)uacc;
+        a.k_out[jj] = rg * PD_T + hit;
+        a.posv[jj + 1] = cur;
+        usum += uacc - 2;
+        ++resolved;
+    }
+    a.anchor[0] = item0 + (uint64_t)resolved;
+    a.anchor[1] = cur;
+    a.anchor[4] = next_round;
+    if (stall) a.anchor[3] = 1;
+    if (tr2) tr2[2] = (long long)wall_clock64();
+    stamp();
+    if (tr) a.trace[15 + (blockIdx.x == 0 ? 0 : 16)] = ti;
+}
+
 // the predictor starts where the exact state stands
 __global__ void rs_pred_start_kernel(const uint64_t* __restrict__ anchor, uint64_t* __restrict__ anchorP)
 {
-    anchorP[0] = anchor[0]; anchorP[1] = anchor[1]; anchorP[2] = anchor[2]; anchorP[3] = 0;
+    anchorP[0] = anchor[0]; anchorP[1] = anchor[1]; anchorP[2] = anchor[2]; anchorP[3] = 0; anchorP[4] = 0;
 }
 
 // Z[:, j - j0] = the normals of item j at its predicted start, j in [j0, predicted); zeros behind
@@ -315,6 +601,19 @@ int launch_rs3p_products(hipStream_t stream, const Rs3Args& a)
 {
     if (a.nunits <= 0) return 0;
     hipLaunchKernelGGL(rs3p_products_kernel, dim3((unsigned)a.nunits), dim3(256), 0, stream, a);
+    GP_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_rs3p_decide(hipStream_t stream, const Rs3Args& a)
+{
+    static bool attr_set = false;
+    constexpr int pad = 96 * 1024;        // with the static LDS: more than half a compute unit's 160 KB -> one work-group per CU
+    if (!attr_set) {
+        GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rs3p_decide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, pad));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(rs3p_decide_kernel, dim3(RS3_CAND * PD_PARTS), dim3(256), pad, stream, a);
     GP_HIP(hipGetLastError());
     return 0;
 }

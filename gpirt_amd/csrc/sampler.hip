@@ -116,6 +116,7 @@ struct gpirt_sampler_s {
     // word, what the verification leaves per item, ctl = [first item not committed, mispredictions, predictor stalls, passes]
     float *Lt32 = nullptr, *rs_part32 = nullptr;
     uint64_t *anchorP = nullptr, *rs_ctl = nullptr, *rs_posP = nullptr;
+    double *rs_dec_part = nullptr, *rs_dec_rec = nullptr; unsigned* rs_dec_ticket = nullptr;
     int *rs_kpred = nullptr, *rs_kv = nullptr, *rs_used = nullptr, *rs_ierr = nullptr, *rs_errP = nullptr;
     // bookkeeping
     int iter = 0;                     // completed iterations
@@ -456,9 +457,12 @@ int do_draw_f(gpirt_sampler_s* s)
         int64_t count = (left + RS3_SLOTS - 1) / RS3_SLOTS + left / 40 + 2;
         if (pass > 4 * m + 64) { set_error("R-stream replay: draw_f made no progress"); return GPIRT_E_NUMERIC; }   // (a pass resolves >= 1 item)
         if (predict) {
+            // (a slice loop that rejects 16 points in a row costs a pass of its own: one item in ten at 8192 x 1024)
+            if (h->cfg.rs_predict != 3) count = (left + RS3_SLOTS - 1) / RS3_SLOTS + left / 8 + 4;
             Rs3Args ap = a;
             ap.anchor = s->anchorP; ap.pos = s->rs_posP; ap.k_out = s->rs_kpred; ap.err = s->rs_errP;
             ap.Lt32 = s->Lt32; ap.nk8 = rs32_tile_octs(n); ap.part32 = s->rs_part32; ap.mispredict = h->rs_mispredict;
+            ap.dec_part = s->rs_dec_part; ap.dec_rec = s->rs_dec_rec; ap.dec_ticket = s->rs_dec_ticket;
             GP_TRY(launch_rs_pred_start(st, s->anchor, s->anchorP));
             for (int64_t q = 0; q < count; ++q, ++pass) {
                 s->rs_tag += 1ull << 20;
@@ -468,7 +472,7 @@ int do_draw_f(gpirt_sampler_s* s)
                 GP_TRY(prof_pair_begin(h, st, pp));
                 GP_TRY(launch_rs3p_products(st, ap));
                 GP_TRY(prof_pair_end(h, st, pp, 4, 2.0 * RS3_CAND * 0.5 * (double)n * (double)(n + 1), 4.0 * 0.5 * (double)n * (double)(n + 1)));
-                GP_TRY(launch_rs3_slice(st, ap));
+                GP_TRY(h->cfg.rs_predict == 3 ? launch_rs3_slice(st, ap) : launch_rs3p_decide(st, ap));
             }
             // phase B: the items [done, predicted) at their predicted starts, exactly
             const int64_t mc = m - done;
@@ -935,10 +939,12 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
             hipMemsetAsync(s->rs_part, 0, sizeof(double) * parts * RS3_CAND * (size_t)n, st);
             hipMemsetAsync(s->anchor, 0, 4 * sizeof(uint64_t), st);
             GP_A(s->Lt32, rs32_tile_floats(n));   GP_A(s->rs_part32, parts * RS3_CAND * (size_t)n);
-            GP_A(s->anchorP, 4);     GP_A(s->rs_ctl, 8);     GP_A(s->rs_posP, 2);
+            GP_A(s->anchorP, 8);     GP_A(s->rs_ctl, 8);     GP_A(s->rs_posP, 2);
+            GP_A(s->rs_dec_part, (size_t)RS3_CAND * 8 * 17 + 8);  GP_A(s->rs_dec_rec, (size_t)RS3_CAND * 18 + 8);  GP_A(s->rs_dec_ticket, 4);
+            hipMemsetAsync(s->rs_dec_ticket, 0, 4 * sizeof(unsigned), st);
             GP_A(s->rs_kpred, m);    GP_A(s->rs_kv, m);      GP_A(s->rs_used, m);     GP_A(s->rs_ierr, m);    GP_A(s->rs_errP, 4);
             hipMemsetAsync(s->rs_part32, 0, sizeof(float) * parts * RS3_CAND * (size_t)n, st);
-            hipMemsetAsync(s->anchorP, 0, 4 * sizeof(uint64_t), st);
+            hipMemsetAsync(s->anchorP, 0, 8 * sizeof(uint64_t), st);
             hipMemsetAsync(s->rs_ctl, 0, 8 * sizeof(uint64_t), st);
             hipMemsetAsync(s->rs_errP, 0, 4 * sizeof(int), st);
             std::vector<uint32_t> units;

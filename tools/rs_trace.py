@@ -21,13 +21,22 @@ import ctypes as C
 t = np.empty(128, dtype=np.int64)
 _lib.check(lib.gpirt_sampler_get(s._s, b"rs_trace", C.c_void_p(t.ctypes.data), 128))
 _lib.check(lib.gpirt_debug_rs_trace(h._h, -1))
-ns = int(t[63])
-st = t[:ns].astype(float) / 100.0
-print("slice kernel, work-group 0 (us from its start):", np.round(st - st[0], 2).tolist())
-sl = t[32:32 + ns].astype(float) / 100.0
-print("slice kernel, LAST work-group (us from work-group 0's start):", np.round(sl - st[0], 2).tolist())
-for b in range(3):
-    q = t[64 + 8 * b: 64 + 8 * b + 6].astype(float) / 100.0
-    print(f"products work-group {b} (0 / middle / last full): anchor {q[1]-q[0]:.2f}, windows staged +{q[2]-q[1]:.2f}, MFMAs +{q[3]-q[2]:.2f}, "
-          f"barrier +{q[4]-q[3]:.2f}, sum + store +{q[5]-q[4]:.2f}; started {q[0]-t[64]/100.0:.2f} us after work-group 0")
-print("slice kernel started %.2f us after the products' work-group 0" % (st[0] - t[64] / 100.0))
+if os.environ.get("GPIRT_RS_PREDICT") in ("2", "3"):
+    ns = int(t[63])
+    st = t[:ns].astype(float) / 100.0
+    print("slice kernel, work-group 0 (us from its start):", np.round(st - st[0], 2).tolist())
+    sl = t[32:32 + ns].astype(float) / 100.0
+    print("slice kernel, LAST work-group (us from work-group 0's start):", np.round(sl - st[0], 2).tolist())
+    for b in range(3):
+        q = t[64 + 8 * b: 64 + 8 * b + 6].astype(float) / 100.0
+        print(f"products work-group {b} (0 / middle / last full): anchor {q[1]-q[0]:.2f}, windows staged +{q[2]-q[1]:.2f}, MFMAs +{q[3]-q[2]:.2f}, "
+              f"barrier +{q[4]-q[3]:.2f}, sum + store +{q[5]-q[4]:.2f}; started {q[0]-t[64]/100.0:.2f} us after work-group 0")
+    print("slice kernel started %.2f us after the products' work-group 0" % (st[0] - t[64] / 100.0))
+else:
+    # the predictor's decide kernel (rs_predict.hip): start, walk + cos / sin done, terms done, ticket taken [, parts read, decided]
+    for b, name in ((0, "work-group 0"), (16, "the last work-group of the grid")):
+        q = t[b:b + 15].astype(float) / 100.0
+        q = q[q > 0]
+        print(f"decide kernel, {name} (us from its start):", np.round(q - q[0], 2).tolist())
+    print("decide kernel, the LAST ARRIVER (work-group %d): ticket returned %.2f us after work-group 0 started, parts read +%.2f, decided +%.2f; work-group 255 started %.2f us after work-group 0"
+          % (t[36], (t[32] - t[0]) / 100.0, (t[33] - t[32]) / 100.0, (t[34] - t[33]) / 100.0, (t[16] - t[0]) / 100.0))
