@@ -339,8 +339,14 @@ def main():
                 handle.prof_enable(False)
                 sr.check()
                 replay_prof = handle.prof_other(reset=True)["replay_products"]
+                rs_stats = sr.get("rs_stats")
                 ref_rng = {"value": 2.0 / dtr, "iterations": 2, "theta_stabilise": int(stab),
                            "passes_over_L_per_iteration": int(replay_prof[1]), "items_per_pass": (m / replay_prof[1]) if replay_prof[1] else None,
+                           "draw_f": "predict + verify (csrc/rs_predict.hip): the starts of all items in R's stream predicted by passes over a "
+                                     "SINGLE-PRECISION copy of L (three items per pass, 32 candidate starts, 16 trial points each), then every item "
+                                     "computed exactly at its predicted start -- one fp64 triangular MFMA product + all slice loops side by side, the "
+                                     "formula as written -- and committed in order; GPIRT_RS_PREDICT=2: every pass in fp64 (rounds 4-5)",
+                           "mispredictions_found_by_the_verification_so_far": int(rs_stats[1]),
                            "contract": "gpirt_default_options: rng = R-stream replay (item-sequential draw_f), draw_fstar = double_solve "
                                        "as written" + ("; theta_stabilise = 1 because the literal default (0) failed on this problem: "
                                                        + literal_error if stab else "; theta_stabilise = 0 (the literal default)")}
@@ -504,9 +510,11 @@ def main():
                                                   "kernel (tools/theta_clock.py).  The fp64 GEMM it replaces ran 0.52 ms at 0.91 of the fp64 MFMA peak"),
                 # the default contract's draw_f: one pass over L per three items (rs3_products_kernel), HBM-bound
                 "replay_products": _roof_entry(replay_prof, "hbm", PEAK_HBM_GBS, "GB/s",
-                                               "rs3_products_kernel (R-stream replay, gpirt_default_options): bytes = the lower triangle of L, "
-                                               "8 n (n + 1) / 2, per launch; timed in the reference_rng leg of this run (an event pair spans the kernel and ONE "
-                                               "kernel boundary, ~2 us of a ~52 us pass: rocprofv3's per-kernel average is that much shorter)"),
+                                               "rs3p_products_kernel (R-stream replay, gpirt_default_options): the predictor's pass over L as single-precision "
+                                               "tiles; bytes = the lower triangle as floats, 4 n (n + 1) / 2, per launch (the spare passes that find every item "
+                                               "predicted and leave at once are left out, as in rocprofv3's median in profiles/); flops = "
+                                               "2 x 32 candidates x n (n + 1) / 2 on v_mfma_f32_32x32x2_f32 (157 TFLOP/s peak: 16.6 us of a ~30 us pass); "
+                                               "timed in the reference_rng leg of this run"),
                 "note": "HIP events around each launch on its own stream (main or look-ahead side stream) inside the timed region, on "
                         "a sample of the timed steps (the first and the middle one: bracketing every launch of every step costs 4 % "
                         "of the iteration rate); launches of the two streams overlap each other and the panel kernel, so "

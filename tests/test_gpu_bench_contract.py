@@ -29,7 +29,10 @@ def test_bench_json_contract():
     if r["launches"]:
         assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    # the headline of cpu_baseline is the MEASURED leg (all host cores, one whole iteration at the full size, nothing
+    # extrapolated); the reference-shaped single-thread figure, stretched from samples, is the sub-object
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["extrapolated"] is False
+    assert c["single_thread_reference_shaped"]["cores"] == 1 and c["single_thread_reference_shaped"]["extrapolated"] is True
     # what the DEFAULT contract (R-stream replay, everything as written) costs on the same problem, in the same line
     rr = d["config"]["reference_rng"]
     assert "error" not in rr, rr.get("error")             # (a failed default-contract run carries its reason, value None)
