@@ -668,6 +668,11 @@ __global__ __launch_bounds__(320) void rs3_slice_kernel(Rs3Args a)
             }
             __syncthreads();
             rs_stamp(tr, ti++);                                                // terms, partial sums stored
+#ifdef GPIRT_PANEL_FENCES
+            // the fenced reference form of the meeting (`make fences`, tests/test_gpu_fences.py): an agent-scope release in
+            // front of the flag, an acquire behind the poll -- the draws must be the default build's bit for bit
+            if (tid == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
             if (tid == 0) __hip_atomic_store(flg + w, (unsigned long long)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (tid < E) {
                 int spins = 0;
@@ -677,6 +682,10 @@ __global__ __launch_bounds__(320) void rs3_slice_kernel(Rs3Args a)
                     seen = __hip_atomic_load(flg + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 if (seen < tag) expired = 1;
+#ifdef GPIRT_PANEL_FENCES
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
                 // work-group tid's sums, straight behind its flag (nine loads in flight)
                 double t9[V];
 #pragma unroll

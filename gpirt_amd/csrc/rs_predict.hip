@@ -362,10 +362,20 @@ __global__ __launch_bounds__(256) void rs3p_decide_kernel(Rs3Args a)
         __hip_atomic_store(a.dec_rec + (size_t)c * PD_REC + (tid - 64), rec[tid - 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#ifdef GPIRT_PANEL_FENCES
+    // the fenced reference form of the ticket (`make fences`, tests/test_gpu_fences.py): release in front of the add, acquire
+    // behind it in the work-group that arrives last
+    if (tid == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
     if (tid == 0) s_old = __hip_atomic_fetch_add(a.dec_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     stamp();
     if ((s_old % (unsigned)gridDim.x) != (unsigned)gridDim.x - 1u) return;      // not the last to arrive
+#ifdef GPIRT_PANEL_FENCES
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#endif
     long long* tr2 = (a.trace && tid == 0) ? a.trace + 32 : nullptr;             // (debug stamps of the LAST ARRIVER: absolute clock)
     if (tr2) { tr2[0] = (long long)wall_clock64(); tr2[4] = blockIdx.x; }
     // ---- the last work-group: every part is in memory (each storing wave waited for its write-through stores before its

@@ -56,3 +56,26 @@ def test_schedule_switches_leave_the_factor_bit_identical(switch):
     b = _hashes(**{k: v})
     assert len(a) == len(b) == 7
     assert a == b, "\n".join(f"{x}\n{y}" for x, y in zip(a, b) if x != y)
+
+
+def test_fenced_build_replays_r_stream_draws_bit_for_bit():
+    """The meetings of the R-stream replay's draw_f -- the slice kernel's flag meeting (rng_ess.hip) and the predictor's ticket
+    (rs_predict.hip) -- hand partial sums between work-groups with write-through stores, a wait, and sc1 loads.  The second
+    library holds their fenced reference forms (agent-scope release in front of the flag / ticket, acquire behind the poll /
+    in the last arriver): every replayed draw -- f, theta, beta, rejection counts, the generator's position -- must be the
+    default build's bit for bit, with the predictor (GPIRT_RS_PREDICT=1) and without (2), at four shapes."""
+    from gpirt_amd import build
+    lib = build.build_fences()
+
+    def run(libpath):
+        env = dict(os.environ)
+        env.pop("GPIRT_HIP_LIBRARY", None)
+        if libpath:
+            env["GPIRT_HIP_LIBRARY"] = libpath
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rstream_hash.py")], env=env, capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return [ln for ln in r.stdout.splitlines() if ln.startswith("replay")]
+    a, b = run(None), run(lib)
+    assert len(a) == len(b) == 8
+    assert a == b, "\n".join(f"{x}\n{y}" for x, y in zip(a, b) if x != y)
