@@ -925,7 +925,11 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
         GP_A(s->U, s->U_cap);       GP_A(s->U2, s->U_cap);      GP_A(s->S, s->U_cap);      GP_A(s->Sraw, s->U_cap);
         GP_A(s->pos, 2);
         // draw_f, three items per pass (rng_ess.hip)
-        s->spec_ok = n >= RS_SPEC_MIN_N && n <= RS3_MAX_N;
+        // The one-phase slice kernel MEETS: its work-groups (320 threads, ~30 KB of LDS) poll each other's flags, so all of
+        // them must be resident at once -- at most one per compute unit is what the launch can count on beside foreign work.
+        // (The predictor's decide kernel has no such need: a ticket, nobody waits for anybody.)  On a device with fewer
+        // compute units than the grid the replay falls back to the item-by-item form.
+        s->spec_ok = n >= RS_SPEC_MIN_N && n <= RS3_MAX_N && rs3_slice_wgs(n) <= h->n_cu;
         if (s->spec_ok) {
             const size_t parts = (size_t)((n + RS_KC - 1) / RS_KC);
             const size_t nrm = (size_t)s->U_cap + 6 * (size_t)n + 128;        // (the products read up to 6n + 39 past an anchor)

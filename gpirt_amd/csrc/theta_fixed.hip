@@ -354,8 +354,11 @@ int launch_theta_fixed(hipStream_t stream, const double* fstar, int64_t N, int64
                        const void* Y8, void* Gq, void* aux, double* logpost, int64_t ldlp, bool trace, gpirt_handle_t prof)
 {
     if (n <= 0 || N <= 0) return 0;
-    // (the recombination's int64 halves are exact doubles while a plane sum stays below 2^27: a million items)
-    if (m > (1 << 20)) { set_error("theta_fixed: m = %lld is beyond the fixed-point product's range (GPIRT_THETA_FIXED=2 selects the fp64 product)", (long long)m); return GPIRT_E_ARG; }
+    // Every refusal BEFORE anything is enqueued.  The recombination's int64 halves are exact doubles while a plane sum stays
+    // below 2^27 (a million items); the quantiser's grid carries two entries per k-step in grid.y, whose limit is 65535
+    // launches: 2 * ksteps <= 65535 (m <= ~524 000 items) is the bound that bites first.
+    if (m > (1 << 20) || 2 * d.ksteps > 65535) { set_error("theta_fixed: m = %lld is beyond the fixed-point product's range (GPIRT_THETA_FIXED=2 selects the fp64 product)", (long long)m); return GPIRT_E_ARG; }
+    if (d.gblocks != 32) { set_error("theta_fixed: the work-group map is laid out for the reference's 1001-point grid"); return GPIRT_E_ARG; }
     unsigned long long* amax = reinterpret_cast<unsigned long long*>(aux);
     double* scale = reinterpret_cast<double*>(amax + d.gblocks * 32);
     int* ovf = tf_overflow(aux, d);
@@ -371,7 +374,6 @@ int launch_theta_fixed(hipStream_t stream, const double* fstar, int64_t N, int64
     a.Y8 = reinterpret_cast<const unsigned char*>(Y8); a.Gq = reinterpret_cast<const unsigned char*>(Gq); a.scale = scale; a.ovf = ovf;
     a.logpost = logpost; a.ldlp = ldlp; a.n = n; a.N = N; a.ksteps = d.ksteps; a.gblocks = d.gblocks; a.itiles = (int)(d.iblocks / 8);
     a.trace = trace ? tf_trace(aux, d) : nullptr;
-    if (d.gblocks != 32) { set_error("theta_fixed: the work-group map is laid out for the reference's 1001-point grid"); return GPIRT_E_ARG; }
     ProfPair pp;
     if (prof) GP_TRY(prof_pair_begin(prof, stream, pp));
     hipLaunchKernelGGL(tf_mfma_kernel, dim3((unsigned)(32 * a.itiles)), dim3(256), 2 * TF_STAGE, stream, a);
