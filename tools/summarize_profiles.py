@@ -3,7 +3,7 @@ usage: python tools/summarize_profiles.py [raw dir] [tag]"""
 import collections, csv, glob, json, os, shutil, sys
 
 raw = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/profiles_raw"
-tag = sys.argv[2] if len(sys.argv) > 2 else "r05"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r06"
 SYRK = {"gemm_f64_kernel<false, true, 128, 8": "128-tile", "gemm_f64_kernel<false, true, 64, 8": "64-tile",
         "gemm_f64_kernel<false, true, 64, 16": "in-panel 64-tile"}
 PANEL = "panel_ll_kernel"
@@ -124,7 +124,7 @@ with open(f"profiles/{tag}_summary.md", "a") as f:
         lines = [l for l in open(raw + "/stats_ref.log") if l.startswith("{")]
         bench_ref = json.loads(lines[-1]) if lines else None
     for name, key in (("draw_f_trmm", "gemm_f64_kernel<false, false, 128, 0"), ("theta_int8_product", "tf_mfma_kernel"),
-                      ("replay_products", "rs3_products_kernel")):
+                      ("replay_products", "rs3p_products_kernel")):
         if name == "replay_products":
             # from the run WITH the default-contract leg; rocprofv3's average over the REAL passes of that run (spare passes,
             # which find every item done and leave at once, are not passes over L -- bench.py's events leave them out too)
@@ -165,7 +165,7 @@ if rstats:
 
     def one(name, counter):
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(newest(f"{raw}/{name}/**/*counter_collection.csv")))
-                if "rs3_products_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+                if "rs3p_products_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter]
         big = [v for v in vals if v > 0.5 * max(vals)] if vals else []       # (spare passes leave at once: not a pass over L)
         return (sum(big) / len(big), len(big)) if big else (None, 0)
 
@@ -174,29 +174,37 @@ if rstats:
     busy, _ = one("replay_pmc_mfma", "SQ_VALU_MFMA_BUSY_CYCLES")
     gui, _ = one("replay_pmc_mfma", "GRBM_GUI_ACTIVE")
     n_ = 8192
-    alg = 8.0 * n_ * (n_ + 1) / 2
+    alg = 4.0 * n_ * (n_ + 1) / 2
     with open(f"profiles/{tag}_replay_summary.md", "w") as f:
         f.write(f"# Round {tag[1:]}: the default contract (R-stream replay), `rocprofv3 --kernel-trace --stats -- python3 tools/rstream_step.py 8192 1024` (library commit {commit})\n\n")
-        f.write("Init + five iterations at 8192 x 1024.  draw_f resolves up to THREE items per pass over L (rng_ess.hip, DESIGN.md section 2): "
-                "`rs3_products_kernel` = L z for the pass's 32 candidate columns (1 + 15 + 16), `rs3_slice_kernel` = the three slice loops, "
-                "eight trial points per meeting; `rs3_begin_kernel` = the normal that starts at every position of the iteration's window; "
-                "`rs_tile_kernel` = L re-tiled once per iteration; `rs_unpack_kernel` = Mersenne-Twister words -> unif_rand() values.\n\n")
+        f.write("Init + five iterations at 8192 x 1024.  draw_f is PREDICT + VERIFY (csrc/rs_predict.hip, DESIGN.md section 2): the starts of all items "
+                "in R's stream are predicted by passes over a single-precision copy of L -- `rs3p_products_kernel` = L32 z for the pass's 32 candidate "
+                "starts (1 + 15 + 16) of three items, `rs3p_decide_kernel` = the first 16 trial points of every candidate side by side, one ticket, the "
+                "last work-group decides the three slots -- then `rs_gather_kernel` + ONE triangular fp64 product (`gemm_f64_kernel<false, false, 128, ...>`) "
+                "+ `rs_verify_kernel` (every slice loop exactly, side by side) + `rs_commit_*` (accept in order up to the first misprediction).  "
+                "`rs3_begin_kernel` = the normal that starts at every position of the iteration's window; `rs32_tile_kernel` / `rs_tile_kernel` = L re-tiled "
+                "once per iteration (floats for the predictor, doubles for the one-phase fallback); `rs_unpack_kernel` = Mersenne-Twister words -> unif_rand() values.\n\n")
         for l in log:
             f.write(l + "\n\n")
         f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
         for r in rrows[:14]:
             f.write(f"| `{short(r['Name'])[:80]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.3f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |\n")
-        st = stat_row(rrows, "rs3_products_kernel")
+        st = stat_row(rrows, "rs3p_products_kernel")
         if st:
-            # the spare passes (every item already done) leave at once: the average over REAL passes is what the roofline needs
+            # the spare passes (every item already predicted) leave at once: the average over REAL passes is what the roofline needs
             tr = newest(raw + "/replay_stats/**/*kernel_trace.csv")
-            dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(tr)) if "rs3_products_kernel" in r["Kernel_Name"]]
+            trows = list(csv.DictReader(open(tr)))
+            dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in trows if "rs3p_products_kernel" in r["Kernel_Name"]]
             real = [d for d in dur if d > 0.5 * max(dur)]
             avg_us = sum(real) / len(real)
-            f.write(f"\n`rs3_products_kernel`: {len(real)} real passes of {len(dur)} launches (the others find every item done and leave at once), "
-                    f"{avg_us:.1f} us per real pass -> {alg / avg_us / 1e6:.2f} TB/s of L (algorithmic 8 n (n + 1) / 2 = {alg / 1e6:.0f} MB) = "
+            f.write(f"\n`rs3p_products_kernel`: {len(real)} real passes of {len(dur)} launches (the others find every item predicted and leave at once), "
+                    f"{avg_us:.1f} us per real pass -> {alg / avg_us / 1e6:.2f} TB/s of L as floats (algorithmic 4 n (n + 1) / 2 = {alg / 1e6:.0f} MB) = "
                     f"{alg / avg_us / 1e6 / 8.0:.3f} of the 8 TB/s HBM peak; its 2 x 32 x n (n + 1) / 2 = {64 * n_ * (n_ + 1) / 2 / 1e9:.2f} GFLOP per pass = "
-                    f"{64 * n_ * (n_ + 1) / 2 / avg_us / 1e6:.1f} TFLOP/s = {64 * n_ * (n_ + 1) / 2 / avg_us / 1e6 / 78.6:.3f} of the fp64 MFMA peak.\n")
+                    f"{64 * n_ * (n_ + 1) / 2 / avg_us / 1e6:.1f} TFLOP/s = {64 * n_ * (n_ + 1) / 2 / avg_us / 1e6 / 157.3:.3f} of the 157.3 TFLOP/s f32-input MFMA peak.\n")
+            dd = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in trows if "rs3p_decide_kernel" in r["Kernel_Name"]]
+            dreal = [d for d in dd if d > 0.5 * max(dd)] if dd else []
+            if dreal:
+                f.write(f"\n`rs3p_decide_kernel`: {sum(dreal) / len(dreal):.1f} us per real pass ({len(dreal)} of {len(dd)} launches).\n")
         if fk:
             f.write(f"\nPMC passes of `tools/rstream_step.py 8192 128` (separate runs), averages over the {nf} real passes: FETCH_SIZE {fk:.0f} KB raw "
                     f"(x 2 = {2 * fk * 1024 / 1e6:.0f} MB: gfx950 tallies 128-B requests at 64 B), WRITE_SIZE {wk:.0f} KB ({wk * 1024 / 1e6:.1f} MB: the parts of the "
