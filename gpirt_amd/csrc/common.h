@@ -126,7 +126,7 @@ struct gpirt_handle_s {
     // Samplers borrow the handle (its stream, workspaces, side handle).  A handle destroyed while samplers still live --
     // e.g. a host language tearing objects down in arbitrary order at exit -- is only marked (zombie) and freed by the last
     // sampler's destroy: round 3's `std::bad_variant_access` abort at interpreter exit was gpirt_sampler_destroy draining the
-    // stream of a handle that had already been freed.
+    // stream of a handle that had already been freed (DESIGN_HISTORY.md section 8.1).
     int          live_samplers = 0;
     bool         zombie = false;
     int          guard_fallbacks = 0;

@@ -143,7 +143,7 @@ int factor_panel(gpirt_handle_t h, hipStream_t stream, double* A, int64_t n, int
             const int64_t k1 = (k0 + nbp < c1) ? k0 + nbp : c1;
             if (!(part == 2 && k0 == K0)) GP_TRY(launch_panel_ll(h, stream, A, n, lda, k0, k1));
             if (part == 1) return 0;
-#ifndef GPIRT_EXP_SKIP_INPANEL  // (timing experiment, DESIGN.md section 10: a WRONG factor without this product -- what would absorbing it buy?)
+#ifndef GPIRT_EXP_SKIP_INPANEL  // (timing experiment, DESIGN_HISTORY.md section 10: a WRONG factor without this product -- what would absorbing it buy?)
             if (k1 < c1)      // A[k1:n, k1:c1] -= A[k1:n, k0:k1] A[k1:c1, k0:k1]^T
                 GP_TRY(panel_update(h, stream, n - k1, c1 - k1, k1 - k0, A + k1 + k0 * lda, lda, A + k1 + k1 * lda, lda));
 #endif

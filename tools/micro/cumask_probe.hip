@@ -1,4 +1,4 @@
-// Do CU-masked streams partition the chip the way a scheduler would need?  
+// Do CU-masked streams partition the chip the way a scheduler would need?  (DESIGN_HISTORY.md section 10)
 //   hog:   a long kernel (many 256-thread work-groups, ~100 us each, fills every CU it may use) on a stream whose CU
 //          mask excludes R CUs (every 8th... see mask below);
 //   probe: 32 work-groups that each need a WHOLE CU (150 KB of LDS), launched on an unmasked high-priority stream
