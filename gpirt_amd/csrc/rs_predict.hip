@@ -67,8 +67,17 @@ __global__ __launch_bounds__(256) void rs32_tile_kernel(const double* __restrict
 // unconditionally: the compiler's vmcnt bookkeeping then lets step s start when ITS kilobyte has arrived (a load under a
 // run-time condition anywhere in the loop makes it wait for every outstanding load at every step: 44 instead of ~20 us per pass).
 constexpr int P32_STEPS = RS_KC / 32;
+// (steps of L in flight per wave / work-groups per compute unit: 4 ... 16 / 5 ... 8 all measure 30.1-32.3 us per pass -- the pass is
+//  bound by the f32 MFMAs at the clock the chip holds under them (26 us with NO loads of L) and by the 134 MB (25 us with NO MFMAs)
+//  alike, gpurun_out/r6f, r6u)
+#ifndef P32_RINGF
+#define P32_RINGF 16
+#endif
+#ifndef P32_OCC
+#define P32_OCC 5
+#endif
 template <bool FULL>
-__device__ __forceinline__ void rs3p_product_unit(const Rs3Args& a, const uint64_t base, const int bx, const int by, float* lds)
+__device__ __forceinline__ void rs3p_product_unit(const Rs3Args& a, const uint64_t base, const int bx, const int by, float* lds, long long* tr)
 {
     const int tid = threadIdx.x, lane = tid & 63, kq = tid >> 6, c = lane & 31, hh = lane >> 5;
     const int64_t n = a.n;
@@ -94,7 +103,7 @@ __device__ __forceinline__ void rs3p_product_unit(const Rs3Args& a, const uint64
     const double* N0 = a.Nrm + base + 2ull * (uint64_t)k0;
     const double* N1 = N0 + item_step;
     const double* N2 = N1 + item_step;
-    float4 lv[P32_STEPS];
+    float4 lv[P32_RINGF];
     if (FULL) {
         // the windows' loads go out first (L2 hits), the wave's sixteen kilobytes of L straight behind them
         constexpr int C0 = RS_KC / 256, C1 = (2 * RS_KC + 16 + 255) / 256, C2 = (2 * RS_KC + 32 + 255) / 256;
@@ -106,7 +115,7 @@ __device__ __forceinline__ void rs3p_product_unit(const Rs3Args& a, const uint64
 #pragma unroll
         for (int q = 0; q < C2; ++q) { const int x = tid + 256 * q; w2[q] = N2[x < 2 * RS_KC + 32 ? x : 0]; }
 #pragma unroll
-        for (int u = 0; u < P32_STEPS; ++u) lv[u] = *reinterpret_cast<const float4*>(Lp + (int64_t)u * 256);
+        for (int u = 0; u < P32_RINGF; ++u) lv[u] = *reinterpret_cast<const float4*>(Lp + (int64_t)u * 256);
 #pragma unroll
         for (int q = 0; q < C0; ++q) W0[tid + 256 * q] = (float)w0[q];
 #pragma unroll
@@ -122,9 +131,10 @@ __device__ __forceinline__ void rs3p_product_unit(const Rs3Args& a, const uint64
         for (int x = tid; x < x1; x += 256) W1[x] = (float)N1[x];
         for (int x = tid; x < x2; x += 256) W2[x] = (float)N2[x];
 #pragma unroll
-        for (int u = 0; u < P32_STEPS; ++u) lv[u] = (u < steps) ? *reinterpret_cast<const float4*>(Lp + (int64_t)u * 256) : float4{ 0.f, 0.f, 0.f, 0.f };
+        for (int u = 0; u < P32_RINGF; ++u) lv[u] = (u < steps) ? *reinterpret_cast<const float4*>(Lp + (int64_t)u * 256) : float4{ 0.f, 0.f, 0.f, 0.f };
     }
     __syncthreads();
+    if (tr) tr[1] = (long long)wall_clock64();                 // windows staged
     // lane's candidate: column kk of the part is at Zb[zs * kk]
     const float* Zb = (c == 0) ? W0 : (c < 16 ? W1 + (c - 1) : W2 + (c - 16));
     const int zs = (c == 0) ? 1 : 2;
@@ -135,15 +145,23 @@ __device__ __forceinline__ void rs3p_product_unit(const Rs3Args& a, const uint64
 #pragma unroll
     for (int s = 0; s < P32_STEPS; ++s) {
         if (FULL || s < steps) {                                 // (uniform over the wave)
+            const int u = s % P32_RINGF;
+            const float4 l = lv[u];
+            if (s + P32_RINGF < P32_STEPS) {
+                if (FULL) lv[u] = *reinterpret_cast<const float4*>(Lp + (int64_t)(s + P32_RINGF) * 256);   // (static: no run-time condition)
+                else lv[u] = (s + P32_RINGF < steps) ? *reinterpret_cast<const float4*>(Lp + (int64_t)(s + P32_RINGF) * 256) : float4{ 0.f, 0.f, 0.f, 0.f };
+            }
             const float z0 = z[zs * (8 * s)], z1 = z[zs * (8 * s + 1)], z2 = z[zs * (8 * s + 2)], z3 = z[zs * (8 * s + 3)];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(z0, lv[s].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(z1, lv[s].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(z2, lv[s].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(z3, lv[s].w, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(z0, l.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(z1, l.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(z2, l.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(z3, l.w, acc, 0, 0, 0);
         }
     }
     // acc[4 q + r] = candidate 8 q + 4 hh + r, row r0 + c.  The quarters meet in LDS: red[kq][cand][row]
+    if (tr) tr[2] = (long long)wall_clock64();                 // this wave's MFMAs issued
     __syncthreads();                                            // (the windows are no longer read)
+    if (tr) tr[3] = (long long)wall_clock64();
     float* red = lds;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -157,9 +175,10 @@ __device__ __forceinline__ void rs3p_product_unit(const Rs3Args& a, const uint64
         const float v = ((red[x] + red[1024 + x]) + red[2048 + x]) + red[3072 + x];
         if (r0 + row < n) out[(int64_t)cand * n + row] = v;
     }
+    if (tr) tr[4] = (long long)wall_clock64();
 }
 
-__global__ __launch_bounds__(256, 5) void rs3p_products_kernel(Rs3Args a)
+__global__ __launch_bounds__(256, P32_OCC) void rs3p_products_kernel(Rs3Args a)
 {
     // windows: W0 RS_KC floats | W1 2 RS_KC + 16 | W2 2 RS_KC + 32; then the four waves' 32 x 32 accumulators (16 KB)
     __shared__ __attribute__((aligned(16))) float lds[4 * 1024 + 64];
@@ -167,8 +186,12 @@ __global__ __launch_bounds__(256, 5) void rs3p_products_kernel(Rs3Args a)
     const uint32_t unit = a.units[blockIdx.x];
     if (item0 >= (uint64_t)a.m || stalled != 0) return;       // every item is predicted, or the predictor has stalled
     const int bx = (int)(unit & 0xffffu), by = (int)(unit >> 16);
-    if ((int)blockIdx.x < a.nfull) rs3p_product_unit<true>(a, base, bx, by, lds);
-    else                           rs3p_product_unit<false>(a, base, bx, by, lds);
+    // debug stamps (gpirt_debug_rs_trace; tools/rs_trace.py): first / middle / last full unit, 8 words each from trace[64]
+    long long* tr = (a.trace && threadIdx.x == 0 && (blockIdx.x == 0 || (int)blockIdx.x == a.nfull / 2 || (int)blockIdx.x == a.nfull - 1))
+                        ? a.trace + 64 + 8 * (blockIdx.x == 0 ? 0 : (int)blockIdx.x == a.nfull / 2 ? 1 : 2) : nullptr;
+    if (tr) tr[0] = (long long)wall_clock64();
+    if ((int)blockIdx.x < a.nfull) rs3p_product_unit<true>(a, base, bx, by, lds, tr);
+    else                           rs3p_product_unit<false>(a, base, bx, by, lds, tr);
 }
 
 // ---- the predictor's slice loops: ONE meeting per pass -------------------------------------------------------------------

@@ -38,5 +38,9 @@ else:
         q = t[b:b + 15].astype(float) / 100.0
         q = q[q > 0]
         print(f"decide kernel, {name} (us from its start):", np.round(q - q[0], 2).tolist())
+    for b in range(3):
+        q = t[64 + 8 * b: 64 + 8 * b + 5].astype(float) / 100.0
+        print(f"predictor products unit {b} (first / middle / last full): windows staged +{q[1]-q[0]:.2f}, MFMAs issued +{q[2]-q[1]:.2f}, barrier +{q[3]-q[2]:.2f}, "
+              f"sum + store +{q[4]-q[3]:.2f}; started {q[0]-t[64]/100.0:.2f} us after unit 0")
     print("decide kernel, the LAST ARRIVER (work-group %d): ticket returned %.2f us after work-group 0 started, parts read +%.2f, decided +%.2f; work-group 255 started %.2f us after work-group 0"
           % (t[36], (t[32] - t[0]) / 100.0, (t[33] - t[32]) / 100.0, (t[34] - t[33]) / 100.0, (t[16] - t[0]) / 100.0))
