@@ -347,6 +347,7 @@ def main():
                                      "computed exactly at its predicted start -- one fp64 triangular MFMA product + all slice loops side by side, the "
                                      "formula as written -- and committed in order; GPIRT_RS_PREDICT=2: every pass in fp64 (rounds 4-5)",
                            "mispredictions_found_by_the_verification_so_far": int(rs_stats[1]),
+                           "predictor_stalls_handed_to_the_one_phase_replay": int(rs_stats[2]),
                            "contract": "gpirt_default_options: rng = R-stream replay (item-sequential draw_f), draw_fstar = double_solve "
                                        "as written" + ("; theta_stabilise = 1 because the literal default (0) failed on this problem: "
                                                        + literal_error if stab else "; theta_stabilise = 0 (the literal default)")}

@@ -262,39 +262,38 @@ __global__ __launch_bounds__(256) void rs3p_decide_kernel(Rs3Args a)
     const double* fj = a.f + (valid ? j : 0) * n; const double* mj = a.mu + (valid ? j : 0) * n; const double* yj = a.y + (valid ? j : 0) * n;
     constexpr int PD_RB = 4;
     float yv[PD_RB], fv[PD_RB], mv[PD_RB], nv[PD_RB];
-    int parts[PD_RB];
     double yd[PD_RB], fd[PD_RB], md[PD_RB];
-    const int pmax = (int)((((r_end < n ? r_end : n) + RS_KC - 1) / RS_KC));               // (uniform bound: the part's last row)
+    // parts of the candidate's column that can hold something for this work-group's rows: the parts BEHIND a row's own columns
+    // were never written by the products and still hold the zeros of the sampler's creation, so every row simply adds pmax parts
+    const int pmax = (int)((((r_end < n ? r_end : n) + RS_KC - 1) / RS_KC));
+    const int64_t pstep = (int64_t)RS3_CAND * n;
     auto issue_rows = [&](const int64_t i0) {
 #pragma unroll
         for (int e = 0; e < PD_RB; ++e) {
             const int64_t i = i0 + 256 * e;
             const bool in = valid && i < r_end;
             yd[e] = in ? yj[i] : __builtin_nan(""); fd[e] = in ? fj[i] : 0.0; md[e] = in ? mj[i] : 0.0;
-            parts[e] = 0;
-            if (in) {
-                const int64_t grp = (i / RS_ROWS) * RS_ROWS;
-                const int64_t kall = (grp + RS_ROWS < n) ? grp + RS_ROWS : n;
-                parts[e] = (int)((kall + RS_KC - 1) / RS_KC);
-            }
         }
     };
     auto finish_rows = [&](const int64_t i0) {
-        const float* pb = a.part32 + (int64_t)c * n + i0;
-        const int64_t pstep = (int64_t)RS3_CAND * n;
+        const float* pb = a.part32 + (int64_t)c * n;
+        int64_t ro[PD_RB];                                      // (rows past n: the last row's address, y is NaN there)
+#pragma unroll
+        for (int e = 0; e < PD_RB; ++e) ro[e] = (i0 + 256 * e < n) ? i0 + 256 * e : n - 1;
 #pragma unroll
         for (int e = 0; e < PD_RB; ++e) { yv[e] = (float)yd[e]; fv[e] = (float)fd[e]; mv[e] = (float)md[e]; nv[e] = 0.0f; }
         for (int q0 = 0; q0 < pmax; q0 += 4) {                 // (sixteen loads in flight, not sixteen round trips)
             float t4[PD_RB][4];
 #pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* pq = pb + (int64_t)(q0 + u < pmax ? q0 + u : 0) * pstep;       // (uniform)
+#pragma unroll
+                for (int e = 0; e < PD_RB; ++e) t4[e][u] = pq[ro[e]];
+            }
+#pragma unroll
             for (int e = 0; e < PD_RB; ++e)
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    t4[e][u] = (q0 + u < parts[e]) ? pb[(int64_t)(q0 + u) * pstep + 256 * e] : 0.0f;
-#pragma unroll
-            for (int e = 0; e < PD_RB; ++e)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) nv[e] += t4[e][u];
+                for (int u = 0; u < 4; ++u) nv[e] += (q0 + u < pmax) ? t4[e][u] : 0.0f;
         }
     };
     issue_rows(r_beg + tid);
@@ -351,9 +350,10 @@ __global__ __launch_bounds__(256) void rs3p_decide_kernel(Rs3Args a)
 #pragma unroll
             for (int e = 0; e < PD_RB; ++e) {
                 if (yv[e] == yv[e]) {
-                    acc[0] += term(yv[e] * (fv[e] + mv[e]));
+                    const float yf = yv[e] * fv[e], yn = yv[e] * nv[e], ym = yv[e] * mv[e];      // (y = +-1: exact)
+                    acc[0] += term(yf + ym);
 #pragma unroll
-                    for (int t = 0; t < PD_T; ++t) acc[1 + t] += term(yv[e] * ((fv[e] * ct[t] + nv[e] * st[t]) + mv[e]));
+                    for (int t = 0; t < PD_T; ++t) acc[1 + t] += term(__builtin_fmaf(yf, ct[t], __builtin_fmaf(yn, st[t], ym)));
                 }
             }
         }

@@ -501,7 +501,11 @@ int do_draw_f(gpirt_sampler_s* s)
         GP_HIP(hipStreamSynchronize(st));
         if ((int)s->h_next[1] != 0) break;                    // (an error flag: stream_end / check report it)
         if ((int64_t)s->h_next[0] <= done) {
-            if (predict) { predict = false; continue; }       // the predictor stalled on its first item: the one-phase replay goes on
+            if (predict) {                                    // the predictor stalled on its first item: the one-phase replay goes on
+                predict = false;
+                GP_TRY(launch_advance_pos(st, s->rs_ctl + 2, 1));     // (counted: gpirt_sampler_get "rs_stats"[2])
+                continue;
+            }
             set_error("R-stream replay: draw_f made no progress"); return GPIRT_E_NUMERIC;
         }
         done = (int64_t)s->h_next[0];

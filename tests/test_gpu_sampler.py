@@ -627,6 +627,7 @@ def test_r_stream_predicted_replay_survives_a_wrong_predictor(handle, oracle, n,
     finally:
         _lib.check(lib.gpirt_debug_rs_mispredict(handle._h, 0))
     assert stats[1] >= 2 * (m // every) - 2               # (mispredictions found by the verification: the path under test ran)
+    assert stats[2] == 0                                  # (... and the predictor never stalled into the one-phase replay)
     r = oracle.RStream(4242)
     ref = oracle.gpirt_mcmc(r, y, th0, 2, 0)
     assert np.array_equal(got["theta"], ref["theta"][2])
@@ -660,7 +661,7 @@ def test_r_stream_predicted_replay_agrees_with_the_one_phase_replay(handle, n, m
     assert np.array_equal(k1, k2) and np.array_equal(t1, t2)
     assert st1[1] == st2[1] and np.array_equal(st1[0], st2[0])
     assert np.abs(f1 - f2).max() <= 1e-10 and np.abs(b1 - b2).max() <= 1e-10
-    assert q1[1] == 0                                     # (no misprediction on these chains: the predictor earns its keep)
+    assert q1[1] == 0 and q1[2] == 0                      # (no misprediction, no stall on these chains: the predictor earns its keep)
 
 
 @pytest.mark.parametrize("n,m", [(97, 11), (1025, 7), (640, 40)])
