@@ -233,9 +233,11 @@ def main():
         fstar_scale = max(1.0, float(fs_scale.item()))
         del aw, w
         theta_on_grid = bool(torch.all(((e.device_tensor("theta") + 5.0) / 0.01 - torch.round((e.device_tensor("theta") + 5.0) / 0.01)).abs() < 1e-9).item())
-        if not (lowrank_gap <= FSTAR_TOL and lowrank_gap_aw <= FSTAR_TOL * fstar_scale):
+        # (both comparisons relative to max|f*|, as in tests/test_gpu_configs.py: two backward-stable evaluations of k*^T S^-1 f
+        # differ by ~cond(S) eps |f*| -- at n = 16384 the absolute 1e-9 sits AT that floor, 0.8e-9 ... 1.02e-9 from state to state)
+        if not (lowrank_gap <= FSTAR_TOL * fstar_scale and lowrank_gap_aw <= FSTAR_TOL * fstar_scale):
             # the low-rank form missed the tolerance on this state: the headline falls back to the like-for-like form
-            headline_note = (f"lowrank measured max|f*_lowrank - f*_fused| = {lowrank_gap:.3e} (tolerance {FSTAR_TOL:g}) and "
+            headline_note = (f"lowrank measured max|f*_lowrank - f*_fused| = {lowrank_gap:.3e} (tolerance {FSTAR_TOL:g} x max|f*| = {FSTAR_TOL * fstar_scale:.3e}) and "
                              f"max|f*_lowrank - f*_as_written| = {lowrank_gap_aw:.3e} (tolerance {FSTAR_TOL:g} x max|f*| = "
                              f"{FSTAR_TOL * fstar_scale:.3e}): `value` is the `fused` form")
             form = "fused"
@@ -454,13 +456,13 @@ def main():
                                     "lowrank": "fused + K(theta, theta*) = K(theta, c) V^T, 64 Chebyshev nodes: 2 x 64 right-hand "
                                                "sides instead of 1001 + m"}[form],
                 "lowrank_check": None if lowrank_gap is None else {
-                    "max_abs_fstar_lowrank_minus_full_solve": lowrank_gap, "tolerance": FSTAR_TOL,
+                    "max_abs_fstar_lowrank_minus_full_solve": lowrank_gap, "tolerance": FSTAR_TOL * fstar_scale,
                     "max_abs_fstar_lowrank_minus_as_written": lowrank_gap_aw,
                     "tolerance_as_written": FSTAR_TOL * fstar_scale, "max_abs_fstar": fstar_scale,
                     "as_written": "src/draw-fstar.cpp:17-25 (double_solve) on the same state and RNG keys; tolerance 1e-9 x max|f*| "
                                   "(two backward-stable evaluations of k*^T S^-1 f differ by ~cond(S) eps |f*|, DESIGN.md section 5)",
                     "state": f"after {args.warmup + args.steps} iterations of this run, theta on the grid: {theta_on_grid}",
-                    "passed": bool(lowrank_gap <= FSTAR_TOL and lowrank_gap_aw <= FSTAR_TOL * fstar_scale)},
+                    "passed": bool(lowrank_gap <= FSTAR_TOL * fstar_scale and lowrank_gap_aw <= FSTAR_TOL * fstar_scale)},
                 "theta_product": "exact fixed point on the int8 matrix cores (csrc/theta_fixed.hip; GPIRT_THETA_FIXED=2: fp64 GEMM)",
                 "theta_product_check": theta_product_check,
                 "headline_note": headline_note,

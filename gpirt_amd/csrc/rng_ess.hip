@@ -766,7 +766,10 @@ __global__ __launch_bounds__(320) void rs3_slice_kernel(Rs3Args a)
 // Register-resident variant for n <= NTH * EPT: each lane keeps its EPT entries of f, nu, mu and y in
 // registers, so the (2 + k) likelihood passes of a column touch memory once; arithmetic is identical
 // to ess_kernel (same per-element expression, same reduction tree).
-template <int EPT, int NTH, bool FAST>
+// FOLD (n up to 16384: 32 entries per lane of 512): y is +-1 or NaN, so y ((f c + nu s) + mu) = ((y f) c + (y nu) s) + (y mu)
+// bit for bit (a sign change is exact and rounding is symmetric) -- the lane keeps THREE arrays, y f, y nu, y mu (NaN in
+// y mu = a missing response), 192 registers instead of 256, and reads f and nu once more at the end to write f'.
+template <int EPT, int NTH, bool FAST, bool FOLD = false>
 __global__ __launch_bounds__(NTH) void ess_kernel_reg(EssArgs a)
 {
     __shared__ double red[8];
@@ -778,16 +781,21 @@ __global__ __launch_bounds__(NTH) void ess_kernel_reg(EssArgs a)
     const double* yj = a.y + j * n;
     const double* mj = a.mu + j * n;
     const uint32_t item = a.item0 + (uint32_t)j;
-    double F[EPT], V[EPT], M[EPT], Y[EPT];
+    double F[EPT], V[EPT], M[EPT], Y[FOLD ? 1 : EPT];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int64_t i = threadIdx.x + NTH * e;
         const bool in = i < n;
+        const double yy = in ? yj[i] : __builtin_nan("");      // NaN = skipped, like a missing response
         F[e] = in ? fj[i] : 0.0;
         V[e] = in ? nj[i] : 0.0;
         M[e] = in ? mj[i] : 0.0;
-        Y[e] = in ? yj[i] : __builtin_nan("");      // NaN = skipped, like a missing response
+        if (FOLD) { F[e] *= yy; V[e] *= yy; M[e] *= yy; } else Y[e] = yy;
     }
+    // the argument of one term, and whether the row counts
+    auto arg0 = [&](const int e) { return FOLD ? F[e] + M[e] : Y[e] * (F[e] + M[e]); };
+    auto argp = [&](const int e, const double c_, const double s_) { return FOLD ? (F[e] * c_ + V[e] * s_) + M[e] : Y[e] * ((F[e] * c_ + V[e] * s_) + M[e]); };
+    auto live = [&](const int e) { return FOLD ? M[e] == M[e] : Y[e] == Y[e]; };
     uint32_t uidx = 0;
     double acc = 0.0;
     // ll(f) of the current state, the other half of the slice level (:28-29) -- in full precision when it is needed: with the
@@ -798,7 +806,7 @@ __global__ __launch_bounds__(NTH) void ess_kernel_reg(EssArgs a)
         double t = 0.0;
 #pragma unroll
         for (int e = 0; e < EPT; ++e)
-            if (Y[e] == Y[e]) t += ll_t<FAST>(Y[e] * (F[e] + M[e]));
+            if (live(e)) t += ll_t<FAST>(arg0(e));
         return -block_sum(t);
     };
     // the screen's error bound for this item's sums (ll_fast.h): every row could be off by LL_SCREEN_ERR
@@ -811,7 +819,7 @@ __global__ __launch_bounds__(NTH) void ess_kernel_reg(EssArgs a)
     if (lazy) {
 #pragma unroll
         for (int e = 0; e < EPT; ++e)
-            if (Y[e] == Y[e]) acc += ll_term_screen(Y[e] * (F[e] + M[e]));
+            if (live(e)) acc += ll_term_screen(arg0(e));
         lls0 = -block_sum(acc);
     } else {
         ll0 = exact_ll0();
@@ -837,8 +845,8 @@ __global__ __launch_bounds__(NTH) void ess_kernel_reg(EssArgs a)
             int overflows = 0;
 #pragma unroll
             for (int e = 0; e < EPT; ++e)
-                if (Y[e] == Y[e]) {
-                    const double arg = Y[e] * ((F[e] * c + V[e] * s) + M[e]);
+                if (live(e)) {
+                    const double arg = argp(e, c, s);
                     acc += ll_term_screen(arg);
                     if (!FAST && arg < -709.0) overflows = 1;
                 }
@@ -860,7 +868,7 @@ __global__ __launch_bounds__(NTH) void ess_kernel_reg(EssArgs a)
             acc = 0.0;
 #pragma unroll
             for (int e = 0; e < EPT; ++e)
-                if (Y[e] == Y[e]) acc += ll_t<FAST>(Y[e] * ((F[e] * c + V[e] * s) + M[e]));   // :43
+                if (live(e)) acc += ll_t<FAST>(argp(e, c, s));   // :43
             const double llp = -block_sum(acc);
             if (llp > log_y) verdict = 1;                                  // :45-47
             else if (llp != llp || ll0 != ll0) { bad = true; break; }
@@ -875,7 +883,8 @@ __global__ __launch_bounds__(NTH) void ess_kernel_reg(EssArgs a)
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int64_t i = threadIdx.x + NTH * e;
-        if (i < n) fj[i] = F[e] * c + V[e] * s;
+        if (FOLD) { if (i < n) fj[i] = fj[i] * c + nj[i] * s; }       // (the lane's own entries: read back, the folded copies may be NaN)
+        else if (i < n) fj[i] = F[e] * c + V[e] * s;
     }
     if (threadIdx.x == 0) {
         if (a.k_out) a.k_out[j] = k;
@@ -933,6 +942,9 @@ int launch_ess(hipStream_t stream, const EssArgs& a)
     } else if (a.U == nullptr && a.n <= 256 * 32) {
         if (fast) hipLaunchKernelGGL((ess_kernel_reg<16, 512, true>), dim3((unsigned)a.m), dim3(512), 0, stream, a);
         else      hipLaunchKernelGGL((ess_kernel_reg<16, 512, false>), dim3((unsigned)a.m), dim3(512), 0, stream, a);
+    } else if (a.U == nullptr && a.n <= 512 * 32) {
+        if (fast) hipLaunchKernelGGL((ess_kernel_reg<32, 512, true, true>), dim3((unsigned)a.m), dim3(512), 0, stream, a);
+        else      hipLaunchKernelGGL((ess_kernel_reg<32, 512, false, true>), dim3((unsigned)a.m), dim3(512), 0, stream, a);
     } else {
         if (fast) hipLaunchKernelGGL(ess_kernel<true>, dim3((unsigned)a.m), dim3(256), 0, stream, a);
         else      hipLaunchKernelGGL(ess_kernel<false>, dim3((unsigned)a.m), dim3(256), 0, stream, a);

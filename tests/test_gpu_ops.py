@@ -294,6 +294,26 @@ def test_draw_f_item_rng(handle, oracle, n, m):
     assert np.abs(to_host(out) - ref).max() <= 1e-9
 
 
+@pytest.mark.parametrize("n,m", [(9000, 4), (16000, 3)])
+def test_draw_f_item_rng_beyond_8192_rows(handle, oracle, n, m):
+    """The slice kernel keeps a column in registers up to 8192 rows with four arrays (f, nu, mu, y) and up to 16384 with three
+    (y f, y nu, y mu: y is +-1, so the folded form is the same bits; rng_ess.hip, FOLD): draw_f against the oracle's at n = 9000
+    and 16000 on a LAPACK factor (scipy dpotrf -- the oracle's own unblocked factorisation would take minutes here): rejection
+    counts exact, f to 1e-9."""
+    import scipy.linalg as sl
+    from gpirt_amd.ops import to_device, to_host
+    y, theta, f, beta, mu = _problem(n, m, 33)
+    K = np.exp(-0.5 * (theta[:, None] - theta[None, :]) ** 2)
+    K[np.diag_indices(n)] += 1e-3
+    L = np.asfortranarray(np.tril(sl.cholesky(K, lower=True, overwrite_a=True, check_finite=False)))
+    del K
+    seed, it = 5, 2
+    ref, kref = oracle.draw_f(oracle.ItemStream(seed), f, y, L, mu, it=it)
+    out, k = handle.draw_f(to_device(f), to_device(y), to_device(L), to_device(mu), seed, it)
+    assert np.array_equal(k.cpu().numpy(), kref)
+    assert np.abs(to_host(out) - ref).max() <= 1e-9
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_draw_fstar_item_rng(handle, oracle, fused):
     from gpirt_amd.ops import to_device, to_host
