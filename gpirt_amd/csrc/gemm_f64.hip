@@ -762,7 +762,12 @@ int gemm_split_count(gpirt_handle_t h, hipStream_t stream, int tri, int64_t M, i
     return split >= 2 ? (int)split : 1;
 }
 
-static int t128_min_or_default() { return T128_MIN; }
+// ... for PLAIN products from 256 tiles on (one work-group per CU): the trsm recursion's large updates (4096 x 1024 x 4096 at
+// the metric size) run 712 -> ~600 us that way, draw_fstar as written 3.50 -> 3.36 ms (round 6; 128 tiles: 3.88)
+#ifndef T128_PLAIN_MIN
+#define T128_PLAIN_MIN 256
+#endif
+static int t128_min_or_default() { return T128_PLAIN_MIN; }
 
 int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri, int64_t M,
                 int64_t N, int64_t K, double alpha, const double* A, int64_t lda, const double* B,

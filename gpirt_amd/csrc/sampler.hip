@@ -605,7 +605,8 @@ int do_draw_fstar(gpirt_sampler_s* s, uint32_t iter)
     if (fused) {
         GP_TRY(launch_gemm(h, st, true, false, TRI_NONE, N, m, n, 1.0, tmp, n, W, n, 0.0, s->mean, N));
     } else {
-        GP_TRY(launch_trsm_lower(h, st, s->L, n, s->ldl, W, m, n, true));                          // :7 outer
+        // (the block inverses of L are the forward solve's: same factor, not modified since)
+        GP_TRY(launch_trsm_lower(h, st, s->L, n, s->ldl, W, m, n, true, true));                    // :7 outer
         GP_TRY(launch_gemm(h, st, true, false, TRI_NONE, N, m, n, 1.0, s->kstar, n, W, n, 0.0, s->mean, N)); // :25
     }
     FstarEpiArgs a{};
