@@ -766,14 +766,25 @@ __global__ __launch_bounds__(320) void rs3_slice_kernel(Rs3Args a)
 // Register-resident variant for n <= NTH * EPT: each lane keeps its EPT entries of f, nu, mu and y in
 // registers, so the (2 + k) likelihood passes of a column touch memory once; arithmetic is identical
 // to ess_kernel (same per-element expression, same reduction tree).
-// FOLD (n up to 16384: 32 entries per lane of 512): y is +-1 or NaN, so y ((f c + nu s) + mu) = ((y f) c + (y nu) s) + (y mu)
+// FOLD (n up to 16384: 16 entries per lane of 1024, four wavefronts per SIMD at 128 registers): y is +-1 or NaN, so y ((f c + nu s) + mu) = ((y f) c + (y nu) s) + (y mu)
 // bit for bit (a sign change is exact and rounding is symmetric) -- the lane keeps THREE arrays, y f, y nu, y mu (NaN in
-// y mu = a missing response), 192 registers instead of 256, and reads f and nu once more at the end to write f'.
+// y mu = a missing response), 96 registers instead of 128, and reads f and nu once more at the end to write f'.
 template <int EPT, int NTH, bool FAST, bool FOLD = false>
 __global__ __launch_bounds__(NTH) void ess_kernel_reg(EssArgs a)
 {
-    __shared__ double red[8];
-    auto block_sum = [&](double v) { return NTH == 256 ? block_sum_256(v, red) : block_sum_512(v, red); };
+    __shared__ double red[16];
+    auto block_sum = [&](double v) {
+        if (NTH == 256) return block_sum_256(v, red);
+        if (NTH == 512) return block_sum_512(v, red);
+        // 1024 threads: sixteen wavefronts, fixed tree
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        return (((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]))) +
+               (((red[8] + red[9]) + (red[10] + red[11])) + ((red[12] + red[13]) + (red[14] + red[15])));
+    };
     const int64_t j = blockIdx.x;
     const int64_t n = a.n;
     double* fj = a.f + j * n;
@@ -781,7 +792,7 @@ __global__ __launch_bounds__(NTH) void ess_kernel_reg(EssArgs a)
     const double* yj = a.y + j * n;
     const double* mj = a.mu + j * n;
     const uint32_t item = a.item0 + (uint32_t)j;
-    double F[EPT], V[EPT], M[EPT], Y[FOLD ? 1 : EPT];
+    double F[EPT], V[EPT], M[EPT], Y[EPT];          // (FOLD: Y stays unused and costs no register)
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int64_t i = threadIdx.x + NTH * e;
@@ -790,12 +801,15 @@ __global__ __launch_bounds__(NTH) void ess_kernel_reg(EssArgs a)
         F[e] = in ? fj[i] : 0.0;
         V[e] = in ? nj[i] : 0.0;
         M[e] = in ? mj[i] : 0.0;
-        if (FOLD) { F[e] *= yy; V[e] *= yy; M[e] *= yy; } else Y[e] = yy;
+        Y[e] = FOLD ? 0.0 : yy;
+        if (FOLD) { F[e] *= yy; V[e] *= yy; M[e] *= yy; }
     }
-    // the argument of one term, and whether the row counts
-    auto arg0 = [&](const int e) { return FOLD ? F[e] + M[e] : Y[e] * (F[e] + M[e]); };
-    auto argp = [&](const int e, const double c_, const double s_) { return FOLD ? (F[e] * c_ + V[e] * s_) + M[e] : Y[e] * ((F[e] * c_ + V[e] * s_) + M[e]); };
-    auto live = [&](const int e) { return FOLD ? M[e] == M[e] : Y[e] == Y[e]; };
+    // the argument of one term, and whether the row counts.  (Macros, not lambdas: a lambda that captures the arrays by
+    // reference put them into scratch memory -- 164 registers + 432 bytes of scratch per lane instead of 237 registers, and the
+    // kernel ran 330-450 instead of 140-205 us at 8192 x 1024.)
+#define ESS_ARG0(e) (FOLD ? F[e] + M[e] : Y[e] * (F[e] + M[e]))
+#define ESS_ARGP(e, c_, s_) (FOLD ? (F[e] * (c_) + V[e] * (s_)) + M[e] : Y[e] * ((F[e] * (c_) + V[e] * (s_)) + M[e]))
+#define ESS_LIVE(e) (FOLD ? M[e] == M[e] : Y[e] == Y[e])
     uint32_t uidx = 0;
     double acc = 0.0;
     // ll(f) of the current state, the other half of the slice level (:28-29) -- in full precision when it is needed: with the
@@ -806,7 +820,7 @@ __global__ __launch_bounds__(NTH) void ess_kernel_reg(EssArgs a)
         double t = 0.0;
 #pragma unroll
         for (int e = 0; e < EPT; ++e)
-            if (live(e)) t += ll_t<FAST>(arg0(e));
+            if (ESS_LIVE(e)) t += ll_t<FAST>(ESS_ARG0(e));
         return -block_sum(t);
     };
     // the screen's error bound for this item's sums (ll_fast.h): every row could be off by LL_SCREEN_ERR
@@ -819,7 +833,7 @@ __global__ __launch_bounds__(NTH) void ess_kernel_reg(EssArgs a)
     if (lazy) {
 #pragma unroll
         for (int e = 0; e < EPT; ++e)
-            if (live(e)) acc += ll_term_screen(arg0(e));
+            if (ESS_LIVE(e)) acc += ll_term_screen(ESS_ARG0(e));
         lls0 = -block_sum(acc);
     } else {
         ll0 = exact_ll0();
@@ -845,8 +859,8 @@ __global__ __launch_bounds__(NTH) void ess_kernel_reg(EssArgs a)
             int overflows = 0;
 #pragma unroll
             for (int e = 0; e < EPT; ++e)
-                if (live(e)) {
-                    const double arg = argp(e, c, s);
+                if (ESS_LIVE(e)) {
+                    const double arg = ESS_ARGP(e, c, s);
                     acc += ll_term_screen(arg);
                     if (!FAST && arg < -709.0) overflows = 1;
                 }
@@ -868,7 +882,7 @@ __global__ __launch_bounds__(NTH) void ess_kernel_reg(EssArgs a)
             acc = 0.0;
 #pragma unroll
             for (int e = 0; e < EPT; ++e)
-                if (live(e)) acc += ll_t<FAST>(argp(e, c, s));   // :43
+                if (ESS_LIVE(e)) acc += ll_t<FAST>(ESS_ARGP(e, c, s));   // :43
             const double llp = -block_sum(acc);
             if (llp > log_y) verdict = 1;                                  // :45-47
             else if (llp != llp || ll0 != ll0) { bad = true; break; }
@@ -891,6 +905,10 @@ __global__ __launch_bounds__(NTH) void ess_kernel_reg(EssArgs a)
         if (bad && a.err) atomicCAS(a.err, 0, (int)GPIRT_E_NUMERIC);
     }
 }
+
+#undef ESS_ARG0
+#undef ESS_ARGP
+#undef ESS_LIVE
 
 __global__ void advance_pos_kernel(uint64_t* pos, uint64_t delta) { *pos += delta; }
 
@@ -942,9 +960,9 @@ int launch_ess(hipStream_t stream, const EssArgs& a)
     } else if (a.U == nullptr && a.n <= 256 * 32) {
         if (fast) hipLaunchKernelGGL((ess_kernel_reg<16, 512, true>), dim3((unsigned)a.m), dim3(512), 0, stream, a);
         else      hipLaunchKernelGGL((ess_kernel_reg<16, 512, false>), dim3((unsigned)a.m), dim3(512), 0, stream, a);
-    } else if (a.U == nullptr && a.n <= 512 * 32) {
-        if (fast) hipLaunchKernelGGL((ess_kernel_reg<32, 512, true, true>), dim3((unsigned)a.m), dim3(512), 0, stream, a);
-        else      hipLaunchKernelGGL((ess_kernel_reg<32, 512, false, true>), dim3((unsigned)a.m), dim3(512), 0, stream, a);
+    } else if (a.U == nullptr && a.n <= 1024 * 16) {
+        if (fast) hipLaunchKernelGGL((ess_kernel_reg<16, 1024, true, true>), dim3((unsigned)a.m), dim3(1024), 0, stream, a);
+        else      hipLaunchKernelGGL((ess_kernel_reg<16, 1024, false, true>), dim3((unsigned)a.m), dim3(1024), 0, stream, a);
     } else {
         if (fast) hipLaunchKernelGGL(ess_kernel<true>, dim3((unsigned)a.m), dim3(256), 0, stream, a);
         else      hipLaunchKernelGGL(ess_kernel<false>, dim3((unsigned)a.m), dim3(256), 0, stream, a);
