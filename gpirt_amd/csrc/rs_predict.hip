@@ -572,6 +572,78 @@ __global__ __launch_bounds__(256) void rs_verify_kernel(RsVerifyArgs a)
     }
 }
 
+// The same with the item's columns in registers (n <= NTH * EPT; rng_ess.hip's ess_kernel_reg does the item-keyed contract
+// that way): f, nu, mu, y are read once, the (2 + k) likelihood passes run on registers.  Same per-element expression as
+// rs_verify_kernel; the sums are block trees of NTH lanes instead of 256.  (No lambda touches the arrays: one that captures
+// them by reference sends them to scratch memory -- tests/test_scratch_census.py.)
+template <int EPT, int NTH>
+__global__ __launch_bounds__(NTH) void rs_verify_reg_kernel(RsVerifyArgs a)
+{
+    __shared__ double red[8];
+    const int64_t j = a.j0 + blockIdx.x;
+    if ((uint64_t)j >= a.anchorP[0]) return;                   // not predicted
+    const int64_t n = a.n;
+    const double* fj = a.f + j * n;
+    double* nj = a.nu + (j - a.j0) * n;
+    const double* yj = a.y + j * n;
+    const double* mj = a.mu + j * n;
+    const uint64_t p0 = a.posv[j] + 2ull * (uint64_t)n;        // behind the n normals
+    double F[EPT], V[EPT], M[EPT], Y[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int64_t i = threadIdx.x + NTH * e;
+        const bool in = i < n;
+        F[e] = in ? fj[i] : 0.0; V[e] = in ? nj[i] : 0.0; M[e] = in ? mj[i] : 0.0;
+        Y[e] = in ? yj[i] : __builtin_nan("");                  // NaN = skipped, like a missing response
+    }
+    uint32_t uidx = 0;
+    bool overflow = false, nan_state = false;
+    double acc = 0.0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e)
+        if (Y[e] == Y[e]) acc += ll_term(Y[e] * (F[e] + M[e]));
+    const double ll0 = -(NTH == 256 ? block_sum_256(acc, red) : block_sum_512(acc, red));
+    double u = 0.5, u2 = 0.5;
+    { const uint64_t q = p0 + uidx; if (q >= a.cap) overflow = true; else u = a.U[q]; ++uidx; }
+    { const uint64_t q = p0 + uidx; if (q >= a.cap) overflow = true; else u2 = a.U[q]; ++uidx; }
+    const double log_y = ll0 + log(u);                                     // draw-f.cpp:28-29
+    double eps_min = 0.0, eps_max = GP_2PI;                                // :33-34
+    double eps = eps_min + (eps_max - eps_min) * u2;                       // :35
+    eps_min = eps - GP_2PI;                                                // :36
+    int k = 0;
+    double c, s;
+    for (;;) {
+        c = cos(eps);
+        s = sin(eps);
+        acc = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e)
+            if (Y[e] == Y[e]) acc += ll_term(Y[e] * ((F[e] * c + V[e] * s) + M[e]));   // :43
+        const double llp = -(NTH == 256 ? block_sum_256(acc, red) : block_sum_512(acc, red));
+        if (llp > log_y) break;                                            // :45-47
+        if (llp != llp) { nan_state = true; break; }                       // NaN state: never accepts
+        if (eps < 0.0) eps_min = eps; else eps_max = eps;                  // :50-55
+        if (eps_min == eps_max) eps = eps_min;                             // R::runif(a,a) = a
+        else {
+            double un = 0.5;
+            const uint64_t q = p0 + uidx; if (q >= a.cap) overflow = true; else un = a.U[q]; ++uidx;
+            eps = eps_min + (eps_max - eps_min) * un;                      // :56
+        }
+        ++k;
+        if (k >= 100000 || overflow) { overflow = true; break; }
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int64_t i = threadIdx.x + NTH * e;
+        if (i < n) nj[i] = F[e] * c + V[e] * s;
+    }
+    if (threadIdx.x == 0) {
+        a.kv[j] = k;
+        a.used[j] = uidx;
+        a.ierr[j] = nan_state ? (int)GPIRT_E_NUMERIC : overflow ? (int)GPIRT_E_RNG : 0;
+    }
+}
+
 // Walk the verified items in order: item j is exact when every item before it consumed what the predictor said.  Accept up
 // to and including the first item whose own consumption differs (its start was exact), correct the next start, and leave
 // the new exact state: anchor (item, start), the cursor, ctl[0] = first item NOT committed.  An error of an exact item is
@@ -670,7 +742,9 @@ int launch_rs_gather(hipStream_t stream, const double* Nrm, const uint64_t* posv
 int launch_rs_verify(hipStream_t stream, const RsVerifyArgs& a)
 {
     if (a.m <= a.j0) return 0;
-    hipLaunchKernelGGL(rs_verify_kernel, dim3((unsigned)(a.m - a.j0)), dim3(256), 0, stream, a);
+    if (a.n <= 256 * 8)       hipLaunchKernelGGL((rs_verify_reg_kernel<8, 256>), dim3((unsigned)(a.m - a.j0)), dim3(256), 0, stream, a);
+    else if (a.n <= 512 * 16) hipLaunchKernelGGL((rs_verify_reg_kernel<16, 512>), dim3((unsigned)(a.m - a.j0)), dim3(512), 0, stream, a);
+    else                      hipLaunchKernelGGL(rs_verify_kernel, dim3((unsigned)(a.m - a.j0)), dim3(256), 0, stream, a);
     GP_HIP(hipGetLastError());
     return 0;
 }

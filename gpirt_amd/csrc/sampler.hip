@@ -431,7 +431,7 @@ int do_draw_f(gpirt_sampler_s* s)
     // three slice loops; a slice loop that ran longer than its successors' candidates reach just ends the pass early.  All of
     // it is device-side state (next_item, posv): the host enqueues ceil(m / 3) passes and a few spare ones -- a pass that finds
     // every item done leaves at once -- and reads the item counter back once.
-    GP_TRY(launch_rs_tiles(st, s->L, n, s->ldl, s->Lt));
+    bool tiles64 = false;                       // (L as fp64 tiles: only the one-phase replay reads them -- built when it first runs)
     Rs3Args a{};
     a.U = s->U; a.cap = s->U_cap; a.Nrm = s->Nrm; a.anchor = s->anchor; a.pos = s->pos; a.posv = s->posv; a.k_out = s->ess_k;
     a.err = s->flags; a.n = n; a.m = m; a.Lt = s->Lt; a.nkb = rs_tile_quads(n); a.part = s->rs_part;
@@ -484,7 +484,8 @@ int do_draw_f(gpirt_sampler_s* s)
             v.kv = s->rs_kv; v.used = s->rs_used; v.ierr = s->rs_ierr;
             GP_TRY(launch_rs_verify(st, v));
             GP_TRY(launch_rs_commit(st, v, s->anchor, s->pos, s->rs_ctl, s->flags, s->f, s->ess_k));
-        } else
+        } else {
+        if (!tiles64) { GP_TRY(launch_rs_tiles(st, s->L, n, s->ldl, s->Lt)); tiles64 = true; }
         for (int64_t q = 0; q < count; ++q, ++pass) {
             s->rs_tag += 1ull << 20;
             a.tag = s->rs_tag;
@@ -494,6 +495,7 @@ int do_draw_f(gpirt_sampler_s* s)
             GP_TRY(launch_rs3_products(st, a));
             GP_TRY(prof_pair_end(h, st, pp, 4, 2.0 * RS3_CAND * 0.5 * (double)n * (double)(n + 1), 8.0 * 0.5 * (double)n * (double)(n + 1)));
             GP_TRY(launch_rs3_slice(st, a));
+        }
         }
         GP_HIP(hipMemcpyAsync(s->h_next, s->anchor, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         GP_HIP(hipMemcpyAsync(s->h_next + 1, s->flags, sizeof(int), hipMemcpyDeviceToHost, st));
