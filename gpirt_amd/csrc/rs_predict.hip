@@ -267,22 +267,35 @@ __global__ __launch_bounds__(256) void rs3p_decide_kernel(Rs3Args a)
     // were never written by the products and still hold the zeros of the sampler's creation, so every row simply adds pmax parts
     const int pmax = (int)((((r_end < n ? r_end : n) + RS_KC - 1) / RS_KC));
     const int64_t pstep = (int64_t)RS3_CAND * n;
+    // Every load of a row is UNCONDITIONAL (rows past the part's end read the last row of the matrix and are masked when the
+    // values are used): a load under a predicate is followed by its select, and the select waits for the load -- twelve
+    // round trips one after the other instead of one (2.0 of the prologue's 5 us, in-kernel stamps).
+    constexpr int PD_QB = 16;                                  // parts of a row in flight together (n <= 8192: all of them)
+    float t16[PD_RB][PD_QB];
+    int64_t ro[PD_RB];
     auto issue_rows = [&](const int64_t i0) {
 #pragma unroll
-        for (int e = 0; e < PD_RB; ++e) {
-            const int64_t i = i0 + 256 * e;
-            const bool in = valid && i < r_end;
-            yd[e] = in ? yj[i] : __builtin_nan(""); fd[e] = in ? fj[i] : 0.0; md[e] = in ? mj[i] : 0.0;
+        for (int e = 0; e < PD_RB; ++e) ro[e] = (i0 + 256 * e < n) ? i0 + 256 * e : n - 1;
+#pragma unroll
+        for (int e = 0; e < PD_RB; ++e) { yd[e] = yj[ro[e]]; fd[e] = fj[ro[e]]; md[e] = mj[ro[e]]; }
+        const float* pb = a.part32 + (int64_t)c * n;
+#pragma unroll
+        for (int u = 0; u < PD_QB; ++u) {
+            const float* pq = pb + (int64_t)(u < pmax ? u : 0) * pstep;          // (uniform)
+#pragma unroll
+            for (int e = 0; e < PD_RB; ++e) t16[e][u] = pq[ro[e]];
         }
     };
     auto finish_rows = [&](const int64_t i0) {
         const float* pb = a.part32 + (int64_t)c * n;
-        int64_t ro[PD_RB];                                      // (rows past n: the last row's address, y is NaN there)
 #pragma unroll
-        for (int e = 0; e < PD_RB; ++e) ro[e] = (i0 + 256 * e < n) ? i0 + 256 * e : n - 1;
+        for (int e = 0; e < PD_RB; ++e) {
+            const bool in = valid && i0 + 256 * e < r_end;
+            yv[e] = in ? (float)yd[e] : __builtin_nanf(""); fv[e] = (float)fd[e]; mv[e] = (float)md[e]; nv[e] = 0.0f;
 #pragma unroll
-        for (int e = 0; e < PD_RB; ++e) { yv[e] = (float)yd[e]; fv[e] = (float)fd[e]; mv[e] = (float)md[e]; nv[e] = 0.0f; }
-        for (int q0 = 0; q0 < pmax; q0 += 4) {                 // (sixteen loads in flight, not sixteen round trips)
+            for (int u = 0; u < PD_QB; ++u) nv[e] += (u < pmax) ? t16[e][u] : 0.0f;
+        }
+        for (int q0 = PD_QB; q0 < pmax; q0 += 4) {             // (n > 8192: the parts behind the sixteenth, four at a time)
             float t4[PD_RB][4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
