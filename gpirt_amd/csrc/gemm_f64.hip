@@ -817,7 +817,8 @@ int launch_gemm(gpirt_handle_t h, hipStream_t stream, bool ta, bool tb, int tri,
     if ((tri == TRI_A_LOWER || tri == TRI_A_UPPER) && h != nullptr && stream == h->stream && K >= 1024) {
         constexpr bool tri_split_on = true;
         const int64_t pairs = (((M + 63) / 64 + 1) / 2) * ((N + 63) / 64);
-        int S = (int)(384 / (pairs > 0 ? pairs : 1));
+        // (slots = 512: two work-groups on every CU; 384 left half the CUs with one -- 8192 x 128: 183 -> 156 us, x 256: 304 -> 289, round 6)
+        int S = (int)(512 / (pairs > 0 ? pairs : 1));
         if (S > 4) S = 4;
         if (tri_split_on && S >= 2) {
             const size_t need = (size_t)S * (size_t)M * (size_t)N * sizeof(double);
