@@ -215,7 +215,7 @@ constexpr int PD_V = PD_T + 1;           // sums per work-group: ll(f), then the
 constexpr int PD_MAXROUND = 14;          // 2 + PD_T * (PD_MAXROUND + 1) uniforms staged <= 256
 constexpr int PD_REC = PD_T + 2;         // per candidate: uniforms consumed when point t is the current one (-1: past the window), log(u), valid
 
-__global__ __launch_bounds__(256) void rs3p_decide_kernel(Rs3Args a)
+__global__ __launch_bounds__(320) void rs3p_decide_kernel(Rs3Args a)
 {
     extern __shared__ double pd_pad[];    // (dynamic LDS only to keep these work-groups one per compute unit: the ticket's hand-off was measured that way)
     __shared__ double uL[256];
@@ -243,11 +243,12 @@ __global__ __launch_bounds__(256) void rs3p_decide_kernel(Rs3Args a)
     auto stamp = [&]() { if (tr && ti < 16) tr[ti] = (long long)wall_clock64(); ++ti; };
     stamp();
     const int nU = 2 + PD_T * (rnd + 1);
-    // wave 0 alone fetches the uniforms, walks the bracket sequence and takes the cos / sin (its row loads are in flight
-    // meanwhile); the other waves go straight to their rows and meet it at ONE barrier
+    // Five waves: waves 0..3 (tid < 256) are the row workers; wave 4 alone fetches the uniforms, walks the bracket sequence
+    // and takes the cos / sin while the others load and add their rows -- they meet at ONE barrier
     const int wv = tid >> 6, lane = tid & 63;
+    const bool worker = tid < 256;
     double uval[4];
-    if (wv == 0) {
+    if (wv == 4) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int x = lane + 64 * k;
@@ -309,8 +310,11 @@ __global__ __launch_bounds__(256) void rs3p_decide_kernel(Rs3Args a)
                 for (int u = 0; u < 4; ++u) nv[e] += (q0 + u < pmax) ? t4[e][u] : 0.0f;
         }
     };
-    issue_rows(r_beg + tid);
-    if (wv == 0) {
+    if (worker) {
+        issue_rows(r_beg + tid);
+        if (tid == 64) rec[PD_T] = (valid && p0 < a.cap) ? log(a.U[p0]) : 0.0;       // log(u), :28-29
+        finish_rows(r_beg + tid);
+    } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) uL[lane + 64 * k] = uval[k];
         // (one wave: its LDS accesses execute in order; the wait only keeps the compiler from moving them)
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(256) void rs3p_decide_kernel(Rs3Args a)
         __builtin_amdgcn_wave_barrier();
         // The bracket walk (src/draw-f.cpp:33-36, 50-56) from the stream alone, every point as if all before it were rejected
         // -- by EVERY lane of the wave alike (uniform control flow, LDS broadcasts), lane t keeping point t for its cos / sin.
-        int uidx = 1; bool bad = false;                              // (uL[0] = u of :28: its logarithm is wave 1's)
+        int uidx = 1; bool bad = false;                              // (uL[0] = u of :28: its logarithm is a worker's)
         auto next_u = [&]() -> double { const double x = uL[uidx]; ++uidx; if (x != x) { bad = true; return 0.5; } return x; };
         double eps_min = 0.0, eps_max = GP_2PI;
         double eps = eps_min + (eps_max - eps_min) * next_u();
@@ -328,13 +332,33 @@ __global__ __launch_bounds__(256) void rs3p_decide_kernel(Rs3Args a)
             if (eps < 0.0) eps_min = eps; else eps_max = eps;
             if (eps_min == eps_max) eps = eps_min; else eps = eps_min + (eps_max - eps_min) * next_u();
         }
-        double my_eps = 0.0, my_rec = 0.0;
+        // the round's uniforms read together, as if every rejection consumed one -- true unless the bracket closes
+        // (eps_min == eps_max, where :56 consumes nothing): then the round is walked again with dependent reads
+        double uu[PD_T];
 #pragma unroll
-        for (int t = 0; t < PD_T; ++t) {
-            if (lane == t) { my_eps = eps; my_rec = bad ? -1.0 : (double)uidx; }
-            if (eps < 0.0) eps_min = eps; else eps_max = eps;       // :50-55
-            if (eps_min == eps_max) eps = eps_min;                  // R::runif(a, a) = a, nothing consumed
-            else eps = eps_min + (eps_max - eps_min) * next_u();    // :56
+        for (int t = 0; t < PD_T; ++t) uu[t] = uL[uidx + t];
+        double my_eps = 0.0, my_rec = 0.0;
+        {
+            double e0 = eps, emin = eps_min, emax = eps_max;
+            bool closed = false, badf = bad;
+#pragma unroll
+            for (int t = 0; t < PD_T; ++t) {
+                if (lane == t) { my_eps = e0; my_rec = badf ? -1.0 : (double)(uidx + t); }
+                if (e0 < 0.0) emin = e0; else emax = e0;            // :50-55
+                if (emin == emax) closed = true;
+                double x = uu[t];
+                if (x != x) { badf = true; x = 0.5; }
+                e0 = emin + (emax - emin) * x;                      // :56
+            }
+            if (closed) {
+#pragma unroll 1
+                for (int t = 0; t < PD_T; ++t) {
+                    if (lane == t) { my_eps = eps; my_rec = bad ? -1.0 : (double)uidx; }
+                    if (eps < 0.0) eps_min = eps; else eps_max = eps;
+                    if (eps_min == eps_max) eps = eps_min;          // R::runif(a, a) = a, nothing consumed
+                    else eps = eps_min + (eps_max - eps_min) * next_u();
+                }
+            }
         }
         if (lane < PD_T) {
             double sn, cn;
@@ -342,10 +366,7 @@ __global__ __launch_bounds__(256) void rs3p_decide_kernel(Rs3Args a)
             cs[lane] = cn; cs[PD_T + lane] = sn; rec[lane] = my_rec;
         }
         if (lane == 0) rec[PD_T + 1] = valid ? 1.0 : 0.0;
-    } else if (tid == 64) {
-        rec[PD_T] = (valid && p0 < a.cap) ? log(a.U[p0]) : 0.0;       // log(u), :28-29
     }
-    finish_rows(r_beg + tid);
     __syncthreads();
     stamp();
     // the terms: single precision throughout (argument, exp, log, and the sum over this thread's few rows) -- what comes out
@@ -364,7 +385,7 @@ __global__ __launch_bounds__(256) void rs3p_decide_kernel(Rs3Args a)
             const float e = __builtin_amdgcn_exp2f(fabsf(arg) * -1.44269504088896341f);
             return __builtin_fmaf(__builtin_amdgcn_logf(1.0f + e), 0.693147180559945309f, fmaxf(-arg, 0.0f));
         };
-        for (int64_t i0 = r_beg + tid; i0 < r_end; i0 += 256 * PD_RB) {
+        for (int64_t i0 = r_beg + tid; worker && i0 < r_end; i0 += 256 * PD_RB) {
             if (i0 != r_beg + tid) { issue_rows(i0); finish_rows(i0); }
 #pragma unroll
             for (int e = 0; e < PD_RB; ++e) {
@@ -382,10 +403,10 @@ __global__ __launch_bounds__(256) void rs3p_decide_kernel(Rs3Args a)
     {
         float* sred = reinterpret_cast<float*>(pd_pad);          // PD_V x 256 floats of the dynamic LDS
 #pragma unroll
-        for (int v = 0; v < PD_V; ++v) sred[v * 256 + tid] = acc[v];
+        for (int v = 0; v < PD_V; ++v) if (worker) sred[v * 256 + tid] = acc[v];
         __syncthreads();
         double* sred2 = pd_pad + (PD_V * 256) / 2 + 8;           // PD_V x 16 doubles behind it
-        for (int x = tid; x < PD_V * 16; x += 256) {
+        for (int x = tid; x < PD_V * 16; x += 320) {
             const int v = x >> 4, ch = x & 15;
             double r = 0.0;
 #pragma unroll
@@ -435,12 +456,12 @@ __global__ __launch_bounds__(256) void rs3p_decide_kernel(Rs3Args a)
             const int x = tid + 256 * k, cc = x / PD_V, v = x % PD_V;
 #pragma unroll
             for (int q = 0; q < PD_PARTS; ++q)
-                pv[k][q] = (x < RS3_CAND * PD_V) ? __hip_atomic_load(a.dec_part + ((size_t)(cc * PD_PARTS + q)) * PD_V + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                pv[k][q] = (worker && x < RS3_CAND * PD_V) ? __hip_atomic_load(a.dec_part + ((size_t)(cc * PD_PARTS + q)) * PD_V + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
         }
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
             const int x = tid + 256 * k;
-            rv[k] = (x < RS3_CAND * PD_REC) ? __hip_atomic_load(a.dec_rec + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            rv[k] = (worker && x < RS3_CAND * PD_REC) ? __hip_atomic_load(a.dec_rec + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
         }
 #pragma unroll
         for (int k = 0; k < NX; ++k) {
@@ -448,12 +469,12 @@ __global__ __launch_bounds__(256) void rs3p_decide_kernel(Rs3Args a)
             double r = 0.0;
 #pragma unroll
             for (int q = 0; q < PD_PARTS; ++q) r += pv[k][q];
-            if (x < RS3_CAND * PD_V) tot[x / PD_V][x % PD_V] = r;
+            if (worker && x < RS3_CAND * PD_V) tot[x / PD_V][x % PD_V] = r;
         }
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
             const int x = tid + 256 * k;
-            if (x < RS3_CAND * PD_REC) recs[x / PD_REC][x % PD_REC] = rv[k];
+            if (worker && x < RS3_CAND * PD_REC) recs[x / PD_REC][x % PD_REC] = rv[k];
         }
     }
     __syncthreads();
@@ -461,7 +482,7 @@ __global__ __launch_bounds__(256) void rs3p_decide_kernel(Rs3Args a)
     if (tid < RS3_CAND) { hitv[tid] = 99; nanv[tid] = 99; }
     __syncthreads();
     // every (candidate, point) comparison side by side: the first point above the slice level (:45-47), the first NaN
-    for (int x = tid; x < RS3_CAND * PD_T; x += 256) {
+    for (int x = tid; x < RS3_CAND * PD_T; x += 320) {
         const int cc = x / PD_T, t = x % PD_T;
         const double llp = -tot[cc][1 + t];
         const double log_y = -tot[cc][0] + recs[cc][PD_T];                    // draw-f.cpp:28-29
@@ -737,7 +758,7 @@ int launch_rs3p_decide(hipStream_t stream, const Rs3Args& a)
         GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rs3p_decide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, pad));
         attr_set = true;
     }
-    hipLaunchKernelGGL(rs3p_decide_kernel, dim3(RS3_CAND * PD_PARTS), dim3(256), pad, stream, a);
+    hipLaunchKernelGGL(rs3p_decide_kernel, dim3(RS3_CAND * PD_PARTS), dim3(320), pad, stream, a);
     GP_HIP(hipGetLastError());
     return 0;
 }

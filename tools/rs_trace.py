@@ -35,9 +35,12 @@ if os.environ.get("GPIRT_RS_PREDICT") in ("2", "3"):
 else:
     # the predictor's decide kernel (rs_predict.hip): start, walk + cos / sin done, terms done, ticket taken [, parts read, decided]
     for b, name in ((0, "work-group 0"), (16, "the last work-group of the grid")):
-        q = t[b:b + 15].astype(float) / 100.0
+        q = t[b:b + 6].astype(float) / 100.0
         q = q[q > 0]
         print(f"decide kernel, {name} (us from its start):", np.round(q - q[0], 2).tolist())
+        w = t[b + 6:b + 10].astype(float) / 100.0
+        if (w > 0).all():
+            print(f"    its wave 0: rows issued +{w[0] - q[0]:.2f}, uniforms in LDS +{w[1] - w[0]:.2f}, walk +{w[2] - w[1]:.2f}, cos / sin +{w[3] - w[2]:.2f}")
     for b in range(3):
         q = t[64 + 8 * b: 64 + 8 * b + 5].astype(float) / 100.0
         print(f"predictor products unit {b} (first / middle / last full): windows staged +{q[1]-q[0]:.2f}, MFMAs issued +{q[2]-q[1]:.2f}, barrier +{q[3]-q[2]:.2f}, "
