@@ -143,6 +143,7 @@ struct Rs3Args {
     int mispredict;                  // debug (gpirt_debug_rs_mispredict): the predictor is off by one at every mispredict-th item
     // rs3p_decide_kernel: partial sums [work-group][17], the candidates' walk records [32][18], the ticket (monotonic)
     double* dec_part; double* dec_rec; unsigned* dec_ticket;
+    uint64_t* pass_count;            // += 1 per real pass of the predictor (rs_ctl[3])
 };
 inline int64_t rs_tile_quads(int64_t n) { return (n + 3) / 4 + 1; }
 inline size_t rs_tile_doubles(int64_t n) { return (size_t)((n + RS_ROWS - 1) / RS_ROWS) * (size_t)rs_tile_quads(n) * 128; }

@@ -523,6 +523,7 @@ __global__ __launch_bounds__(320) void rs3p_decide_kernel(Rs3Args a)
     a.anchor[0] = item0 + (uint64_t)resolved;
     a.anchor[1] = cur;
     a.anchor[4] = next_round;
+    if (a.pass_count) *a.pass_count += 1;                      // (real passes so far: the host sizes the next draw's launches by it)
     if (stall) a.anchor[3] = 1;
     if (tr2) tr2[2] = (long long)wall_clock64();
     stamp();

@@ -117,6 +117,7 @@ struct gpirt_sampler_s {
     float *Lt32 = nullptr, *rs_part32 = nullptr;
     uint64_t *anchorP = nullptr, *rs_ctl = nullptr, *rs_posP = nullptr;
     double *rs_dec_part = nullptr, *rs_dec_rec = nullptr; unsigned* rs_dec_ticket = nullptr;
+    double rs_pass_rate = 0.0; uint64_t rs_pass_seen = 0;    // real predictor passes per item of the last round / the counter's last reading
     int *rs_kpred = nullptr, *rs_kv = nullptr, *rs_used = nullptr, *rs_ierr = nullptr, *rs_errP = nullptr;
     // bookkeeping
     int iter = 0;                     // completed iterations
@@ -457,12 +458,21 @@ int do_draw_f(gpirt_sampler_s* s)
         int64_t count = (left + RS3_SLOTS - 1) / RS3_SLOTS + left / 40 + 2;
         if (pass > 4 * m + 64) { set_error("R-stream replay: draw_f made no progress"); return GPIRT_E_NUMERIC; }   // (a pass resolves >= 1 item)
         if (predict) {
-            // (a slice loop that rejects 16 points in a row costs a pass of its own: one item in ten at 8192 x 1024)
-            if (h->cfg.rs_predict != 3) count = (left + RS3_SLOTS - 1) / RS3_SLOTS + left / 8 + 4;
+            // (a slice loop that rejects 16 points in a row costs a pass of its own.)  How many passes a draw needs is a property
+            // of the chain's state and moves slowly: the predictor counts its real passes (rs_ctl[3]) and the next draw enqueues
+            // that many per item + 3 % + 4 -- a pass that finds every item predicted leaves at once, but 120 of them per draw
+            // were 0.5 ms; too few only costs one more round of both phases for the items left over
+            if (h->cfg.rs_predict != 3) {
+                count = (left + RS3_SLOTS - 1) / RS3_SLOTS + left / 8 + 4;
+                if (s->rs_pass_rate > 0.0) {
+                    const int64_t hint = (int64_t)(s->rs_pass_rate * 1.03 * (double)left) + 4;
+                    if (hint < count) count = hint;
+                }
+            }
             Rs3Args ap = a;
             ap.anchor = s->anchorP; ap.pos = s->rs_posP; ap.k_out = s->rs_kpred; ap.err = s->rs_errP;
             ap.Lt32 = s->Lt32; ap.nk8 = rs32_tile_octs(n); ap.part32 = s->rs_part32; ap.mispredict = h->rs_mispredict;
-            ap.dec_part = s->rs_dec_part; ap.dec_rec = s->rs_dec_rec; ap.dec_ticket = s->rs_dec_ticket;
+            ap.dec_part = s->rs_dec_part; ap.dec_rec = s->rs_dec_rec; ap.dec_ticket = s->rs_dec_ticket; ap.pass_count = s->rs_ctl + 3;
             GP_TRY(launch_rs_pred_start(st, s->anchor, s->anchorP));
             for (int64_t q = 0; q < count; ++q, ++pass) {
                 s->rs_tag += 1ull << 20;
@@ -499,6 +509,7 @@ int do_draw_f(gpirt_sampler_s* s)
         }
         GP_HIP(hipMemcpyAsync(s->h_next, s->anchor, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         GP_HIP(hipMemcpyAsync(s->h_next + 1, s->flags, sizeof(int), hipMemcpyDeviceToHost, st));
+        if (predict) GP_HIP(hipMemcpyAsync(s->h_next + 2, s->rs_ctl + 3, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         if (s->stream_open && !topped) { GP_TRY(ahead_topup(s, stream_window(s))); topped = true; }     // the next window's uniforms, while the items run
         GP_HIP(hipStreamSynchronize(st));
         if ((int)s->h_next[1] != 0) break;                    // (an error flag: stream_end / check report it)
@@ -509,6 +520,12 @@ int do_draw_f(gpirt_sampler_s* s)
                 continue;
             }
             set_error("R-stream replay: draw_f made no progress"); return GPIRT_E_NUMERIC;
+        }
+        if (predict && (int64_t)s->h_next[0] > done) {
+            // real passes per item of this round (the counter is monotonic: difference to the last reading)
+            const uint64_t real = s->h_next[2] - s->rs_pass_seen;
+            s->rs_pass_seen = s->h_next[2];
+            s->rs_pass_rate = (double)real / (double)((int64_t)s->h_next[0] - done);
         }
         done = (int64_t)s->h_next[0];
     }
@@ -971,7 +988,7 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
             hipHostMalloc(&s->hA, s->U_cap * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
             hipHostMalloc(&s->h_pos, 2 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess ||
             hipStreamCreateWithFlags(&s->cs, hipStreamNonBlocking) != hipSuccess ||
-            hipHostMalloc(&s->h_next, 2 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc(&s->h_next, 4 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess ||
             hipEventCreateWithFlags(&s->ev_up, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s->ev_asm, hipEventDisableTiming) != hipSuccess) {
             set_error("pinned allocation for the R-stream window failed");
