@@ -637,7 +637,7 @@ def test_r_stream_predicted_replay_survives_a_wrong_predictor(handle, oracle, n,
     assert state[1] == mti_ref and np.array_equal(state[0], mt_ref)
 
 
-@pytest.mark.parametrize("n,m", [(257, 9), (1024, 33), (3000, 12)])
+@pytest.mark.parametrize("n,m", [(64, 1), (130, 2), (257, 9), (1024, 33), (3000, 12), (8200, 4)])
 def test_r_stream_predicted_replay_agrees_with_the_one_phase_replay(handle, n, m):
     """GPIRT_RS_PREDICT=2 runs every pass over L in fp64 (the one-phase replay of rng_ess.hip); the default predicts in single
     precision and verifies in fp64.  Same rejection counts, same theta, same stream position; f to rounding (nu = L z is summed
