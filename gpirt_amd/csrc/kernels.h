@@ -159,6 +159,11 @@ int launch_rs3_slice(hipStream_t stream, const Rs3Args& a);
 // side by side + an in-order commit)
 inline int64_t rs32_tile_octs(int64_t n) { return (n + 7) / 8 + 1; }
 inline size_t rs32_tile_floats(int64_t n) { return (size_t)((n + RS_ROWS - 1) / RS_ROWS) * (size_t)rs32_tile_octs(n) * 256; }
+#ifndef RS3P_KC_VALUE
+#define RS3P_KC_VALUE 512
+#endif
+constexpr int RS3P_KC = RS3P_KC_VALUE;   // columns of L per unit of the PREDICTOR's products (its own unit table: rs3p_unit_table)
+void rs3p_unit_table(int64_t n, std::vector<uint32_t>& units, int* nfull);
 struct RsVerifyArgs {
     const double* f; double* nu; const double* y; const double* mu;    // n x m; nu = the product's columns for items j0 .. (n x (m - j0)), f' on return
     int64_t n, m, j0;

@@ -26,6 +26,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "ll_fast.h"
+#include <vector>
 
 namespace gpirt {
 
@@ -66,7 +67,9 @@ __global__ __launch_bounds__(256) void rs32_tile_kernel(const double* __restrict
 // A FULL part (every wave has its 16 steps; 9 of 10 work-groups) issues all sixteen kilobytes of its wave up front,
 // unconditionally: the compiler's vmcnt bookkeeping then lets step s start when ITS kilobyte has arrived (a load under a
 // run-time condition anywhere in the loop makes it wait for every outstanding load at every step: 44 instead of ~20 us per pass).
-constexpr int P32_STEPS = RS_KC / 32;
+constexpr int P32_STEPS = RS3P_KC / 32;
+constexpr int P32_LDS = (5 * RS3P_KC + 64 > 4 * 1024) ? 5 * RS3P_KC + 64 : 4 * 1024;       // the windows, then the four waves' 32 x 32 sums
+// (units of 1024 columns instead of 512 -- half the prologues: 37.5 instead of 30 us per pass, gpurun_out/r7l;)
 // (steps of L in flight per wave / work-groups per compute unit: 4 ... 16 / 5 ... 8 all measure 30.1-32.3 us per pass -- the pass is
 //  bound by the f32 MFMAs at the clock the chip holds under them (26 us with NO loads of L) and by the 134 MB (25 us with NO MFMAs)
 //  alike, gpurun_out/r6f, r6u)
@@ -83,11 +86,11 @@ __device__ __forceinline__ void rs3p_product_unit(const Rs3Args& a, const uint64
     const int64_t n = a.n;
     const int64_t r0 = (int64_t)bx * RS_ROWS;
     const int64_t kall = (r0 + RS_ROWS < n) ? r0 + RS_ROWS : n;
-    const int64_t k0 = (int64_t)by * RS_KC;
+    const int64_t k0 = (int64_t)by * RS3P_KC;
     if (!FULL && k0 >= kall) return;
-    const int64_t kend = FULL ? k0 + RS_KC : ((k0 + RS_KC < kall) ? k0 + RS_KC : kall);          // this part's columns [k0, kend)
+    const int64_t kend = FULL ? k0 + RS3P_KC : ((k0 + RS3P_KC < kall) ? k0 + RS3P_KC : kall);          // this part's columns [k0, kend)
     const int kw = (int)(kend - k0);
-    // this wave's steps: octs of 8 columns, a quarter of RS_KC per wave
+    // this wave's steps: octs of 8 columns, a quarter of RS3P_KC per wave
     const int64_t o_beg = (k0 >> 3) + (int64_t)kq * P32_STEPS;
     int steps = P32_STEPS;
     if (!FULL) {
@@ -97,8 +100,8 @@ __device__ __forceinline__ void rs3p_product_unit(const Rs3Args& a, const uint64
         steps = o_end > o_beg ? (int)(o_end - o_beg) : 0;
     }
     const float* Lp = a.Lt32 + ((int64_t)bx * a.nk8 + o_beg) * 256 + 4 * lane;
-    float* W0 = lds; float* W1 = lds + RS_KC; float* W2 = W1 + 2 * RS_KC + 16;
-    static_assert(RS_KC + (2 * RS_KC + 16) + (2 * RS_KC + 32) <= 4 * 1024 + 64, "the windows must fit");
+    float* W0 = lds; float* W1 = lds + RS3P_KC; float* W2 = W1 + 2 * RS3P_KC + 16;
+    static_assert(RS3P_KC + (2 * RS3P_KC + 16) + (2 * RS3P_KC + 32) <= P32_LDS, "the windows must fit");
     const uint64_t item_step = 2ull * (uint64_t)n + 2ull;
     const double* N0 = a.Nrm + base + 2ull * (uint64_t)k0;
     const double* N1 = N0 + item_step;
@@ -106,22 +109,22 @@ __device__ __forceinline__ void rs3p_product_unit(const Rs3Args& a, const uint64
     float4 lv[P32_RINGF];
     if (FULL) {
         // the windows' loads go out first (L2 hits), the wave's sixteen kilobytes of L straight behind them
-        constexpr int C0 = RS_KC / 256, C1 = (2 * RS_KC + 16 + 255) / 256, C2 = (2 * RS_KC + 32 + 255) / 256;
+        constexpr int C0 = RS3P_KC / 256, C1 = (2 * RS3P_KC + 16 + 255) / 256, C2 = (2 * RS3P_KC + 32 + 255) / 256;
         double w0[C0], w1[C1], w2[C2];
 #pragma unroll
         for (int q = 0; q < C0; ++q) w0[q] = N0[2 * (tid + 256 * q)];
 #pragma unroll
-        for (int q = 0; q < C1; ++q) { const int x = tid + 256 * q; w1[q] = N1[x < 2 * RS_KC + 16 ? x : 0]; }
+        for (int q = 0; q < C1; ++q) { const int x = tid + 256 * q; w1[q] = N1[x < 2 * RS3P_KC + 16 ? x : 0]; }
 #pragma unroll
-        for (int q = 0; q < C2; ++q) { const int x = tid + 256 * q; w2[q] = N2[x < 2 * RS_KC + 32 ? x : 0]; }
+        for (int q = 0; q < C2; ++q) { const int x = tid + 256 * q; w2[q] = N2[x < 2 * RS3P_KC + 32 ? x : 0]; }
 #pragma unroll
         for (int u = 0; u < P32_RINGF; ++u) lv[u] = *reinterpret_cast<const float4*>(Lp + (int64_t)u * 256);
 #pragma unroll
         for (int q = 0; q < C0; ++q) W0[tid + 256 * q] = (float)w0[q];
 #pragma unroll
-        for (int q = 0; q < C1; ++q) { const int x = tid + 256 * q; if (x < 2 * RS_KC + 16) W1[x] = (float)w1[q]; }
+        for (int q = 0; q < C1; ++q) { const int x = tid + 256 * q; if (x < 2 * RS3P_KC + 16) W1[x] = (float)w1[q]; }
 #pragma unroll
-        for (int q = 0; q < C2; ++q) { const int x = tid + 256 * q; if (x < 2 * RS_KC + 32) W2[x] = (float)w2[q]; }
+        for (int q = 0; q < C2; ++q) { const int x = tid + 256 * q; if (x < 2 * RS3P_KC + 32) W2[x] = (float)w2[q]; }
     } else {
         // (entries of the windows this part can touch; a ragged last oct reads up to 7 columns past the part -- zeros in the
         // tile, so the normals there must be staged too: an unstaged LDS word may hold a NaN)
@@ -180,8 +183,8 @@ __device__ __forceinline__ void rs3p_product_unit(const Rs3Args& a, const uint64
 
 __global__ __launch_bounds__(256, P32_OCC) void rs3p_products_kernel(Rs3Args a)
 {
-    // windows: W0 RS_KC floats | W1 2 RS_KC + 16 | W2 2 RS_KC + 32; then the four waves' 32 x 32 accumulators (16 KB)
-    __shared__ __attribute__((aligned(16))) float lds[4 * 1024 + 64];
+    // windows: W0 RS3P_KC floats | W1 2 RS3P_KC + 16 | W2 2 RS3P_KC + 32; then the four waves' 32 x 32 accumulators (16 KB)
+    __shared__ __attribute__((aligned(16))) float lds[P32_LDS];
     const uint64_t item0 = a.anchor[0], base = a.anchor[1], stalled = a.anchor[3];
     const uint32_t unit = a.units[blockIdx.x];
     if (item0 >= (uint64_t)a.m || stalled != 0) return;       // every item is predicted, or the predictor has stalled
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(320) void rs3p_decide_kernel(Rs3Args a)
     double yd[PD_RB], fd[PD_RB], md[PD_RB];
     // parts of the candidate's column that can hold something for this work-group's rows: the parts BEHIND a row's own columns
     // were never written by the products and still hold the zeros of the sampler's creation, so every row simply adds pmax parts
-    const int pmax = (int)((((r_end < n ? r_end : n) + RS_KC - 1) / RS_KC));
+    const int pmax = (int)((((r_end < n ? r_end : n) + RS3P_KC - 1) / RS3P_KC));
     const int64_t pstep = (int64_t)RS3_CAND * n;
     // Every load of a row is UNCONDITIONAL (rows past the part's end read the last row of the matrix and are masked when the
     // values are used): a load under a predicate is followed by its select, and the select waits for the load -- twelve
@@ -762,6 +765,23 @@ int launch_rs3p_decide(hipStream_t stream, const Rs3Args& a)
     hipLaunchKernelGGL(rs3p_decide_kernel, dim3(RS3_CAND * PD_PARTS), dim3(320), pad, stream, a);
     GP_HIP(hipGetLastError());
     return 0;
+}
+
+// the predictor's work-groups: every (row group, part of RS3P_KC columns) that holds a non-zero of L, full parts first
+void rs3p_unit_table(int64_t n, std::vector<uint32_t>& units, int* nfull)
+{
+    std::vector<uint32_t> ragged;
+    units.clear();
+    const int64_t nbx = (n + RS_ROWS - 1) / RS_ROWS;
+    for (int64_t bx = 0; bx < nbx; ++bx) {
+        const int64_t kall = ((bx + 1) * RS_ROWS < n) ? (bx + 1) * RS_ROWS : n;
+        for (int64_t by = 0; by * RS3P_KC < kall; ++by) {
+            const uint32_t u = (uint32_t)bx | ((uint32_t)by << 16);
+            if ((by + 1) * RS3P_KC <= kall) units.push_back(u); else ragged.push_back(u);
+        }
+    }
+    *nfull = (int)units.size();
+    units.insert(units.end(), ragged.begin(), ragged.end());
 }
 
 int launch_rs_pred_start(hipStream_t stream, const uint64_t* anchor, uint64_t* anchorP)

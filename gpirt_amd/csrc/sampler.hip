@@ -111,6 +111,7 @@ struct gpirt_sampler_s {
     double* Lt = nullptr;             // L in the candidate products' tile order (rebuilt at the start of every draw_f)
     double *Nrm = nullptr, *rs_part = nullptr;
     uint32_t* rs_units = nullptr; int rs_nunits = 0, rs_nfull = 0;
+    uint32_t* rs_unitsP = nullptr; int rs_nunitsP = 0, rs_nfullP = 0;     // the predictor's own units (RS3P_KC columns each)
     long long* rs_trace = nullptr;    // debug stamps of one pass (gpirt_debug_rs_trace)
     // the predicted replay (rs_predict.hip): single-precision tiles of L and parts, the predictor's own anchor / cursor / error
     // word, what the verification leaves per item, ctl = [first item not committed, mispredictions, predictor stalls, passes]
@@ -471,6 +472,7 @@ int do_draw_f(gpirt_sampler_s* s)
             }
             Rs3Args ap = a;
             ap.anchor = s->anchorP; ap.pos = s->rs_posP; ap.k_out = s->rs_kpred; ap.err = s->rs_errP;
+            ap.units = s->rs_unitsP; ap.nunits = s->rs_nunitsP; ap.nfull = s->rs_nfullP;
             ap.Lt32 = s->Lt32; ap.nk8 = rs32_tile_octs(n); ap.part32 = s->rs_part32; ap.mispredict = h->rs_mispredict;
             ap.dec_part = s->rs_dec_part; ap.dec_rec = s->rs_dec_rec; ap.dec_ticket = s->rs_dec_ticket; ap.pass_count = s->rs_ctl + 3;
             GP_TRY(launch_rs_pred_start(st, s->anchor, s->anchorP));
@@ -966,12 +968,14 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
             hipMemsetAsync(s->Nrm, 0, sizeof(double) * nrm, st);              // (positions no draw has filled are read, never used)
             hipMemsetAsync(s->rs_part, 0, sizeof(double) * parts * RS3_CAND * (size_t)n, st);
             hipMemsetAsync(s->anchor, 0, 4 * sizeof(uint64_t), st);
-            GP_A(s->Lt32, rs32_tile_floats(n));   GP_A(s->rs_part32, parts * RS3_CAND * (size_t)n);
+            static_assert(RS3P_KC == RS_KC, "GPIRT_RS_PREDICT=3 reads the predictor's parts with the one-phase kernel's part width");
+            const size_t partsP = (size_t)((n + RS3P_KC - 1) / RS3P_KC);
+            GP_A(s->Lt32, rs32_tile_floats(n));   GP_A(s->rs_part32, partsP * RS3_CAND * (size_t)n);
             GP_A(s->anchorP, 8);     GP_A(s->rs_ctl, 8);     GP_A(s->rs_posP, 2);
             GP_A(s->rs_dec_part, (size_t)RS3_CAND * 8 * 17 + 8);  GP_A(s->rs_dec_rec, (size_t)RS3_CAND * 18 + 8);  GP_A(s->rs_dec_ticket, 4);
             hipMemsetAsync(s->rs_dec_ticket, 0, 4 * sizeof(unsigned), st);
             GP_A(s->rs_kpred, m);    GP_A(s->rs_kv, m);      GP_A(s->rs_used, m);     GP_A(s->rs_ierr, m);    GP_A(s->rs_errP, 4);
-            hipMemsetAsync(s->rs_part32, 0, sizeof(float) * parts * RS3_CAND * (size_t)n, st);
+            hipMemsetAsync(s->rs_part32, 0, sizeof(float) * partsP * RS3_CAND * (size_t)n, st);
             hipMemsetAsync(s->anchorP, 0, 8 * sizeof(uint64_t), st);
             hipMemsetAsync(s->rs_ctl, 0, 8 * sizeof(uint64_t), st);
             hipMemsetAsync(s->rs_errP, 0, 4 * sizeof(int), st);
@@ -980,6 +984,12 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
             s->rs_nunits = (int)units.size();
             GP_A(s->rs_units, units.size());
             hipMemcpyAsync(s->rs_units, units.data(), units.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+            std::vector<uint32_t> unitsP;
+            rs3p_unit_table(n, unitsP, &s->rs_nfullP);
+            s->rs_nunitsP = (int)unitsP.size();
+            GP_A(s->rs_unitsP, unitsP.size());
+            hipMemcpyAsync(s->rs_unitsP, unitsP.data(), unitsP.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+            hipStreamSynchronize(st);                                          // (unitsP leaves scope with units below)
             hipStreamSynchronize(st);                                          // (units leaves scope)
         }
         GP_A(s->beta_off, m);
