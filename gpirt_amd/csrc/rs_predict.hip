@@ -433,10 +433,23 @@ __global__ __launch_bounds__(320) void rs3p_decide_kernel(Rs3Args a)
     // behind it in the work-group that arrives last
     if (tid == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #endif
-    if (tid == 0) s_old = __hip_atomic_fetch_add(a.dec_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // The ticket, in two levels: 256 adds to ONE word queue up in the L2 (~12 ns each: the last of them waited ~3 us); the
+    // work-groups of one row part (32 of them, one per candidate) share a word on a line of its own, and the last of each
+    // adds to the top word.  Whoever is last THERE knows every part is in memory: each arrival's stores had been waited for
+    // before its add, and each first-level "last" saw all of its group's adds.  (A stale read here could only cost a
+    // misprediction -- the exact phase verifies every count.)
+    if (tid == 0) {
+        unsigned last = 0;
+        const unsigned o1 = __hip_atomic_fetch_add(a.dec_ticket + 32 * (1 + p), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((o1 % (unsigned)RS3_CAND) == (unsigned)RS3_CAND - 1u) {
+            const unsigned o2 = __hip_atomic_fetch_add(a.dec_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (o2 % (unsigned)PD_PARTS) == (unsigned)PD_PARTS - 1u;
+        }
+        s_old = last;
+    }
     __syncthreads();
     stamp();
-    if ((s_old % (unsigned)gridDim.x) != (unsigned)gridDim.x - 1u) return;      // not the last to arrive
+    if (s_old == 0) return;                                     // not the last to arrive
 #ifdef GPIRT_PANEL_FENCES
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -972,8 +972,8 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
             const size_t partsP = (size_t)((n + RS3P_KC - 1) / RS3P_KC);
             GP_A(s->Lt32, rs32_tile_floats(n));   GP_A(s->rs_part32, partsP * RS3_CAND * (size_t)n);
             GP_A(s->anchorP, 8);     GP_A(s->rs_ctl, 8);     GP_A(s->rs_posP, 2);
-            GP_A(s->rs_dec_part, (size_t)RS3_CAND * 8 * 17 + 8);  GP_A(s->rs_dec_rec, (size_t)RS3_CAND * 18 + 8);  GP_A(s->rs_dec_ticket, 4);
-            hipMemsetAsync(s->rs_dec_ticket, 0, 4 * sizeof(unsigned), st);
+            GP_A(s->rs_dec_part, (size_t)RS3_CAND * 8 * 17 + 8);  GP_A(s->rs_dec_rec, (size_t)RS3_CAND * 18 + 8);  GP_A(s->rs_dec_ticket, 32 * 9);      // the top word + one per row part, 128 bytes apart
+            hipMemsetAsync(s->rs_dec_ticket, 0, 32 * 9 * sizeof(unsigned), st);
             GP_A(s->rs_kpred, m);    GP_A(s->rs_kv, m);      GP_A(s->rs_used, m);     GP_A(s->rs_ierr, m);    GP_A(s->rs_errP, 4);
             hipMemsetAsync(s->rs_part32, 0, sizeof(float) * partsP * RS3_CAND * (size_t)n, st);
             hipMemsetAsync(s->anchorP, 0, 8 * sizeof(uint64_t), st);
