@@ -178,7 +178,7 @@ __device__ __forceinline__ void rs3p_product_unit(const Rs3Args& a, const uint64
         const float v = ((red[x] + red[1024 + x]) + red[2048 + x]) + red[3072 + x];
         if (r0 + row < n) out[(int64_t)cand * n + row] = v;
     }
-    if (tr) tr[4] = (long long)wall_clock64();
+    if (tr) { tr[4] = (long long)wall_clock64(); tr[6] = (long long)clock64(); }
 }
 
 __global__ __launch_bounds__(256, P32_OCC) void rs3p_products_kernel(Rs3Args a)
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, P32_OCC) void rs3p_products_kernel(Rs3Args a)
     // debug stamps (gpirt_debug_rs_trace; tools/rs_trace.py): first / middle / last full unit, 8 words each from trace[64]
     long long* tr = (a.trace && threadIdx.x == 0 && (blockIdx.x == 0 || (int)blockIdx.x == a.nfull / 2 || (int)blockIdx.x == a.nfull - 1))
                         ? a.trace + 64 + 8 * (blockIdx.x == 0 ? 0 : (int)blockIdx.x == a.nfull / 2 ? 1 : 2) : nullptr;
-    if (tr) tr[0] = (long long)wall_clock64();
+    if (tr) { tr[0] = (long long)wall_clock64(); tr[5] = (long long)clock64(); }
     if ((int)blockIdx.x < a.nfull) rs3p_product_unit<true>(a, base, bx, by, lds, tr);
     else                           rs3p_product_unit<false>(a, base, bx, by, lds, tr);
 }

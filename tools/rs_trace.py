@@ -37,13 +37,17 @@ else:
     for b, name in ((0, "work-group 0"), (16, "the last work-group of the grid")):
         q = t[b:b + 6].astype(float) / 100.0
         q = q[q > 0]
+        if len(q) == 0:
+            print(f"decide kernel, {name}: no stamps (the pass asked for found every item predicted?)")
+            continue
         print(f"decide kernel, {name} (us from its start):", np.round(q - q[0], 2).tolist())
         w = t[b + 6:b + 10].astype(float) / 100.0
         if (w > 0).all():
             print(f"    its wave 0: rows issued +{w[0] - q[0]:.2f}, uniforms in LDS +{w[1] - w[0]:.2f}, walk +{w[2] - w[1]:.2f}, cos / sin +{w[3] - w[2]:.2f}")
     for b in range(3):
         q = t[64 + 8 * b: 64 + 8 * b + 5].astype(float) / 100.0
+        cyc = int(t[64 + 8 * b + 6] - t[64 + 8 * b + 5])
         print(f"predictor products unit {b} (first / middle / last full): windows staged +{q[1]-q[0]:.2f}, MFMAs issued +{q[2]-q[1]:.2f}, barrier +{q[3]-q[2]:.2f}, "
-              f"sum + store +{q[4]-q[3]:.2f}; started {q[0]-t[64]/100.0:.2f} us after unit 0")
+              f"sum + store +{q[4]-q[3]:.2f}; started {q[0]-t[64]/100.0:.2f} us after unit 0; shader clock {cyc / max(q[4]-q[0], 1e-9):.0f} MHz")
     print("decide kernel, the LAST ARRIVER (work-group %d): ticket returned %.2f us after work-group 0 started, parts read +%.2f, decided +%.2f; work-group 255 started %.2f us after work-group 0"
           % (t[36], (t[32] - t[0]) / 100.0, (t[33] - t[32]) / 100.0, (t[34] - t[33]) / 100.0, (t[16] - t[0]) / 100.0))
