@@ -175,7 +175,7 @@ struct RsVerifyArgs {
 int launch_rs32_tiles(hipStream_t stream, const double* L, int64_t n, int64_t ldl, float* Lt);
 int launch_rs3p_products(hipStream_t stream, const Rs3Args& a);
 int launch_rs3p_decide(hipStream_t stream, const Rs3Args& a);
-int launch_rs_pred_start(hipStream_t stream, const uint64_t* anchor, uint64_t* anchorP);
+int launch_rs_pred_start(hipStream_t stream, const uint64_t* anchor, uint64_t* anchorP, const int* k_last, int64_t m);
 int launch_rs_gather(hipStream_t stream, const double* Nrm, const uint64_t* posv, const uint64_t* anchorP, int64_t n, int64_t j0,
                      int64_t m, double* Z);
 int launch_rs_verify(hipStream_t stream, const RsVerifyArgs& a);

@@ -80,7 +80,7 @@ constexpr int P32_LDS = (5 * RS3P_KC + 64 > 4 * 1024) ? 5 * RS3P_KC + 64 : 4 * 1
 #define P32_OCC 5
 #endif
 template <bool FULL>
-__device__ __forceinline__ void rs3p_product_unit(const Rs3Args& a, const uint64_t base, const int bx, const int by, float* lds, long long* tr)
+__device__ __forceinline__ void rs3p_product_unit(const Rs3Args& a, const uint64_t base, const uint64_t off, const uint64_t lo2, const int bx, const int by, float* lds, long long* tr)
 {
     const int tid = threadIdx.x, lane = tid & 63, kq = tid >> 6, c = lane & 31, hh = lane >> 5;
     const int64_t n = a.n;
@@ -104,8 +104,8 @@ __device__ __forceinline__ void rs3p_product_unit(const Rs3Args& a, const uint64
     static_assert(RS3P_KC + (2 * RS3P_KC + 16) + (2 * RS3P_KC + 32) <= P32_LDS, "the windows must fit");
     const uint64_t item_step = 2ull * (uint64_t)n + 2ull;
     const double* N0 = a.Nrm + base + 2ull * (uint64_t)k0;
-    const double* N1 = N0 + item_step;
-    const double* N2 = N1 + item_step;
+    const double* N1 = N0 + item_step + off;                    // (off: what the anchor's lost rounds have consumed, rs3p_decide_kernel)
+    const double* N2 = N1 + item_step + lo2;                    // (lo2: where slot 2's window of counts begins, rs_pred_start_kernel)
     float4 lv[P32_RINGF];
     if (FULL) {
         // the windows' loads go out first (L2 hits), the wave's sixteen kilobytes of L straight behind them
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256, P32_OCC) void rs3p_products_kernel(Rs3Args a)
 {
     // windows: W0 RS3P_KC floats | W1 2 RS3P_KC + 16 | W2 2 RS3P_KC + 32; then the four waves' 32 x 32 accumulators (16 KB)
     __shared__ __attribute__((aligned(16))) float lds[P32_LDS];
-    const uint64_t item0 = a.anchor[0], base = a.anchor[1], stalled = a.anchor[3];
+    const uint64_t item0 = a.anchor[0], base = a.anchor[1], stalled = a.anchor[3], off = a.anchor[5], lo2 = a.anchor[6];
     const uint32_t unit = a.units[blockIdx.x];
     if (item0 >= (uint64_t)a.m || stalled != 0) return;       // every item is predicted, or the predictor has stalled
     const int bx = (int)(unit & 0xffffu), by = (int)(unit >> 16);
@@ -193,8 +193,8 @@ __global__ __launch_bounds__(256, P32_OCC) void rs3p_products_kernel(Rs3Args a)
     long long* tr = (a.trace && threadIdx.x == 0 && (blockIdx.x == 0 || (int)blockIdx.x == a.nfull / 2 || (int)blockIdx.x == a.nfull - 1))
                         ? a.trace + 64 + 8 * (blockIdx.x == 0 ? 0 : (int)blockIdx.x == a.nfull / 2 ? 1 : 2) : nullptr;
     if (tr) { tr[0] = (long long)wall_clock64(); tr[5] = (long long)clock64(); }
-    if ((int)blockIdx.x < a.nfull) rs3p_product_unit<true>(a, base, bx, by, lds, tr);
-    else                           rs3p_product_unit<false>(a, base, bx, by, lds, tr);
+    if ((int)blockIdx.x < a.nfull) rs3p_product_unit<true>(a, base, off, lo2, bx, by, lds, tr);
+    else                           rs3p_product_unit<false>(a, base, off, lo2, bx, by, lds, tr);
 }
 
 // ---- the predictor's slice loops: ONE meeting per pass -------------------------------------------------------------------
@@ -216,7 +216,8 @@ constexpr int PD_T = 16;                 // trial points per candidate and pass
 constexpr int PD_PARTS = 8;              // row parts per candidate
 constexpr int PD_V = PD_T + 1;           // sums per work-group: ll(f), then the trial points
 constexpr int PD_MAXROUND = 14;          // 2 + PD_T * (PD_MAXROUND + 1) uniforms staged <= 256
-constexpr int PD_REC = PD_T + 2;         // per candidate: uniforms consumed when point t is the current one (-1: past the window), log(u), valid
+constexpr int PD_REC = PD_T + 3;         // per candidate: uniforms consumed when point t is the current one (-1: past the window), log(u), valid,
+                                         // uniforms consumed when the NEXT round's first point is the current one
 
 __global__ __launch_bounds__(320) void rs3p_decide_kernel(Rs3Args a)
 {
@@ -229,14 +230,15 @@ __global__ __launch_bounds__(320) void rs3p_decide_kernel(Rs3Args a)
     __shared__ unsigned s_old;
     __shared__ int hitv[RS3_CAND], nanv[RS3_CAND];
     const int tid = threadIdx.x;
-    const uint64_t item0 = a.anchor[0], start = a.anchor[1], nrm_end = a.anchor[2], stalled = a.anchor[3], round0 = a.anchor[4];
+    const uint64_t item0 = a.anchor[0], start = a.anchor[1], nrm_end = a.anchor[2], stalled = a.anchor[3], round0 = a.anchor[4], off0 = a.anchor[5], lo2 = a.anchor[6];
     if (item0 >= (uint64_t)a.m || stalled != 0) return;       // every item is predicted, or the predictor has stalled
     const int64_t n = a.n;
     const int c = (int)blockIdx.x / PD_PARTS, p = (int)blockIdx.x % PD_PARTS;
     const int g = (c == 0) ? 0 : (c < 16 ? 1 : 2);
     const int64_t j = (int64_t)item0 + g;
     const uint64_t item_step = 2ull * (uint64_t)n + 2ull;
-    const uint64_t start_c = start + (uint64_t)g * item_step + (uint64_t)(c == 0 ? 0 : c < 16 ? c - 1 : c - 16);
+    // (an anchor in round r has consumed off0 uniforms in its lost rounds: the candidate starts of the items behind it begin there)
+    const uint64_t start_c = start + (uint64_t)g * item_step + (c == 0 ? 0ull : off0 + (c < 16 ? (uint64_t)(c - 1) : lo2 + (uint64_t)(c - 16)));
     const uint64_t p0 = start_c + 2ull * (uint64_t)n;           // behind the n normals
     const int rnd = (c == 0) ? (int)round0 : 0;
     // the item's 2n uniforms (all its normals were built) and its first two slice uniforms lie inside the window
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(320) void rs3p_decide_kernel(Rs3Args a)
         double uu[PD_T];
 #pragma unroll
         for (int t = 0; t < PD_T; ++t) uu[t] = uL[uidx + t];
-        double my_eps = 0.0, my_rec = 0.0;
+        double my_eps = 0.0, my_rec = 0.0, end_rec = 0.0;
         {
             double e0 = eps, emin = eps_min, emax = eps_max;
             bool closed = false, badf = bad;
@@ -353,6 +355,7 @@ __global__ __launch_bounds__(320) void rs3p_decide_kernel(Rs3Args a)
                 if (x != x) { badf = true; x = 0.5; }
                 e0 = emin + (emax - emin) * x;                      // :56
             }
+            end_rec = badf ? -1.0 : (double)(uidx + PD_T);
             if (closed) {
 #pragma unroll 1
                 for (int t = 0; t < PD_T; ++t) {
@@ -361,6 +364,7 @@ __global__ __launch_bounds__(320) void rs3p_decide_kernel(Rs3Args a)
                     if (eps_min == eps_max) eps = eps_min;          // R::runif(a, a) = a, nothing consumed
                     else eps = eps_min + (eps_max - eps_min) * next_u();
                 }
+                end_rec = bad ? -1.0 : (double)uidx;
             }
         }
         if (lane < PD_T) {
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(320) void rs3p_decide_kernel(Rs3Args a)
             sincos(my_eps, &sn, &cn);
             cs[lane] = cn; cs[PD_T + lane] = sn; rec[lane] = my_rec;
         }
-        if (lane == 0) rec[PD_T + 1] = valid ? 1.0 : 0.0;
+        if (lane == 0) { rec[PD_T + 1] = valid ? 1.0 : 0.0; rec[PD_T + 2] = end_rec; }
     }
     __syncthreads();
     stamp();
@@ -509,12 +513,17 @@ __global__ __launch_bounds__(320) void rs3p_decide_kernel(Rs3Args a)
     stamp();
     if (tid != 0) return;
     const int ns = ((int64_t)a.m - (int64_t)item0 < RS3_SLOTS) ? (int)((int64_t)a.m - (int64_t)item0) : RS3_SLOTS;
+    // usum: uniforms the slots in front have consumed beyond their first two -- counted from the anchor's start, so in a pass
+    // whose anchor has lost rounds it begins at off0 and the candidate columns of slots 1 / 2 are taken relative to that
     int usum = 0, resolved = 0, stall = 0;
-    uint64_t cur = start, next_round = 0;
+    uint64_t cur = start, next_round = 0, next_off = 0;
     for (int gg = 0; gg < ns; ++gg) {
         int col = 0;
-        if (gg == 1) { if (usum >= a.lim1) break; col = 1 + usum; }
-        if (gg == 2) { if (usum >= a.lim2) break; col = 16 + usum; }
+        if (gg >= 1) {
+            const int rel = usum - (int)off0 - (gg == 2 ? (int)lo2 : 0);
+            if (rel < 0 || rel >= (gg == 1 ? a.lim1 : a.lim2)) break;
+            col = (gg == 1 ? 1 : 16) + rel;
+        }
         const int64_t jj = (int64_t)item0 + gg;
         if (recs[col][PD_T + 1] == 0.0) { stall = 1; break; }               // past the window: the exact phase reports it if it is real
         const int rg = (gg == 0) ? (int)round0 : 0;
@@ -523,7 +532,8 @@ __global__ __launch_bounds__(320) void rs3p_decide_kernel(Rs3Args a)
         if (nn < (hit < 0 ? PD_T : hit)) { stall = 1; break; }                 // NaN state: never accepts
         if (hit < 0) {                                                         // all PD_T points rejected: the next pass goes on from here
             next_round = (uint64_t)(rg + 1);
-            if (rg + 1 > PD_MAXROUND) stall = 1;
+            if (rg + 1 > PD_MAXROUND || recs[col][PD_T + 2] < 2.0) stall = 1;
+            else next_off = (uint64_t)((int)recs[col][PD_T + 2] - 2);
             break;
         }
         if (recs[col][hit] < 0.0) { stall = 1; break; }                       // a uniform past the window
@@ -539,6 +549,7 @@ __global__ __launch_bounds__(320) void rs3p_decide_kernel(Rs3Args a)
     a.anchor[0] = item0 + (uint64_t)resolved;
     a.anchor[1] = cur;
     a.anchor[4] = next_round;
+    a.anchor[5] = next_off;
     if (a.pass_count) *a.pass_count += 1;                      // (real passes so far: the host sizes the next draw's launches by it)
     if (stall) a.anchor[3] = 1;
     if (tr2) tr2[2] = (long long)wall_clock64();
@@ -546,10 +557,28 @@ __global__ __launch_bounds__(320) void rs3p_decide_kernel(Rs3Args a)
     if (tr) a.trace[15 + (blockIdx.x == 0 ? 0 : 16)] = ti;
 }
 
-// the predictor starts where the exact state stands
-__global__ void rs_pred_start_kernel(const uint64_t* __restrict__ anchor, uint64_t* __restrict__ anchorP)
+// The predictor starts where the exact state stands.  It also places slot 2's candidate window: the sixteen starts it can try
+// cover k0 + k1 in [lo2, lo2 + 16), and the sum of two counts has its mass around twice the mean count (8192 x 1024 in steady
+// state: mean 6.7, [0, 16) holds 68 % of the sums, [6, 22) 90 %; tools/k_histogram.py) -- so the window is centred on twice the
+// mean of the counts of the last draw.  (Whatever it is, only the number of passes depends on it.)
+__global__ __launch_bounds__(256) void rs_pred_start_kernel(const uint64_t* __restrict__ anchor, uint64_t* __restrict__ anchorP,
+                                                            const int* __restrict__ k_last, int64_t m)
 {
-    anchorP[0] = anchor[0]; anchorP[1] = anchor[1]; anchorP[2] = anchor[2]; anchorP[3] = 0; anchorP[4] = 0;
+    __shared__ long long part[256];
+    long long sum = 0;
+    if (k_last)
+        for (int64_t j = threadIdx.x; j < m; j += 256) { const int k = k_last[j]; sum += (k < 0) ? 0 : (k > 64 ? 64 : k); }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int q = 1; q < 256; ++q) sum += part[q];
+    long long lo2 = 0;
+    if (k_last && m > 0) {
+        lo2 = (long long)floor(2.0 * (double)sum / (double)m - 7.0);
+        lo2 = lo2 < 0 ? 0 : (lo2 > 24 ? 24 : lo2);
+    }
+    anchorP[0] = anchor[0]; anchorP[1] = anchor[1]; anchorP[2] = anchor[2]; anchorP[3] = 0; anchorP[4] = 0; anchorP[5] = 0;
+    anchorP[6] = (uint64_t)lo2;
 }
 
 // Z[:, j - j0] = the normals of item j at its predicted start, j in [j0, predicted); zeros behind
@@ -797,9 +826,9 @@ void rs3p_unit_table(int64_t n, std::vector<uint32_t>& units, int* nfull)
     units.insert(units.end(), ragged.begin(), ragged.end());
 }
 
-int launch_rs_pred_start(hipStream_t stream, const uint64_t* anchor, uint64_t* anchorP)
+int launch_rs_pred_start(hipStream_t stream, const uint64_t* anchor, uint64_t* anchorP, const int* k_last, int64_t m)
 {
-    hipLaunchKernelGGL(rs_pred_start_kernel, dim3(1), dim3(1), 0, stream, anchor, anchorP);
+    hipLaunchKernelGGL(rs_pred_start_kernel, dim3(1), dim3(256), 0, stream, anchor, anchorP, k_last, m);
     GP_HIP(hipGetLastError());
     return 0;
 }

@@ -475,7 +475,7 @@ int do_draw_f(gpirt_sampler_s* s)
             ap.units = s->rs_unitsP; ap.nunits = s->rs_nunitsP; ap.nfull = s->rs_nfullP;
             ap.Lt32 = s->Lt32; ap.nk8 = rs32_tile_octs(n); ap.part32 = s->rs_part32; ap.mispredict = h->rs_mispredict;
             ap.dec_part = s->rs_dec_part; ap.dec_rec = s->rs_dec_rec; ap.dec_ticket = s->rs_dec_ticket; ap.pass_count = s->rs_ctl + 3;
-            GP_TRY(launch_rs_pred_start(st, s->anchor, s->anchorP));
+            GP_TRY(launch_rs_pred_start(st, s->anchor, s->anchorP, h->cfg.rs_predict == 3 ? nullptr : s->ess_k, m));
             for (int64_t q = 0; q < count; ++q, ++pass) {
                 s->rs_tag += 1ull << 20;
                 ap.tag = s->rs_tag;
@@ -958,7 +958,7 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
         s->spec_ok = n >= RS_SPEC_MIN_N && n <= RS3_MAX_N && rs3_slice_wgs(n) <= h->n_cu;
         if (s->spec_ok) {
             const size_t parts = (size_t)((n + RS_KC - 1) / RS_KC);
-            const size_t nrm = (size_t)s->U_cap + 6 * (size_t)n + 128;        // (the products read up to 6n + 39 past an anchor)
+            const size_t nrm = (size_t)s->U_cap + 6 * (size_t)n + 512;        // (the products read up to 6n + 39 + 16 PD_MAXROUND past an anchor)
             GP_A(s->Lt, rs_tile_doubles(n));
             GP_A(s->posv, m + 1);    GP_A(s->anchor, 4);    GP_A(s->rs_trace, 128);
             hipMemsetAsync(s->rs_trace, 0, 128 * sizeof(long long), st);
@@ -972,7 +972,7 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
             const size_t partsP = (size_t)((n + RS3P_KC - 1) / RS3P_KC);
             GP_A(s->Lt32, rs32_tile_floats(n));   GP_A(s->rs_part32, partsP * RS3_CAND * (size_t)n);
             GP_A(s->anchorP, 8);     GP_A(s->rs_ctl, 8);     GP_A(s->rs_posP, 2);
-            GP_A(s->rs_dec_part, (size_t)RS3_CAND * 8 * 17 + 8);  GP_A(s->rs_dec_rec, (size_t)RS3_CAND * 18 + 8);  GP_A(s->rs_dec_ticket, 32 * 9);      // the top word + one per row part, 128 bytes apart
+            GP_A(s->rs_dec_part, (size_t)RS3_CAND * 8 * 17 + 8);  GP_A(s->rs_dec_rec, (size_t)RS3_CAND * 20 + 8);  GP_A(s->rs_dec_ticket, 32 * 9);      // the top word + one per row part, 128 bytes apart
             hipMemsetAsync(s->rs_dec_ticket, 0, 32 * 9 * sizeof(unsigned), st);
             GP_A(s->rs_kpred, m);    GP_A(s->rs_kv, m);      GP_A(s->rs_used, m);     GP_A(s->rs_ierr, m);    GP_A(s->rs_errP, 4);
             hipMemsetAsync(s->rs_part32, 0, sizeof(float) * partsP * RS3_CAND * (size_t)n, st);
