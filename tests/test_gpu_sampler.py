@@ -664,6 +664,41 @@ def test_r_stream_predicted_replay_agrees_with_the_one_phase_replay(handle, n, m
     assert q1[1] == 0 and q1[2] == 0                      # (no misprediction, no stall on these chains: the predictor earns its keep)
 
 
+def test_r_stream_predicted_replay_long_slice_loops(handle):
+    """Behind the burn-in of a chain with 8192 respondents the slice loops lengthen (mean count ~6, some above 16): a loop that
+    rejects all sixteen points of a pass goes on in the next pass (round + 1), the candidate starts of the items behind it begin
+    at what the lost rounds consumed, and slot 2's window of counts is centred on twice the last draw's mean (rs_predict.hip).
+    Sixty iterations both ways: same counts, theta and stream position as the one-phase replay; the predictor is (almost)
+    never wrong and never stalls, and needs fewer than 0.42 passes per item."""
+    from gpirt_amd import Sampler
+    from gpirt_amd.ops import RStream
+    from gpirt_amd.synthetic import make_responses
+    n, m, its = 8192, 48, 60
+    y, th0 = make_responses(n, m, seed=20240)
+    outs = []
+    for mode in (1, 2):
+        with handle.config("GPIRT_RS_PREDICT", mode):
+            rs = RStream(20240)
+            s = Sampler(handle, y, th0, rng="reference", rstream=rs, theta_stabilise=True)
+            s.init()
+            kmax, ks = 0, []
+            for i in range(its):
+                s.step()
+                if i >= its - 20:
+                    s.check()
+                    k = s.get("ess_k")
+                    kmax = max(kmax, int(k.max())); ks.append(k.copy())
+            s.check()
+            outs.append((np.array(ks), s.get("theta"), rs.state(), s.get("rs_stats"), kmax))
+            s.close()
+    (k1, t1, st1, q1, kmax1), (k2, t2, st2, q2, _) = outs
+    assert np.array_equal(k1, k2) and np.array_equal(t1, t2)
+    assert st1[1] == st2[1] and np.array_equal(st1[0], st2[0])
+    assert kmax1 >= 16, kmax1                             # (the regime this test is about was reached)
+    assert q1[1] <= 2 and q1[2] == 0, q1
+    assert q1[3] < 0.42 * its * m, q1
+
+
 @pytest.mark.parametrize("n,m", [(97, 11), (1025, 7), (640, 40)])
 def test_r_stream_draw_f_three_items_per_pass_odd_shapes(handle, oracle, n, m):
     """The replay's draw_f resolves up to three items per pass over L (rng_ess.hip): odd n (rows and columns past the last
