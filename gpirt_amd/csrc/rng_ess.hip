@@ -486,10 +486,7 @@ __global__ __launch_bounds__(256, 5) void rs3_products_kernel(Rs3Args a)
 // (Measured and not kept: each sum as ONE 16-byte record {value, tag ^ bits(value)} polled directly, no flag and no wait
 // for the stores -- fewer round trips on paper, 5.6 instead of 3.8 us per meeting: gpurun_out/r5o.)
 // The work-groups are the whole grid of a launch on an otherwise idle stream, <= one per CU: resident together.
-// PRED (rs_predict.hip, the predicted replay): the same loops on the single-precision candidate products of the predictor's
-// pass -- parts read as floats, nothing written to f, a failure only stalls the predictor (anchor[3]) instead of failing the
-// draw: what comes out are the predicted counts and start positions (k_out, posv) that the exact second phase verifies.
-template <int R, bool PRED = false>
+template <int R>
 __global__ __launch_bounds__(320) void rs3_slice_kernel(Rs3Args a)
 {
     constexpr int T = RS3_TRIALS, V = T + 1, RW = 32 * R;
@@ -504,7 +501,6 @@ __global__ __launch_bounds__(320) void rs3_slice_kernel(Rs3Args a)
     const int w = blockIdx.x, E = gridDim.x;
     const int64_t n = a.n;
     if (a.anchor[0] >= (uint64_t)a.m) return;                 // every item is done (or the draw has failed)
-    if (PRED && a.anchor[3] != 0) return;                     // the predictor has stalled: the exact phase takes over
     const int item0 = (int)a.anchor[0];
     const int ns = ((int)a.m - item0 < RS3_SLOTS) ? (int)a.m - item0 : RS3_SLOTS;
     const uint64_t nrm_end = a.anchor[2];
@@ -558,7 +554,7 @@ __global__ __launch_bounds__(320) void rs3_slice_kernel(Rs3Args a)
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const int64_t at = ((int64_t)(q0 + u) * RS3_CAND + col) * n + i;
-                            t[u] = (q0 + u < q1) ? (PRED ? (double)a.part32[at] : a.part[at]) : 0.0;
+                            t[u] = (q0 + u < q1) ? a.part[at] : 0.0;
                         }
 #pragma unroll
                         for (int u = 0; u < 4; ++u) v += t[u];
@@ -739,15 +735,13 @@ __global__ __launch_bounds__(320) void rs3_slice_kernel(Rs3Args a)
             }
         }
         if (fail) break;
-        if (!PRED && wv == 0 && hh == 0) {
+        if (wv == 0 && hh == 0) {
 #pragma unroll
             for (int e = 0; e < R; ++e) {
                 const int64_t i = i0 + 32 * e;
                 if (i < n) a.f[j * n + i] = F[e] * c + Vn[e] * sn;
             }
         }
-        // (tests: gpirt_debug_rs_mispredict makes the predictor wrong on purpose at every mis-th item)
-        if (PRED && a.mispredict > 0 && (j % a.mispredict) == a.mispredict - 1) uacc += 1;
         start = p0 + uacc;
         usum += (int)uacc - 2;
         ++resolved;
@@ -756,9 +750,7 @@ __global__ __launch_bounds__(320) void rs3_slice_kernel(Rs3Args a)
     rs_stamp(tr, ti++);
     if (tr && w == 0) a.trace[63] = ti;
     if (tid == 0) {
-        if (PRED) {
-            if (w == 0) { a.anchor[0] = (uint64_t)(item0 + resolved); a.anchor[1] = start; if (fail) a.anchor[3] = 1; }
-        } else if (fail) { atomicCAS(a.err, 0, fail); a.anchor[0] = (uint64_t)a.m; }        // every later kernel of the draw leaves at once
+        if (fail) { atomicCAS(a.err, 0, fail); a.anchor[0] = (uint64_t)a.m; }        // every later kernel of the draw leaves at once
         else if (w == 0) { a.anchor[0] = (uint64_t)(item0 + resolved); a.anchor[1] = start; *a.pos = start; }
     }
 }
@@ -1029,20 +1021,11 @@ int launch_rs3_slice(hipStream_t stream, const Rs3Args& a)
 {
     const int wgs = rs3_slice_wgs(a.n);
     if (wgs > RS3_MAX_WGS) { set_error("R-stream replay: n = %lld is beyond the slice kernel's %lld rows", (long long)a.n, (long long)RS3_MAX_N); return GPIRT_E_ARG; }
-    if (a.part32) {                  // the predictor's pass (rs_predict.hip)
-        switch (rs3_slice_rows(a.n)) {
-        case 1: hipLaunchKernelGGL((rs3_slice_kernel<1, true>), dim3((unsigned)wgs), dim3(320), 0, stream, a); break;
-        case 2: hipLaunchKernelGGL((rs3_slice_kernel<2, true>), dim3((unsigned)wgs), dim3(320), 0, stream, a); break;
-        case 4: hipLaunchKernelGGL((rs3_slice_kernel<4, true>), dim3((unsigned)wgs), dim3(320), 0, stream, a); break;
-        default: hipLaunchKernelGGL((rs3_slice_kernel<8, true>), dim3((unsigned)wgs), dim3(320), 0, stream, a); break;
-        }
-    } else {
-        switch (rs3_slice_rows(a.n)) {
-        case 1: hipLaunchKernelGGL((rs3_slice_kernel<1, false>), dim3((unsigned)wgs), dim3(320), 0, stream, a); break;
-        case 2: hipLaunchKernelGGL((rs3_slice_kernel<2, false>), dim3((unsigned)wgs), dim3(320), 0, stream, a); break;
-        case 4: hipLaunchKernelGGL((rs3_slice_kernel<4, false>), dim3((unsigned)wgs), dim3(320), 0, stream, a); break;
-        default: hipLaunchKernelGGL((rs3_slice_kernel<8, false>), dim3((unsigned)wgs), dim3(320), 0, stream, a); break;
-        }
+    switch (rs3_slice_rows(a.n)) {
+    case 1: hipLaunchKernelGGL((rs3_slice_kernel<1>), dim3((unsigned)wgs), dim3(320), 0, stream, a); break;
+    case 2: hipLaunchKernelGGL((rs3_slice_kernel<2>), dim3((unsigned)wgs), dim3(320), 0, stream, a); break;
+    case 4: hipLaunchKernelGGL((rs3_slice_kernel<4>), dim3((unsigned)wgs), dim3(320), 0, stream, a); break;
+    default: hipLaunchKernelGGL((rs3_slice_kernel<8>), dim3((unsigned)wgs), dim3(320), 0, stream, a); break;
     }
     GP_HIP(hipGetLastError());
     return 0;

@@ -67,20 +67,30 @@ __global__ __launch_bounds__(256) void rs32_tile_kernel(const double* __restrict
 // A FULL part (every wave has its 16 steps; 9 of 10 work-groups) issues all sixteen kilobytes of its wave up front,
 // unconditionally: the compiler's vmcnt bookkeeping then lets step s start when ITS kilobyte has arrived (a load under a
 // run-time condition anywhere in the loop makes it wait for every outstanding load at every step: 44 instead of ~20 us per pass).
+// A pass places up to FOUR items: the anchor (its start is known: one candidate) and three more, whose starts depend on the
+// counts in front of them -- slot 1 tries PD_W1 consecutive starts (k0 = 0 .. 12), slot 2 PD_W2 (k0 + k1 = lo2 .. lo2 + 10),
+// slot 3 PD_W3 (k0 + k1 + k2 = lo3 .. lo3 + 6); lo2 / lo3 follow the last draw's mean count (rs_pred_start_kernel).  On the
+// counts of a chain at 8192 x 1024 (tools/k_histogram.py) this layout needs 0.33 passes per item in steady state (mean count
+// 6.7) and 0.31 at the start (3.5); 1 + 15 + 16 starts for three items: 0.38 / 0.34, with the third's window moved 0.35 / 0.34.
+constexpr int PD_SLOTS = 4;
+constexpr int PD_W1 = 13, PD_W2 = 11, PD_W3 = 7;
+constexpr int PD_B2 = 1 + PD_W1, PD_B3 = PD_B2 + PD_W2;        // first candidate column of slots 2 / 3 (slot 1: column 1)
+static_assert(PD_B3 + PD_W3 == RS3_CAND, "the four slots' candidates are the pass's 32 columns");
 constexpr int P32_STEPS = RS3P_KC / 32;
-constexpr int P32_LDS = (5 * RS3P_KC + 64 > 4 * 1024) ? 5 * RS3P_KC + 64 : 4 * 1024;       // the windows, then the four waves' 32 x 32 sums
+constexpr int P32_WIN = 2 * RS3P_KC + 32;                      // a slot's window of normals: every other one from <= 13 consecutive starts
+constexpr int P32_LDS = (RS3P_KC + 3 * P32_WIN > 4 * 1024) ? RS3P_KC + 3 * P32_WIN : 4 * 1024;       // the windows, then the four waves' 32 x 32 sums
 // (units of 1024 columns instead of 512 -- half the prologues: 37.5 instead of 30 us per pass, gpurun_out/r7l;)
 // (steps of L in flight per wave / work-groups per compute unit: 4 ... 16 / 5 ... 8 all measure 30.1-32.3 us per pass -- the pass is
 //  bound by the f32 MFMAs at the clock the chip holds under them (26 us with NO loads of L) and by the 134 MB (25 us with NO MFMAs)
 //  alike, gpurun_out/r6f, r6u)
 #ifndef P32_RINGF
-#define P32_RINGF 16
+#define P32_RINGF 12
 #endif
 #ifndef P32_OCC
 #define P32_OCC 5
 #endif
 template <bool FULL>
-__device__ __forceinline__ void rs3p_product_unit(const Rs3Args& a, const uint64_t base, const uint64_t off, const uint64_t lo2, const int bx, const int by, float* lds, long long* tr)
+__device__ __forceinline__ void rs3p_product_unit(const Rs3Args& a, const uint64_t base, const uint64_t off, const uint64_t lo2, const uint64_t lo3, const int bx, const int by, float* lds, long long* tr)
 {
     const int tid = threadIdx.x, lane = tid & 63, kq = tid >> 6, c = lane & 31, hh = lane >> 5;
     const int64_t n = a.n;
@@ -100,46 +110,43 @@ __device__ __forceinline__ void rs3p_product_unit(const Rs3Args& a, const uint64
         steps = o_end > o_beg ? (int)(o_end - o_beg) : 0;
     }
     const float* Lp = a.Lt32 + ((int64_t)bx * a.nk8 + o_beg) * 256 + 4 * lane;
-    float* W0 = lds; float* W1 = lds + RS3P_KC; float* W2 = W1 + 2 * RS3P_KC + 16;
-    static_assert(RS3P_KC + (2 * RS3P_KC + 16) + (2 * RS3P_KC + 32) <= P32_LDS, "the windows must fit");
+    float* W0 = lds; float* W1 = lds + RS3P_KC; float* W2 = W1 + P32_WIN; float* W3 = W2 + P32_WIN;
+    static_assert(RS3P_KC + 3 * P32_WIN <= P32_LDS, "the windows must fit");
+    static_assert(PD_W1 <= 32 && PD_W2 <= 32 && PD_W3 <= 32, "a window holds 2 RS3P_KC + 32 normals");
     const uint64_t item_step = 2ull * (uint64_t)n + 2ull;
     const double* N0 = a.Nrm + base + 2ull * (uint64_t)k0;
     const double* N1 = N0 + item_step + off;                    // (off: what the anchor's lost rounds have consumed, rs3p_decide_kernel)
-    const double* N2 = N1 + item_step + lo2;                    // (lo2: where slot 2's window of counts begins, rs_pred_start_kernel)
+    const double* N2 = N1 + item_step + lo2;                    // (lo2 / lo3: where the windows of counts of slots 2 / 3 begin, rs_pred_start_kernel)
+    const double* N3 = N1 + 2ull * item_step + lo3;
     float4 lv[P32_RINGF];
     if (FULL) {
         // the windows' loads go out first (L2 hits), the wave's sixteen kilobytes of L straight behind them
-        constexpr int C0 = RS3P_KC / 256, C1 = (2 * RS3P_KC + 16 + 255) / 256, C2 = (2 * RS3P_KC + 32 + 255) / 256;
-        double w0[C0], w1[C1], w2[C2];
+        constexpr int C0 = RS3P_KC / 256, CW = (P32_WIN + 255) / 256;
+        double w0[C0], w1[CW], w2[CW], w3[CW];
 #pragma unroll
         for (int q = 0; q < C0; ++q) w0[q] = N0[2 * (tid + 256 * q)];
 #pragma unroll
-        for (int q = 0; q < C1; ++q) { const int x = tid + 256 * q; w1[q] = N1[x < 2 * RS3P_KC + 16 ? x : 0]; }
-#pragma unroll
-        for (int q = 0; q < C2; ++q) { const int x = tid + 256 * q; w2[q] = N2[x < 2 * RS3P_KC + 32 ? x : 0]; }
+        for (int q = 0; q < CW; ++q) { const int x = tid + 256 * q; const int xc = x < P32_WIN ? x : 0; w1[q] = N1[xc]; w2[q] = N2[xc]; w3[q] = N3[xc]; }
 #pragma unroll
         for (int u = 0; u < P32_RINGF; ++u) lv[u] = *reinterpret_cast<const float4*>(Lp + (int64_t)u * 256);
 #pragma unroll
         for (int q = 0; q < C0; ++q) W0[tid + 256 * q] = (float)w0[q];
 #pragma unroll
-        for (int q = 0; q < C1; ++q) { const int x = tid + 256 * q; if (x < 2 * RS3P_KC + 16) W1[x] = (float)w1[q]; }
-#pragma unroll
-        for (int q = 0; q < C2; ++q) { const int x = tid + 256 * q; if (x < 2 * RS3P_KC + 32) W2[x] = (float)w2[q]; }
+        for (int q = 0; q < CW; ++q) { const int x = tid + 256 * q; if (x < P32_WIN) { W1[x] = (float)w1[q]; W2[x] = (float)w2[q]; W3[x] = (float)w3[q]; } }
     } else {
         // (entries of the windows this part can touch; a ragged last oct reads up to 7 columns past the part -- zeros in the
         // tile, so the normals there must be staged too: an unstaged LDS word may hold a NaN)
         const int kw8 = (kw + 7) & ~7;
-        const int x1 = 2 * kw8 + 16, x2 = 2 * kw8 + 32;
+        const int x1 = 2 * kw8 + 32;
         for (int x = tid; x < kw8; x += 256) W0[x] = (float)N0[2 * x];
-        for (int x = tid; x < x1; x += 256) W1[x] = (float)N1[x];
-        for (int x = tid; x < x2; x += 256) W2[x] = (float)N2[x];
+        for (int x = tid; x < x1; x += 256) { W1[x] = (float)N1[x]; W2[x] = (float)N2[x]; W3[x] = (float)N3[x]; }
 #pragma unroll
         for (int u = 0; u < P32_RINGF; ++u) lv[u] = (u < steps) ? *reinterpret_cast<const float4*>(Lp + (int64_t)u * 256) : float4{ 0.f, 0.f, 0.f, 0.f };
     }
     __syncthreads();
     if (tr) tr[1] = (long long)wall_clock64();                 // windows staged
     // lane's candidate: column kk of the part is at Zb[zs * kk]
-    const float* Zb = (c == 0) ? W0 : (c < 16 ? W1 + (c - 1) : W2 + (c - 16));
+    const float* Zb = (c == 0) ? W0 : (c < PD_B2 ? W1 + (c - 1) : c < PD_B3 ? W2 + (c - PD_B2) : W3 + (c - PD_B3));
     const int zs = (c == 0) ? 1 : 2;
     const float* z = Zb + zs * ((int)((o_beg << 3) - k0) + 4 * hh);
     f16v acc;
@@ -183,9 +190,9 @@ __device__ __forceinline__ void rs3p_product_unit(const Rs3Args& a, const uint64
 
 __global__ __launch_bounds__(256, P32_OCC) void rs3p_products_kernel(Rs3Args a)
 {
-    // windows: W0 RS3P_KC floats | W1 2 RS3P_KC + 16 | W2 2 RS3P_KC + 32; then the four waves' 32 x 32 accumulators (16 KB)
+    // windows: W0 RS3P_KC floats | W1, W2, W3 2 RS3P_KC + 32 each; then the four waves' 32 x 32 accumulators (16 KB)
     __shared__ __attribute__((aligned(16))) float lds[P32_LDS];
-    const uint64_t item0 = a.anchor[0], base = a.anchor[1], stalled = a.anchor[3], off = a.anchor[5], lo2 = a.anchor[6];
+    const uint64_t item0 = a.anchor[0], base = a.anchor[1], stalled = a.anchor[3], off = a.anchor[5], lo2 = a.anchor[6], lo3 = a.anchor[7];
     const uint32_t unit = a.units[blockIdx.x];
     if (item0 >= (uint64_t)a.m || stalled != 0) return;       // every item is predicted, or the predictor has stalled
     const int bx = (int)(unit & 0xffffu), by = (int)(unit >> 16);
@@ -193,8 +200,8 @@ __global__ __launch_bounds__(256, P32_OCC) void rs3p_products_kernel(Rs3Args a)
     long long* tr = (a.trace && threadIdx.x == 0 && (blockIdx.x == 0 || (int)blockIdx.x == a.nfull / 2 || (int)blockIdx.x == a.nfull - 1))
                         ? a.trace + 64 + 8 * (blockIdx.x == 0 ? 0 : (int)blockIdx.x == a.nfull / 2 ? 1 : 2) : nullptr;
     if (tr) { tr[0] = (long long)wall_clock64(); tr[5] = (long long)clock64(); }
-    if ((int)blockIdx.x < a.nfull) rs3p_product_unit<true>(a, base, off, lo2, bx, by, lds, tr);
-    else                           rs3p_product_unit<false>(a, base, off, lo2, bx, by, lds, tr);
+    if ((int)blockIdx.x < a.nfull) rs3p_product_unit<true>(a, base, off, lo2, lo3, bx, by, lds, tr);
+    else                           rs3p_product_unit<false>(a, base, off, lo2, lo3, bx, by, lds, tr);
 }
 
 // ---- the predictor's slice loops: ONE meeting per pass -------------------------------------------------------------------
@@ -230,15 +237,15 @@ __global__ __launch_bounds__(320) void rs3p_decide_kernel(Rs3Args a)
     __shared__ unsigned s_old;
     __shared__ int hitv[RS3_CAND], nanv[RS3_CAND];
     const int tid = threadIdx.x;
-    const uint64_t item0 = a.anchor[0], start = a.anchor[1], nrm_end = a.anchor[2], stalled = a.anchor[3], round0 = a.anchor[4], off0 = a.anchor[5], lo2 = a.anchor[6];
+    const uint64_t item0 = a.anchor[0], start = a.anchor[1], nrm_end = a.anchor[2], stalled = a.anchor[3], round0 = a.anchor[4], off0 = a.anchor[5], lo2 = a.anchor[6], lo3 = a.anchor[7];
     if (item0 >= (uint64_t)a.m || stalled != 0) return;       // every item is predicted, or the predictor has stalled
     const int64_t n = a.n;
     const int c = (int)blockIdx.x / PD_PARTS, p = (int)blockIdx.x % PD_PARTS;
-    const int g = (c == 0) ? 0 : (c < 16 ? 1 : 2);
+    const int g = (c == 0) ? 0 : (c < PD_B2 ? 1 : c < PD_B3 ? 2 : 3);
     const int64_t j = (int64_t)item0 + g;
     const uint64_t item_step = 2ull * (uint64_t)n + 2ull;
     // (an anchor in round r has consumed off0 uniforms in its lost rounds: the candidate starts of the items behind it begin there)
-    const uint64_t start_c = start + (uint64_t)g * item_step + (c == 0 ? 0ull : off0 + (c < 16 ? (uint64_t)(c - 1) : lo2 + (uint64_t)(c - 16)));
+    const uint64_t start_c = start + (uint64_t)g * item_step + (c == 0 ? 0ull : off0 + (g == 1 ? (uint64_t)(c - 1) : g == 2 ? lo2 + (uint64_t)(c - PD_B2) : lo3 + (uint64_t)(c - PD_B3)));
     const uint64_t p0 = start_c + 2ull * (uint64_t)n;           // behind the n normals
     const int rnd = (c == 0) ? (int)round0 : 0;
     // the item's 2n uniforms (all its normals were built) and its first two slice uniforms lie inside the window
@@ -512,7 +519,7 @@ __global__ __launch_bounds__(320) void rs3p_decide_kernel(Rs3Args a)
     __syncthreads();
     stamp();
     if (tid != 0) return;
-    const int ns = ((int64_t)a.m - (int64_t)item0 < RS3_SLOTS) ? (int)((int64_t)a.m - (int64_t)item0) : RS3_SLOTS;
+    const int ns = ((int64_t)a.m - (int64_t)item0 < PD_SLOTS) ? (int)((int64_t)a.m - (int64_t)item0) : PD_SLOTS;
     // usum: uniforms the slots in front have consumed beyond their first two -- counted from the anchor's start, so in a pass
     // whose anchor has lost rounds it begins at off0 and the candidate columns of slots 1 / 2 are taken relative to that
     int usum = 0, resolved = 0, stall = 0;
@@ -520,9 +527,10 @@ __global__ __launch_bounds__(320) void rs3p_decide_kernel(Rs3Args a)
     for (int gg = 0; gg < ns; ++gg) {
         int col = 0;
         if (gg >= 1) {
-            const int rel = usum - (int)off0 - (gg == 2 ? (int)lo2 : 0);
-            if (rel < 0 || rel >= (gg == 1 ? a.lim1 : a.lim2)) break;
-            col = (gg == 1 ? 1 : 16) + rel;
+            const int rel = usum - (int)off0 - (gg == 1 ? 0 : gg == 2 ? (int)lo2 : (int)lo3);
+            const int wd = (gg == 1) ? (PD_W1 < a.lim1 ? PD_W1 : a.lim1) : ((gg == 2 ? PD_W2 : PD_W3) < a.lim2 ? (gg == 2 ? PD_W2 : PD_W3) : a.lim2);
+            if (rel < 0 || rel >= wd) break;
+            col = (gg == 1 ? 1 : gg == 2 ? PD_B2 : PD_B3) + rel;
         }
         const int64_t jj = (int64_t)item0 + gg;
         if (recs[col][PD_T + 1] == 0.0) { stall = 1; break; }               // past the window: the exact phase reports it if it is real
@@ -572,13 +580,16 @@ __global__ __launch_bounds__(256) void rs_pred_start_kernel(const uint64_t* __re
     __syncthreads();
     if (threadIdx.x != 0) return;
     for (int q = 1; q < 256; ++q) sum += part[q];
-    long long lo2 = 0;
+    long long lo2 = 0, lo3 = 0;
     if (k_last && m > 0) {
-        lo2 = (long long)floor(2.0 * (double)sum / (double)m - 7.0);
+        const double kbar = (double)sum / (double)m;
+        lo2 = (long long)floor(2.0 * kbar - 6.0);
+        lo3 = (long long)floor(3.0 * kbar - 4.0);
         lo2 = lo2 < 0 ? 0 : (lo2 > 24 ? 24 : lo2);
+        lo3 = lo3 < 0 ? 0 : (lo3 > 40 ? 40 : lo3);
     }
     anchorP[0] = anchor[0]; anchorP[1] = anchor[1]; anchorP[2] = anchor[2]; anchorP[3] = 0; anchorP[4] = 0; anchorP[5] = 0;
-    anchorP[6] = (uint64_t)lo2;
+    anchorP[6] = (uint64_t)lo2; anchorP[7] = (uint64_t)lo3;
 }
 
 // Z[:, j - j0] = the normals of item j at its predicted start, j in [j0, predicted); zeros behind

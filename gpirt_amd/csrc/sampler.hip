@@ -463,19 +463,17 @@ int do_draw_f(gpirt_sampler_s* s)
             // of the chain's state and moves slowly: the predictor counts its real passes (rs_ctl[3]) and the next draw enqueues
             // that many per item + 3 % + 4 -- a pass that finds every item predicted leaves at once, but 120 of them per draw
             // were 0.5 ms; too few only costs one more round of both phases for the items left over
-            if (h->cfg.rs_predict != 3) {
-                count = (left + RS3_SLOTS - 1) / RS3_SLOTS + left / 8 + 4;
-                if (s->rs_pass_rate > 0.0) {
-                    const int64_t hint = (int64_t)(s->rs_pass_rate * 1.03 * (double)left) + 4;
-                    if (hint < count) count = hint;
-                }
+            count = (left + RS3_SLOTS - 1) / RS3_SLOTS + left / 8 + 4;
+            if (s->rs_pass_rate > 0.0) {
+                const int64_t hint = (int64_t)(s->rs_pass_rate * 1.03 * (double)left) + 4;
+                if (hint < count) count = hint;
             }
             Rs3Args ap = a;
             ap.anchor = s->anchorP; ap.pos = s->rs_posP; ap.k_out = s->rs_kpred; ap.err = s->rs_errP;
             ap.units = s->rs_unitsP; ap.nunits = s->rs_nunitsP; ap.nfull = s->rs_nfullP;
             ap.Lt32 = s->Lt32; ap.nk8 = rs32_tile_octs(n); ap.part32 = s->rs_part32; ap.mispredict = h->rs_mispredict;
             ap.dec_part = s->rs_dec_part; ap.dec_rec = s->rs_dec_rec; ap.dec_ticket = s->rs_dec_ticket; ap.pass_count = s->rs_ctl + 3;
-            GP_TRY(launch_rs_pred_start(st, s->anchor, s->anchorP, h->cfg.rs_predict == 3 ? nullptr : s->ess_k, m));
+            GP_TRY(launch_rs_pred_start(st, s->anchor, s->anchorP, s->ess_k, m));
             for (int64_t q = 0; q < count; ++q, ++pass) {
                 s->rs_tag += 1ull << 20;
                 ap.tag = s->rs_tag;
@@ -484,7 +482,7 @@ int do_draw_f(gpirt_sampler_s* s)
                 GP_TRY(prof_pair_begin(h, st, pp));
                 GP_TRY(launch_rs3p_products(st, ap));
                 GP_TRY(prof_pair_end(h, st, pp, 4, 2.0 * RS3_CAND * 0.5 * (double)n * (double)(n + 1), 4.0 * 0.5 * (double)n * (double)(n + 1)));
-                GP_TRY(h->cfg.rs_predict == 3 ? launch_rs3_slice(st, ap) : launch_rs3p_decide(st, ap));
+                GP_TRY(launch_rs3p_decide(st, ap));
             }
             // phase B: the items [done, predicted) at their predicted starts, exactly
             const int64_t mc = m - done;
@@ -958,7 +956,7 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
         s->spec_ok = n >= RS_SPEC_MIN_N && n <= RS3_MAX_N && rs3_slice_wgs(n) <= h->n_cu;
         if (s->spec_ok) {
             const size_t parts = (size_t)((n + RS_KC - 1) / RS_KC);
-            const size_t nrm = (size_t)s->U_cap + 6 * (size_t)n + 512;        // (the products read up to 6n + 39 + 16 PD_MAXROUND past an anchor)
+            const size_t nrm = (size_t)s->U_cap + 8 * (size_t)n + 1024;       // (the predictor's products read up to 8n + 6 + 32 + 16 PD_MAXROUND + 40 past an anchor)
             GP_A(s->Lt, rs_tile_doubles(n));
             GP_A(s->posv, m + 1);    GP_A(s->anchor, 4);    GP_A(s->rs_trace, 128);
             hipMemsetAsync(s->rs_trace, 0, 128 * sizeof(long long), st);
@@ -968,7 +966,6 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
             hipMemsetAsync(s->Nrm, 0, sizeof(double) * nrm, st);              // (positions no draw has filled are read, never used)
             hipMemsetAsync(s->rs_part, 0, sizeof(double) * parts * RS3_CAND * (size_t)n, st);
             hipMemsetAsync(s->anchor, 0, 4 * sizeof(uint64_t), st);
-            static_assert(RS3P_KC == RS_KC, "GPIRT_RS_PREDICT=3 reads the predictor's parts with the one-phase kernel's part width");
             const size_t partsP = (size_t)((n + RS3P_KC - 1) / RS3P_KC);
             GP_A(s->Lt32, rs32_tile_floats(n));   GP_A(s->rs_part32, partsP * RS3_CAND * (size_t)n);
             GP_A(s->anchorP, 8);     GP_A(s->rs_ctl, 8);     GP_A(s->rs_posP, 2);
