@@ -345,7 +345,7 @@ def main():
                 ref_rng = {"value": 2.0 / dtr, "iterations": 2, "theta_stabilise": int(stab),
                            "passes_over_L_per_iteration": int(replay_prof[1]), "items_per_pass": (m / replay_prof[1]) if replay_prof[1] else None,
                            "draw_f": "predict + verify (csrc/rs_predict.hip): the starts of all items in R's stream predicted by passes over a "
-                                     "SINGLE-PRECISION copy of L (three items per pass, 32 candidate starts, 16 trial points each), then every item "
+                                     "SINGLE-PRECISION copy of L (up to four items per pass, 32 candidate starts, 16 trial points each), then every item "
                                      "computed exactly at its predicted start -- one fp64 triangular MFMA product + all slice loops side by side, the "
                                      "formula as written -- and committed in order; GPIRT_RS_PREDICT=2: every pass in fp64 (rounds 4-5)",
                            "mispredictions_found_by_the_verification_so_far": int(rs_stats[1]),
@@ -511,7 +511,7 @@ def main():
                                                   "operations per launch, exact int32 sums; peak = twice the dense bf16 rate "
                                                   "(MI355X_MICROARCH.md, matrix cores) at the nominal 2.4 GHz -- the chip holds ~1.8 GHz under this "
                                                   "kernel (tools/theta_clock.py).  The fp64 GEMM it replaces ran 0.52 ms at 0.91 of the fp64 MFMA peak"),
-                # the default contract's draw_f: one pass over L per three items (rs3_products_kernel), HBM-bound
+                # the default contract's draw_f: one pass over L per up to four items (rs3p_products_kernel), HBM-bound
                 "replay_products": _roof_entry(replay_prof, "hbm", PEAK_HBM_GBS, "GB/s",
                                                "rs3p_products_kernel (R-stream replay, gpirt_default_options): the predictor's pass over L as single-precision "
                                                "tiles; bytes = the lower triangle as floats, 4 n (n + 1) / 2, per launch (the spare passes that find every item "

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256, P32_OCC) void rs3p_products_kernel(Rs3Args a)
 // meeting of 256 work-groups: 31 us per pass, more than the predictor's products.  Nothing here has to follow the reference's
 // arithmetic to the letter -- only the COUNTS come out, and the exact phase verifies them -- so the predictor turns the loops
 // inside out: the trial points of a slice loop do not depend on the data (src/draw-f.cpp:50-56: a rejected point only moves the
-// bracket end of its own sign), hence the first PD_T points of EVERY candidate start of all three items can be evaluated side
+// bracket end of its own sign), hence the first PD_T points of EVERY candidate start of all four items can be evaluated side
 // by side before anything is decided.  Work-group (candidate c, row part p) of 32 x PD_PARTS: walks candidate c's bracket
 // sequence from R's uniforms at ITS position in the stream, takes cos / sin of the PD_T points, and sums, over its rows,
 // ll(f) and the PD_T trial log-likelihoods of the item the candidate belongs to -- the term in single precision through the

@@ -179,8 +179,8 @@ if rstats:
         f.write(f"# Round {tag[1:]}: the default contract (R-stream replay), `rocprofv3 --kernel-trace --stats -- python3 tools/rstream_step.py 8192 1024` (library commit {commit})\n\n")
         f.write("Init + five iterations at 8192 x 1024.  draw_f is PREDICT + VERIFY (csrc/rs_predict.hip, DESIGN.md section 2): the starts of all items "
                 "in R's stream are predicted by passes over a single-precision copy of L -- `rs3p_products_kernel` = L32 z for the pass's 32 candidate "
-                "starts (1 + 15 + 16) of three items, `rs3p_decide_kernel` = the first 16 trial points of every candidate side by side, one ticket, the "
-                "last work-group decides the three slots -- then `rs_gather_kernel` + ONE triangular fp64 product (`gemm_f64_kernel<false, false, 128, ...>`) "
+                "starts (1 + 13 + 11 + 7) of four items, `rs3p_decide_kernel` = the first 16 trial points of every candidate side by side, one ticket, the "
+                "last work-group decides the four slots -- then `rs_gather_kernel` + ONE triangular fp64 product (`gemm_f64_kernel<false, false, 128, ...>`) "
                 "+ `rs_verify_kernel` (every slice loop exactly, side by side) + `rs_commit_*` (accept in order up to the first misprediction).  "
                 "`rs3_begin_kernel` = the normal that starts at every position of the iteration's window; `rs32_tile_kernel` / `rs_tile_kernel` = L re-tiled "
                 "once per iteration (floats for the predictor, doubles for the one-phase fallback); `rs_unpack_kernel` = Mersenne-Twister words -> unif_rand() values.\n\n")
