@@ -186,8 +186,8 @@ if rstats:
                 "once per iteration (floats for the predictor, doubles for the one-phase fallback); `rs_unpack_kernel` = Mersenne-Twister words -> unif_rand() values.\n\n")
         for l in log:
             f.write(l + "\n\n")
-        f.write("(Under rocprofv3 the host falls behind -- a draw is ~1000 launches and a launch costs ~8 us of host time under the profiler -- so the "
-                "iteration reads ~40 ms here; unprofiled the same command gives 29.1 ms per iteration, draw_f 19.6 ms.  Per-kernel durations are unaffected.)\n\n")
+        f.write("(Under rocprofv3 a launch costs the host more -- a draw is ~700 launches -- so the iteration above reads a few ms longer than unprofiled "
+                "(`profiles/r06_bench.json`: `config.reference_rng`; `profiles/r06_predictor_stats.txt` for long chains).  Per-kernel durations are unaffected.)\n\n")
         f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
         for r in rrows[:14]:
             f.write(f"| `{short(r['Name'])[:80]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.3f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |\n")
