@@ -36,6 +36,7 @@ const Config& env_config()
         d.prep_early = env_value("GPIRT_PREP_EARLY", d.prep_early);
         d.guard_verbose = env_value("GPIRT_GUARD_VERBOSE", d.guard_verbose);
         d.rs_predict = env_value("GPIRT_RS_PREDICT", d.rs_predict);
+        d.rs_lr = env_value("GPIRT_RS_LR", d.rs_lr);
         if (d.nbo < 64) d.nbo = 1024;
         if (d.nbp != 0 && d.nbp < 64) d.nbp = 512;          // (0 = by size: potrf_subpanel_width)
         return d;
@@ -290,6 +291,7 @@ static int* config_slot(gpirt_handle_t h, const char* name, bool* read_only)
         { "GPIRT_LL_EXACT", &h->cfg.ll_exact, false }, { "GPIRT_ESS_SCREEN", &h->cfg.ess_screen, false }, { "GPIRT_THETA_FIXED", &h->cfg.theta_fixed, false }, { "GPIRT_BORDERED", &h->cfg.bordered, false },
         { "GPIRT_EARLY_INV", &h->cfg.early_inv, false }, { "GPIRT_PREP_EARLY", &h->cfg.prep_early, false },
         { "GPIRT_RS_PREDICT", &h->cfg.rs_predict, false },
+        { "GPIRT_RS_LR", &h->cfg.rs_lr, false },
     };
     for (auto& e : tab)
         if (strcmp(e.k, name) == 0) { if (read_only) *read_only = e.ro; return e.p; }

@@ -78,6 +78,7 @@ struct Config {
     int  bordered = 1;            // GPIRT_BORDERED: 2 = draw_fstar solves for L^-1 K(theta, c) / L^-1 k* explicitly
     int  early_inv = 1;           // GPIRT_EARLY_INV: 2 = no side work beside the factorisation's last outer panel
     int  prep_early = 1;          // GPIRT_PREP_EARLY: 2 = the factor-only part of the rank-r draw_fstar waits for nu = L z
+    int  rs_lr = 1;               // GPIRT_RS_LR: 2 = the predictor's every pass reads all of L as floats (no structured form, rs_lr.hip)
     int  rs_predict = 1;          // GPIRT_RS_PREDICT: 2 = the R-stream replay's draw_f runs every pass over L in fp64 (one phase, rng_ess.hip)
     int  guard_verbose = 0;       // GPIRT_GUARD_VERBOSE: 1 = a hang-guard fallback prints the guard record to stderr
 };

@@ -144,6 +144,12 @@ struct Rs3Args {
     // rs3p_decide_kernel: partial sums [work-group][17], the candidates' walk records [32][18], the ticket (monotonic)
     double* dec_part; double* dec_rec; unsigned* dec_ticket;
     uint64_t* pass_count;            // += 1 per real pass of the predictor (rs_ctl[3])
+    // the predictor's structured form (rs_lr.hip): the blocks of L below the diagonal parts as V C
+    int lr;                          // != 0: the units are the diagonal parts + 2 row groups of C per part (bit 31 of the unit word);
+                                     //       rs_lr_apply_kernel completes part 0 of part32, the decide kernel reads that one part
+    const float* Ct32;               // C in the tile layout of Lt32: RS_LR_RANK rows
+    float* lrY;                      // [parts][RS3_CAND][RS_LR_RANK]: y_J = C_J z_J of the pass
+    const float* V32t;               // [RS_LR_RANK][n]: the Lagrange basis at theta
 };
 inline int64_t rs_tile_quads(int64_t n) { return (n + 3) / 4 + 1; }
 inline size_t rs_tile_doubles(int64_t n) { return (size_t)((n + RS_ROWS - 1) / RS_ROWS) * (size_t)rs_tile_quads(n) * 128; }
@@ -157,7 +163,9 @@ int rs3_slice_rows(int64_t n);
 int launch_rs3_slice(hipStream_t stream, const Rs3Args& a);
 // rs_predict.hip: the predicted replay (phase A on single-precision tiles of L, phase B = one fp64 product + all slice loops
 // side by side + an in-order commit)
-inline int64_t rs32_tile_octs(int64_t n) { return (n + 7) / 8 + 1; }
+constexpr int RS_LR_RANK = 64;       // Chebyshev nodes of the predictor's structured form (rs_lr.hip)
+// (whole parts of 512 columns: the structured form's units read every oct of the part that holds a row group's diagonal)
+inline int64_t rs32_tile_octs(int64_t n) { return ((n + 511) / 512) * 64 + 1; }
 inline size_t rs32_tile_floats(int64_t n) { return (size_t)((n + RS_ROWS - 1) / RS_ROWS) * (size_t)rs32_tile_octs(n) * 256; }
 #ifndef RS3P_KC_VALUE
 #define RS3P_KC_VALUE 512
@@ -173,6 +181,20 @@ struct RsVerifyArgs {
     int* kv; int* used; int* ierr;   // [m]: rejections, uniforms consumed behind the normals, error code of each verified item
 };
 int launch_rs32_tiles(hipStream_t stream, const double* L, int64_t n, int64_t ldl, float* Lt);
+// rs_lr.hip: the structured form of the predictor's pass
+struct RsLrSetup {
+    const double* theta; int64_t n;
+    const double* nodes; const double* wts; const double* Mn;     // RS_LR_RANK nodes, barycentric weights, K(c, c)
+    double eps;                       // the jitter
+    const double* L; int64_t ldl;     // the dense factor (its 64 x 64 diagonal blocks are read)
+    double* V64; double* Gb;          // [64 ceil(n / 64)][RS_LR_RANK]; [ceil(n / 64)][RS_LR_RANK^2]
+    float* V32t; float* Ct32; int64_t nk8;
+    int* bad;                         // |= 1 zero pivot, 2 negative diagonal, 4 a coefficient beyond 1e6
+};
+void rs_lr_nodes(std::vector<double>& nodes, std::vector<double>& wts, std::vector<double>& M);
+void rs_lr_unit_table(int64_t n, std::vector<uint32_t>& units);
+int launch_rs_lr_setup(hipStream_t stream, const RsLrSetup& q);
+int launch_rs_lr_apply(hipStream_t stream, const Rs3Args& a);
 int launch_rs3p_products(hipStream_t stream, const Rs3Args& a);
 int launch_rs3p_decide(hipStream_t stream, const Rs3Args& a);
 int launch_rs_pred_start(hipStream_t stream, const uint64_t* anchor, uint64_t* anchorP, const int* k_last, int64_t m);

@@ -90,7 +90,7 @@ constexpr int P32_LDS = (RS3P_KC + 3 * P32_WIN > 4 * 1024) ? RS3P_KC + 3 * P32_W
 #define P32_OCC 5
 #endif
 template <bool FULL>
-__device__ __forceinline__ void rs3p_product_unit(const Rs3Args& a, const uint64_t base, const uint64_t off, const uint64_t lo2, const uint64_t lo3, const int bx, const int by, float* lds, long long* tr)
+__device__ __forceinline__ void rs3p_product_unit(const Rs3Args& a, const uint64_t base, const uint64_t off, const uint64_t lo2, const uint64_t lo3, const int bx, const int by, const bool ext, float* lds, long long* tr)
 {
     const int tid = threadIdx.x, lane = tid & 63, kq = tid >> 6, c = lane & 31, hh = lane >> 5;
     const int64_t n = a.n;
@@ -109,7 +109,8 @@ __device__ __forceinline__ void rs3p_product_unit(const Rs3Args& a, const uint64
         if (o_end > o_all) o_end = o_all;
         steps = o_end > o_beg ? (int)(o_end - o_beg) : 0;
     }
-    const float* Lp = a.Lt32 + ((int64_t)bx * a.nk8 + o_beg) * 256 + 4 * lane;
+    // (ext: two row groups of C in place of L's, rs_lr.hip -- every column of the part counts, nothing is triangular)
+    const float* Lp = (ext ? a.Ct32 : a.Lt32) + ((int64_t)bx * a.nk8 + o_beg) * 256 + 4 * lane;
     float* W0 = lds; float* W1 = lds + RS3P_KC; float* W2 = W1 + P32_WIN; float* W3 = W2 + P32_WIN;
     static_assert(RS3P_KC + 3 * P32_WIN <= P32_LDS, "the windows must fit");
     static_assert(PD_W1 <= 32 && PD_W2 <= 32 && PD_W3 <= 32, "a window holds 2 RS3P_KC + 32 normals");
@@ -178,12 +179,14 @@ __device__ __forceinline__ void rs3p_product_unit(const Rs3Args& a, const uint64
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[kq * 1024 + (8 * q + 4 * hh + r) * 32 + c] = acc[4 * q + r];
     __syncthreads();
-    float* out = a.part32 + ((int64_t)by * RS3_CAND) * n + r0;
+    // (the structured form: the diagonal part's product is part 0; C's rows go to the part's record of RS_LR_RANK values)
+    float* out = ext ? a.lrY + ((int64_t)by * RS3_CAND) * RS_LR_RANK + r0 : a.part32 + (a.lr ? 0 : ((int64_t)by * RS3_CAND) * n) + r0;
+    const int64_t os = ext ? RS_LR_RANK : n, lim = os - r0;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int x = tid + 256 * p, cand = x >> 5, row = x & 31;
         const float v = ((red[x] + red[1024 + x]) + red[2048 + x]) + red[3072 + x];
-        if (r0 + row < n) out[(int64_t)cand * n + row] = v;
+        if (row < lim) out[(int64_t)cand * os + row] = v;
     }
     if (tr) { tr[4] = (long long)wall_clock64(); tr[6] = (long long)clock64(); }
 }
@@ -195,13 +198,14 @@ __global__ __launch_bounds__(256, P32_OCC) void rs3p_products_kernel(Rs3Args a)
     const uint64_t item0 = a.anchor[0], base = a.anchor[1], stalled = a.anchor[3], off = a.anchor[5], lo2 = a.anchor[6], lo3 = a.anchor[7];
     const uint32_t unit = a.units[blockIdx.x];
     if (item0 >= (uint64_t)a.m || stalled != 0) return;       // every item is predicted, or the predictor has stalled
-    const int bx = (int)(unit & 0xffffu), by = (int)(unit >> 16);
+    const int bx = (int)(unit & 0xffffu), by = (int)((unit >> 16) & 0x7fffu);
+    const bool ext = (unit >> 31) != 0;
     // debug stamps (gpirt_debug_rs_trace; tools/rs_trace.py): first / middle / last full unit, 8 words each from trace[64]
     long long* tr = (a.trace && threadIdx.x == 0 && (blockIdx.x == 0 || (int)blockIdx.x == a.nfull / 2 || (int)blockIdx.x == a.nfull - 1))
                         ? a.trace + 64 + 8 * (blockIdx.x == 0 ? 0 : (int)blockIdx.x == a.nfull / 2 ? 1 : 2) : nullptr;
     if (tr) { tr[0] = (long long)wall_clock64(); tr[5] = (long long)clock64(); }
-    if ((int)blockIdx.x < a.nfull) rs3p_product_unit<true>(a, base, off, lo2, lo3, bx, by, lds, tr);
-    else                           rs3p_product_unit<false>(a, base, off, lo2, lo3, bx, by, lds, tr);
+    if ((int)blockIdx.x < a.nfull) rs3p_product_unit<true>(a, base, off, lo2, lo3, bx, by, ext, lds, tr);
+    else                           rs3p_product_unit<false>(a, base, off, lo2, lo3, bx, by, false, lds, tr);
 }
 
 // ---- the predictor's slice loops: ONE meeting per pass -------------------------------------------------------------------
@@ -226,6 +230,8 @@ constexpr int PD_MAXROUND = 14;          // 2 + PD_T * (PD_MAXROUND + 1) uniform
 constexpr int PD_REC = PD_T + 3;         // per candidate: uniforms consumed when point t is the current one (-1: past the window), log(u), valid,
                                          // uniforms consumed when the NEXT round's first point is the current one
 
+// LR: the structured form (rs_lr.hip) -- a candidate's column is ONE part, completed by rs_lr_apply_kernel
+template <bool LR>
 __global__ __launch_bounds__(320) void rs3p_decide_kernel(Rs3Args a)
 {
     extern __shared__ double pd_pad[];    // (dynamic LDS only to keep these work-groups one per compute unit: the ticket's hand-off was measured that way)
@@ -278,12 +284,12 @@ __global__ __launch_bounds__(320) void rs3p_decide_kernel(Rs3Args a)
     double yd[PD_RB], fd[PD_RB], md[PD_RB];
     // parts of the candidate's column that can hold something for this work-group's rows: the parts BEHIND a row's own columns
     // were never written by the products and still hold the zeros of the sampler's creation, so every row simply adds pmax parts
-    const int pmax = (int)((((r_end < n ? r_end : n) + RS3P_KC - 1) / RS3P_KC));
+    const int pmax = LR ? 1 : (int)((((r_end < n ? r_end : n) + RS3P_KC - 1) / RS3P_KC));
     const int64_t pstep = (int64_t)RS3_CAND * n;
     // Every load of a row is UNCONDITIONAL (rows past the part's end read the last row of the matrix and are masked when the
     // values are used): a load under a predicate is followed by its select, and the select waits for the load -- twelve
     // round trips one after the other instead of one (2.0 of the prologue's 5 us, in-kernel stamps).
-    constexpr int PD_QB = 16;                                  // parts of a row in flight together (n <= 8192: all of them)
+    constexpr int PD_QB = LR ? 1 : 16;                         // parts of a row in flight together (n <= 8192: all of them)
     float t16[PD_RB][PD_QB];
     int64_t ro[PD_RB];
     auto issue_rows = [&](const int64_t i0) {
@@ -812,10 +818,12 @@ int launch_rs3p_decide(hipStream_t stream, const Rs3Args& a)
     static bool attr_set = false;
     constexpr int pad = 96 * 1024;        // with the static LDS: more than half a compute unit's 160 KB -> one work-group per CU
     if (!attr_set) {
-        GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rs3p_decide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, pad));
+        GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rs3p_decide_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, pad));
+        GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rs3p_decide_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, pad));
         attr_set = true;
     }
-    hipLaunchKernelGGL(rs3p_decide_kernel, dim3(RS3_CAND * PD_PARTS), dim3(320), pad, stream, a);
+    if (a.lr) hipLaunchKernelGGL(rs3p_decide_kernel<true>, dim3(RS3_CAND * PD_PARTS), dim3(320), pad, stream, a);
+    else      hipLaunchKernelGGL(rs3p_decide_kernel<false>, dim3(RS3_CAND * PD_PARTS), dim3(320), pad, stream, a);
     GP_HIP(hipGetLastError());
     return 0;
 }

@@ -120,6 +120,12 @@ struct gpirt_sampler_s {
     double *rs_dec_part = nullptr, *rs_dec_rec = nullptr; unsigned* rs_dec_ticket = nullptr;
     double rs_pass_rate = 0.0; uint64_t rs_pass_seen = 0;    // real predictor passes per item of the last round / the counter's last reading
     int *rs_kpred = nullptr, *rs_kv = nullptr, *rs_used = nullptr, *rs_ierr = nullptr, *rs_errP = nullptr;
+    // the predictor's structured form (rs_lr.hip): nodes / weights / K(c, c), the basis at theta in both precisions, prefix Grams,
+    // C as tiles, the parts' records, the units; lr_on: in use; lr_strikes: draws in a row whose structured rounds mispredicted
+    double *lr_nodes = nullptr, *lr_wts = nullptr, *lr_M = nullptr, *lr_V64 = nullptr, *lr_Gb = nullptr;
+    float *lr_V32t = nullptr, *lr_Ct32 = nullptr, *lr_Y = nullptr;
+    int* lr_bad = nullptr; uint32_t* lr_units = nullptr; int lr_nunits = 0;
+    bool lr_on = false; int lr_strikes = 0; uint64_t rs_mis_seen = 0;
     // bookkeeping
     int iter = 0;                     // completed iterations
     bool initialised = false;
@@ -454,6 +460,16 @@ int do_draw_f(gpirt_sampler_s* s)
     // of the draw to the one-phase replay, which always makes progress and reports genuine errors.
     bool predict = h->cfg.rs_predict != 2;
     if (predict) GP_TRY(launch_rs32_tiles(st, s->L, n, s->ldl, s->Lt32));
+    // The structured form of the pass (rs_lr.hip): the blocks of L below the diagonal parts as V C, built from theta alone.  It
+    // serves the draw's rounds until one of them finds a misprediction (the dense pass takes the rest of the draw over); three
+    // such draws in a row, or a coefficient block the construction itself flags, switch it off for this sampler.
+    bool lr = predict && s->lr_on, lr_missed = false;
+    if (lr) {
+        RsLrSetup q{};
+        q.theta = s->theta; q.n = n; q.nodes = s->lr_nodes; q.wts = s->lr_wts; q.Mn = s->lr_M; q.eps = GPIRT_JITTER; q.L = s->L; q.ldl = s->ldl;
+        q.V64 = s->lr_V64; q.Gb = s->lr_Gb; q.V32t = s->lr_V32t; q.Ct32 = s->lr_Ct32; q.nk8 = rs32_tile_octs(n); q.bad = s->lr_bad;
+        GP_TRY(launch_rs_lr_setup(st, q));
+    }
     while (done < m) {
         const int64_t left = m - done;
         int64_t count = (left + RS3_SLOTS - 1) / RS3_SLOTS + left / 40 + 2;
@@ -471,6 +487,11 @@ int do_draw_f(gpirt_sampler_s* s)
             Rs3Args ap = a;
             ap.anchor = s->anchorP; ap.pos = s->rs_posP; ap.k_out = s->rs_kpred; ap.err = s->rs_errP;
             ap.units = s->rs_unitsP; ap.nunits = s->rs_nunitsP; ap.nfull = s->rs_nfullP;
+            ap.lr = lr ? 1 : 0;
+            if (lr) {
+                ap.units = s->lr_units; ap.nunits = ap.nfull = s->lr_nunits;
+                ap.Ct32 = s->lr_Ct32; ap.lrY = s->lr_Y; ap.V32t = s->lr_V32t;
+            }
             ap.Lt32 = s->Lt32; ap.nk8 = rs32_tile_octs(n); ap.part32 = s->rs_part32; ap.mispredict = h->rs_mispredict;
             ap.dec_part = s->rs_dec_part; ap.dec_rec = s->rs_dec_rec; ap.dec_ticket = s->rs_dec_ticket; ap.pass_count = s->rs_ctl + 3;
             GP_TRY(launch_rs_pred_start(st, s->anchor, s->anchorP, s->ess_k, m));
@@ -481,7 +502,10 @@ int do_draw_f(gpirt_sampler_s* s)
                 ProfPair pp;                                      // (bench.py's roofline: class 4, the lower triangle as floats)
                 GP_TRY(prof_pair_begin(h, st, pp));
                 GP_TRY(launch_rs3p_products(st, ap));
-                GP_TRY(prof_pair_end(h, st, pp, 4, 2.0 * RS3_CAND * 0.5 * (double)n * (double)(n + 1), 4.0 * 0.5 * (double)n * (double)(n + 1)));
+                // (algorithmic bytes / flops of the pass: the lower triangle as floats -- or, structured, the diagonal parts' rows and C)
+                const double pass_el = lr ? (double)(RS3P_KC + RS_LR_RANK) * (double)n : 0.5 * (double)n * (double)(n + 1);
+                GP_TRY(prof_pair_end(h, st, pp, 4, 2.0 * RS3_CAND * pass_el, 4.0 * pass_el));
+                if (lr) GP_TRY(launch_rs_lr_apply(st, ap));
                 GP_TRY(launch_rs3p_decide(st, ap));
             }
             // phase B: the items [done, predicted) at their predicted starts, exactly
@@ -510,9 +534,16 @@ int do_draw_f(gpirt_sampler_s* s)
         GP_HIP(hipMemcpyAsync(s->h_next, s->anchor, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         GP_HIP(hipMemcpyAsync(s->h_next + 1, s->flags, sizeof(int), hipMemcpyDeviceToHost, st));
         if (predict) GP_HIP(hipMemcpyAsync(s->h_next + 2, s->rs_ctl + 3, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        if (predict) GP_HIP(hipMemcpyAsync(s->h_next + 3, s->rs_ctl + 1, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        if (lr) GP_HIP(hipMemcpyAsync(s->h_next + 4, s->lr_bad, sizeof(int), hipMemcpyDeviceToHost, st));
         if (s->stream_open && !topped) { GP_TRY(ahead_topup(s, stream_window(s))); topped = true; }     // the next window's uniforms, while the items run
         GP_HIP(hipStreamSynchronize(st));
         if ((int)s->h_next[1] != 0) break;                    // (an error flag: stream_end / check report it)
+        if (predict) {
+            if (lr && (int)s->h_next[4] != 0) { s->lr_on = false; lr = false; }                  // the construction flagged itself
+            if (lr && s->h_next[3] != s->rs_mis_seen) { lr = false; lr_missed = true; }          // a misprediction: dense from here
+            s->rs_mis_seen = s->h_next[3];
+        }
         if ((int64_t)s->h_next[0] <= done) {
             if (predict) {                                    // the predictor stalled on its first item: the one-phase replay goes on
                 predict = false;
@@ -528,6 +559,10 @@ int do_draw_f(gpirt_sampler_s* s)
             s->rs_pass_rate = (double)real / (double)((int64_t)s->h_next[0] - done);
         }
         done = (int64_t)s->h_next[0];
+    }
+    if (s->lr_on) {
+        s->lr_strikes = lr_missed ? s->lr_strikes + 1 : 0;
+        if (s->lr_strikes >= 3) s->lr_on = false;
     }
     return 0;
 }
@@ -956,7 +991,7 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
         s->spec_ok = n >= RS_SPEC_MIN_N && n <= RS3_MAX_N && rs3_slice_wgs(n) <= h->n_cu;
         if (s->spec_ok) {
             const size_t parts = (size_t)((n + RS_KC - 1) / RS_KC);
-            const size_t nrm = (size_t)s->U_cap + 8 * (size_t)n + 1024;       // (the predictor's products read up to 8n + 6 + 32 + 16 PD_MAXROUND + 40 past an anchor)
+            const size_t nrm = (size_t)s->U_cap + 8 * (size_t)n + 4096;       // (the predictor's products read up to 8n + 6 + 32 + 16 PD_MAXROUND + 40 past an anchor)
             GP_A(s->Lt, rs_tile_doubles(n));
             GP_A(s->posv, m + 1);    GP_A(s->anchor, 4);    GP_A(s->rs_trace, 128);
             hipMemsetAsync(s->rs_trace, 0, 128 * sizeof(long long), st);
@@ -986,7 +1021,30 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
             s->rs_nunitsP = (int)unitsP.size();
             GP_A(s->rs_unitsP, unitsP.size());
             hipMemcpyAsync(s->rs_unitsP, unitsP.data(), unitsP.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
-            hipStreamSynchronize(st);                                          // (unitsP leaves scope with units below)
+            // the structured form of the predictor's pass (rs_lr.hip): from 4096 rows on (below, a pass over L is a few MB anyway: 2048 x 256 runs at 270 it/s with it, 298 without),
+            // not with the single-precision kernel build (S then is not the kernel the basis represents, to 6e-8)
+            s->lr_on = h->cfg.rs_lr != 2 && n >= 4096 && !s->opt.kernel_fp32;
+            std::vector<uint32_t> unitsL;
+            if (s->lr_on) {
+                std::vector<double> nodes, wts, Mn;
+                rs_lr_nodes(nodes, wts, Mn);
+                const size_t nb = (size_t)((n + 63) / 64), lparts = (size_t)((n + RS3P_KC - 1) / RS3P_KC);
+                GP_A(s->lr_nodes, RS_LR_RANK);  GP_A(s->lr_wts, RS_LR_RANK);  GP_A(s->lr_M, RS_LR_RANK * RS_LR_RANK);
+                GP_A(s->lr_V64, nb * 64 * RS_LR_RANK);  GP_A(s->lr_Gb, nb * RS_LR_RANK * RS_LR_RANK);
+                GP_A(s->lr_V32t, (size_t)RS_LR_RANK * (size_t)n);  GP_A(s->lr_Ct32, (size_t)(RS_LR_RANK / RS_ROWS) * (size_t)rs32_tile_octs(n) * 256);
+                GP_A(s->lr_Y, lparts * RS3_CAND * RS_LR_RANK);  GP_A(s->lr_bad, 4);
+                hipMemcpyAsync(s->lr_nodes, nodes.data(), sizeof(double) * RS_LR_RANK, hipMemcpyHostToDevice, st);
+                hipMemcpyAsync(s->lr_wts, wts.data(), sizeof(double) * RS_LR_RANK, hipMemcpyHostToDevice, st);
+                hipMemcpyAsync(s->lr_M, Mn.data(), sizeof(double) * RS_LR_RANK * RS_LR_RANK, hipMemcpyHostToDevice, st);
+                hipMemsetAsync(s->lr_Ct32, 0, sizeof(float) * (size_t)(RS_LR_RANK / RS_ROWS) * (size_t)rs32_tile_octs(n) * 256, st);
+                hipMemsetAsync(s->lr_Y, 0, sizeof(float) * lparts * RS3_CAND * RS_LR_RANK, st);
+                hipMemsetAsync(s->lr_bad, 0, 4 * sizeof(int), st);
+                rs_lr_unit_table(n, unitsL);
+                s->lr_nunits = (int)unitsL.size();
+                GP_A(s->lr_units, unitsL.size());
+                hipMemcpyAsync(s->lr_units, unitsL.data(), unitsL.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+            }
+            hipStreamSynchronize(st);                                          // (unitsP, unitsL leave scope with units below)
             hipStreamSynchronize(st);                                          // (units leaves scope)
         }
         GP_A(s->beta_off, m);
@@ -995,7 +1053,7 @@ int gpirt_sampler_create(gpirt_sampler_t* out, gpirt_handle_t h, const double* h
             hipHostMalloc(&s->hA, s->U_cap * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
             hipHostMalloc(&s->h_pos, 2 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess ||
             hipStreamCreateWithFlags(&s->cs, hipStreamNonBlocking) != hipSuccess ||
-            hipHostMalloc(&s->h_next, 4 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc(&s->h_next, 8 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess ||
             hipEventCreateWithFlags(&s->ev_up, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s->ev_asm, hipEventDisableTiming) != hipSuccess) {
             set_error("pinned allocation for the R-stream window failed");
