@@ -664,6 +664,47 @@ def test_r_stream_predicted_replay_agrees_with_the_one_phase_replay(handle, n, m
     assert q1[1] == 0 and q1[2] == 0                      # (no misprediction, no stall on these chains: the predictor earns its keep)
 
 
+@pytest.mark.parametrize("n,m,every", [(4096, 30, 0), (4500, 21, 0), (8192, 16, 0), (4500, 21, 5)])
+def test_r_stream_structured_predictor_agrees_with_the_dense_predictor(handle, n, m, every):
+    """From 4096 respondents on the predictor's pass does not read L: the blocks of the factor below the 512-column diagonal
+    parts are applied as V C -- the Lagrange basis of 64 Chebyshev nodes at theta times coefficients built from theta alone
+    (rs_lr.hip); GPIRT_RS_LR=2 keeps the dense single-precision pass.  Both only PREDICT; what is returned is verified exactly:
+    same counts, theta, stream position and f as the dense predictor, and the structured predictor is right (no misprediction
+    over these chains, n a multiple of 512 or not).  every > 0: the predictor is made wrong on purpose at every fifth item --
+    the first round of a draw is structured, the dense pass takes the rest of the draw over, three such draws retire the
+    structured form for the sampler; the draws are unchanged."""
+    from gpirt_amd import Sampler, _lib
+    from gpirt_amd.ops import RStream
+    from gpirt_amd.synthetic import make_responses
+    lib = _lib.load()
+    y, th0 = make_responses(n, m, seed=5 * n + m)
+    outs = []
+    for mode in (1, 2):
+        with handle.config("GPIRT_RS_LR", mode):
+            if every and mode == 1:
+                _lib.check(lib.gpirt_debug_rs_mispredict(handle._h, every))
+            try:
+                rs = RStream(77)
+                s = Sampler(handle, y, th0, rng="reference", rstream=rs, theta_stabilise=True)
+                s.init()
+                for _ in range(5):
+                    s.step()
+                s.check()
+                outs.append((s.get("f"), s.get("ess_k"), s.get("theta"), rs.state(), s.get("rs_stats")))
+                s.close()
+            finally:
+                _lib.check(lib.gpirt_debug_rs_mispredict(handle._h, 0))
+    (f1, k1, t1, st1, q1), (f2, k2, t2, st2, q2) = outs
+    assert np.array_equal(k1, k2) and np.array_equal(t1, t2)
+    assert st1[1] == st2[1] and np.array_equal(st1[0], st2[0])
+    assert np.abs(f1 - f2).max() <= 1e-10
+    assert q1[2] == 0 and q2[2] == 0
+    if every == 0:
+        assert q1[1] == 0 and q2[1] == 0, (q1, q2)
+    else:
+        assert q1[1] >= 5 * (m // every) - 5, q1
+
+
 def test_r_stream_predicted_replay_long_slice_loops(handle):
     """Behind the burn-in of a chain with 8192 respondents the slice loops lengthen (mean count ~6, some above 16): a loop that
     rejects all sixteen points of a pass goes on in the next pass (round + 1), the candidate starts of the items behind it begin
