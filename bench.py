@@ -67,6 +67,33 @@ def _roof_entry(prof, bound, peak, unit, kernel):
             "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak}
 
 
+def _replay_entry(prof, n):
+    """The roofline entry of the R-stream predictor's products kernel.  From 4096 respondents on the pass is STRUCTURED
+    (csrc/rs_lr.hip): it reads the 512-column diagonal parts of L and 64 rows of coefficients instead of the lower triangle --
+    told apart here by the bytes the library booked per launch."""
+    e = _roof_entry(prof, "hbm", PEAK_HBM_GBS, "GB/s", "")
+    if e is None:
+        return None
+    dense_bytes = 4.0 * 0.5 * n * (n + 1)
+    if e["algorithmic_bytes_per_launch"] < 0.5 * dense_bytes:
+        e["kernel"] = ("rs3p_products_kernel (R-stream replay, gpirt_default_options), STRUCTURED pass (csrc/rs_lr.hip): the blocks of L below "
+                       "the 512-column diagonal parts are applied as V C (Lagrange basis of 64 Chebyshev nodes at theta x coefficients "
+                       "built from theta alone), so a pass reads 4 (512 + 64) n bytes -- %.1f MB instead of the lower triangle's %.1f MB as "
+                       "floats -- and this kernel is bound by its launch and two memory round trips, not by bytes; beside it per pass: "
+                       "rs_lr_apply_kernel (prefix over the parts' records + V x prefix) and rs3p_decide_kernel.  GPIRT_RS_LR=2: the dense "
+                       "single-precision pass (134 MB at n = 8192: 30 us = 0.52-0.57 of the HBM peak, profiles/r06_replay_dense_summary.md)"
+                       % (e["algorithmic_bytes_per_launch"] / 1e6, dense_bytes / 1e6))
+        e["structured"] = True
+    else:
+        e["kernel"] = ("rs3p_products_kernel (R-stream replay, gpirt_default_options): the predictor's pass over L as single-precision "
+                       "tiles; bytes = the lower triangle as floats, 4 n (n + 1) / 2, per launch (the spare passes that find every item "
+                       "predicted and leave at once are left out, as in rocprofv3's median in profiles/); flops = "
+                       "2 x 32 candidates x n (n + 1) / 2 on v_mfma_f32_32x32x2_f32 (157 TFLOP/s peak: 16.6 us of a ~30 us pass)")
+        e["structured"] = False
+    e["kernel"] += "; timed in the reference_rng leg of this run"
+    return e
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -344,8 +371,9 @@ def main():
                 rs_stats = sr.get("rs_stats")
                 ref_rng = {"value": 2.0 / dtr, "iterations": 2, "theta_stabilise": int(stab),
                            "passes_over_L_per_iteration": int(replay_prof[1]), "items_per_pass": (m / replay_prof[1]) if replay_prof[1] else None,
-                           "draw_f": "predict + verify (csrc/rs_predict.hip): the starts of all items in R's stream predicted by passes over a "
-                                     "SINGLE-PRECISION copy of L (up to four items per pass, 32 candidate starts, 16 trial points each), then every item "
+                           "draw_f": "predict + verify (csrc/rs_predict.hip, csrc/rs_lr.hip): the starts of all items in R's stream predicted by passes over a "
+                                     "SINGLE-PRECISION copy of L (up to four items per pass, 32 candidate starts, 16 trial points each; from 4096 respondents on a "
+                                     "pass reads only L's 512-column diagonal parts and applies the blocks below them in a rank-64 Lagrange basis), then every item "
                                      "computed exactly at its predicted start -- one fp64 triangular MFMA product + all slice loops side by side, the "
                                      "formula as written -- and committed in order; GPIRT_RS_PREDICT=2: every pass in fp64 (rounds 4-5)",
                            "mispredictions_found_by_the_verification_so_far": int(rs_stats[1]),
@@ -511,13 +539,8 @@ def main():
                                                   "operations per launch, exact int32 sums; peak = twice the dense bf16 rate "
                                                   "(MI355X_MICROARCH.md, matrix cores) at the nominal 2.4 GHz -- the chip holds ~1.8 GHz under this "
                                                   "kernel (tools/theta_clock.py).  The fp64 GEMM it replaces ran 0.52 ms at 0.91 of the fp64 MFMA peak"),
-                # the default contract's draw_f: one pass over L per up to four items (rs3p_products_kernel), HBM-bound
-                "replay_products": _roof_entry(replay_prof, "hbm", PEAK_HBM_GBS, "GB/s",
-                                               "rs3p_products_kernel (R-stream replay, gpirt_default_options): the predictor's pass over L as single-precision "
-                                               "tiles; bytes = the lower triangle as floats, 4 n (n + 1) / 2, per launch (the spare passes that find every item "
-                                               "predicted and leave at once are left out, as in rocprofv3's median in profiles/); flops = "
-                                               "2 x 32 candidates x n (n + 1) / 2 on v_mfma_f32_32x32x2_f32 (157 TFLOP/s peak: 16.6 us of a ~30 us pass); "
-                                               "timed in the reference_rng leg of this run"),
+                # the default contract's draw_f: the predictor's pass for up to four items (rs3p_products_kernel)
+                "replay_products": _replay_entry(replay_prof, n),
                 "note": "HIP events around each launch on its own stream (main or look-ahead side stream) inside the timed region, on "
                         "a sample of the timed steps (the first and the middle one: bracketing every launch of every step costs 4 % "
                         "of the iteration rate); launches of the two streams overlap each other and the panel kernel, so "

@@ -153,60 +153,85 @@ with open(f"profiles/{tag}_summary.md", "a") as f:
         f.write(f"\nDefault contract in the same run (`config.reference_rng`): {rr.get('value')} iterations/s, "
                 f"{rr.get('passes_over_L_per_iteration')} passes over L per iteration ({rr.get('items_per_pass')} items per pass).\n")
 
-# ---- the default contract (R-stream replay): tools/rstream_step.py 8192 1024 under rocprofv3
-try:
-    rstats = newest(raw + "/replay_stats/**/*kernel_stats.csv")
-except ValueError:
-    rstats = None
-if rstats:
-    shutil.copy(rstats, f"profiles/{tag}_replay_kernel_stats.csv")
+# ---- the default contract (R-stream replay): tools/rstream_step.py 8192 1024 under rocprofv3, with the structured pass of the
+# predictor (the default from 4096 respondents on, csrc/rs_lr.hip) and with the dense single-precision pass (GPIRT_RS_LR=2)
+def replay_section(sub, structured):
+    try:
+        rstats = newest(f"{raw}/{sub}_stats/**/*kernel_stats.csv")
+    except ValueError:
+        return
+    name = "replay" if structured else "replay_dense"
+    shutil.copy(rstats, f"profiles/{tag}_{name}_kernel_stats.csv")
     rrows = list(csv.DictReader(open(rstats)))
-    log = [l.strip() for l in open(raw + "/replay_stats.log") if ("per iteration" in l or "stage ms" in l or "rejection counts" in l)]
+    log = [l.strip() for l in open(f"{raw}/{sub}_stats.log") if ("per iteration" in l or "stage ms" in l or "rejection counts" in l)]
 
-    def one(name, counter):
-        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(newest(f"{raw}/{name}/**/*counter_collection.csv")))
+    def one(pm, counter):
+        try:
+            path = newest(f"{raw}/{sub}_{pm}/**/*counter_collection.csv")
+        except ValueError:
+            return (None, 0)
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
                 if "rs3p_products_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter]
-        big = [v for v in vals if v > 0.5 * max(vals)] if vals else []       # (spare passes leave at once: not a pass over L)
+        big = [v for v in vals if v > 0.5 * max(vals)] if vals else []       # (spare passes leave at once: not a pass)
         return (sum(big) / len(big), len(big)) if big else (None, 0)
 
-    fk, nf = one("replay_pmc_fetch", "FETCH_SIZE")
-    wk, _ = one("replay_pmc_write", "WRITE_SIZE")
-    busy, _ = one("replay_pmc_mfma", "SQ_VALU_MFMA_BUSY_CYCLES")
-    gui, _ = one("replay_pmc_mfma", "GRBM_GUI_ACTIVE")
+    fk, nf = one("pmc_fetch", "FETCH_SIZE")
+    wk, _ = one("pmc_write", "WRITE_SIZE")
+    busy, _ = one("pmc_mfma", "SQ_VALU_MFMA_BUSY_CYCLES")
+    gui, _ = one("pmc_mfma", "GRBM_GUI_ACTIVE")
     n_ = 8192
-    alg = 4.0 * n_ * (n_ + 1) / 2
-    with open(f"profiles/{tag}_replay_summary.md", "w") as f:
-        f.write(f"# Round {tag[1:]}: the default contract (R-stream replay), `rocprofv3 --kernel-trace --stats -- python3 tools/rstream_step.py 8192 1024` (library commit {commit})\n\n")
+    alg = 4.0 * (512 + 64) * n_ if structured else 4.0 * n_ * (n_ + 1) / 2
+    with open(f"profiles/{tag}_{name}_summary.md", "w") as f:
+        f.write(f"# Round {tag[1:]}: the default contract (R-stream replay), " + ("" if structured else "`GPIRT_RS_LR=2` (the predictor's DENSE pass), ") +
+                f"`rocprofv3 --kernel-trace --stats -- python3 tools/rstream_step.py 8192 1024` (library commit {commit})\n\n")
         f.write("Init + five iterations at 8192 x 1024.  draw_f is PREDICT + VERIFY (csrc/rs_predict.hip, DESIGN.md section 2): the starts of all items "
-                "in R's stream are predicted by passes over a single-precision copy of L -- `rs3p_products_kernel` = L32 z for the pass's 32 candidate "
-                "starts (1 + 13 + 11 + 7) of four items, `rs3p_decide_kernel` = the first 16 trial points of every candidate side by side, one ticket, the "
+                "in R's stream are predicted by a chain of passes, each placing up to four items from 32 candidate starts (1 + 13 + 11 + 7) -- ")
+        if structured:
+            f.write("`rs3p_products_kernel` = the STRUCTURED pass (csrc/rs_lr.hip): L32 z over the 512-column part that holds each row group's diagonal, "
+                    "plus y_J = C_J z_J for the parts' coefficient blocks (the blocks of L below the diagonal parts are V C: the Lagrange basis of 64 "
+                    "Chebyshev nodes at theta times coefficients built once per iteration from theta and the factor's 64 x 64 diagonal blocks by "
+                    "`lr_basis_kernel`, `lr_gram_kernel`, `lr_scan_kernel`, `lr_coef_kernel`); `rs_lr_apply_kernel` = prefix over the parts' records + V x prefix; ")
+        else:
+            f.write("`rs3p_products_kernel` = L32 z for the pass's candidates over the whole lower triangle as single-precision tiles; ")
+        f.write("`rs3p_decide_kernel` = the first 16 trial points of every candidate side by side, one ticket, the "
                 "last work-group decides the four slots -- then `rs_gather_kernel` + ONE triangular fp64 product (`gemm_f64_kernel<false, false, 128, ...>`) "
                 "+ `rs_verify_kernel` (every slice loop exactly, side by side) + `rs_commit_*` (accept in order up to the first misprediction).  "
-                "`rs3_begin_kernel` = the normal that starts at every position of the iteration's window; `rs32_tile_kernel` / `rs_tile_kernel` = L re-tiled "
-                "once per iteration (floats for the predictor, doubles for the one-phase fallback); `rs_unpack_kernel` = Mersenne-Twister words -> unif_rand() values.\n\n")
+                "`rs3_begin_kernel` = the normal that starts at every position of the iteration's window; `rs32_tile_kernel` = L re-tiled "
+                "once per iteration as floats; `rs_unpack_kernel` = Mersenne-Twister words -> unif_rand() values.\n\n")
         for l in log:
             f.write(l + "\n\n")
-        f.write("(Under rocprofv3 a launch costs the host more -- a draw is ~700 launches -- so the iteration above reads a few ms longer than unprofiled "
+        f.write("(Under rocprofv3 a launch costs the host more -- a draw is ~700-1000 launches -- so the iteration above reads a few ms longer than unprofiled "
                 "(`profiles/r06_bench.json`: `config.reference_rng`; `profiles/r06_predictor_stats.txt` for long chains).  Per-kernel durations are unaffected.)\n\n")
         f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
-        for r in rrows[:14]:
+        for r in rrows[:16]:
             f.write(f"| `{short(r['Name'])[:80]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.3f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |\n")
-        st = stat_row(rrows, "rs3p_products_kernel")
-        if st:
-            # the spare passes (every item already predicted) leave at once: the average over REAL passes is what the roofline needs
-            tr = newest(raw + "/replay_stats/**/*kernel_trace.csv")
-            trows = list(csv.DictReader(open(tr)))
-            dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in trows if "rs3p_products_kernel" in r["Kernel_Name"]]
-            real = [d for d in dur if d > 0.5 * max(dur)]
-            avg_us = sum(real) / len(real)
-            f.write(f"\n`rs3p_products_kernel`: {len(real)} real passes of {len(dur)} launches (the others find every item predicted and leave at once), "
-                    f"{avg_us:.1f} us per real pass -> {alg / avg_us / 1e6:.2f} TB/s of L as floats (algorithmic 4 n (n + 1) / 2 = {alg / 1e6:.0f} MB) = "
-                    f"{alg / avg_us / 1e6 / 8.0:.3f} of the 8 TB/s HBM peak; its 2 x 32 x n (n + 1) / 2 = {64 * n_ * (n_ + 1) / 2 / 1e9:.2f} GFLOP per pass = "
-                    f"{64 * n_ * (n_ + 1) / 2 / avg_us / 1e6:.1f} TFLOP/s = {64 * n_ * (n_ + 1) / 2 / avg_us / 1e6 / 157.3:.3f} of the 157.3 TFLOP/s f32-input MFMA peak.\n")
-            dd = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in trows if "rs3p_decide_kernel" in r["Kernel_Name"]]
-            dreal = [d for d in dd if d > 0.5 * max(dd)] if dd else []
-            if dreal:
-                f.write(f"\n`rs3p_decide_kernel`: {sum(dreal) / len(dreal):.1f} us per real pass ({len(dreal)} of {len(dd)} launches).\n")
+        tr = newest(f"{raw}/{sub}_stats/**/*kernel_trace.csv")
+        trows = list(csv.DictReader(open(tr)))
+
+        def real_avg(kname):
+            # the spare passes (every item already predicted) leave at once: the average over REAL passes is what counts
+            dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in trows if kname in r["Kernel_Name"]]
+            real = [d for d in dur if d > 0.4 * sorted(dur)[(len(dur) * 3) // 4]] if dur else []
+            return (sum(real) / len(real), len(real), len(dur)) if real else (None, 0, 0)
+
+        avg_us, nreal, nall = real_avg("rs3p_products_kernel")
+        if avg_us:
+            if structured:
+                f.write(f"\n`rs3p_products_kernel` (structured): {nreal} real passes of {nall} launches (the others find every item predicted and leave at once), "
+                        f"{avg_us:.1f} us per real pass for 4 (512 + 64) n = {alg / 1e6:.1f} MB (the dense pass: {4.0 * n_ * (n_ + 1) / 2 / 1e6:.0f} MB) -> "
+                        f"{alg / avg_us / 1e6:.2f} TB/s = {alg / avg_us / 1e6 / 8.0:.3f} of the 8 TB/s HBM peak: the kernel is bound by its launch and two "
+                        f"dependent memory round trips (anchor, then windows and tiles), not by bytes.\n")
+                a_us, na, _ = real_avg("rs_lr_apply_kernel")
+                if a_us:
+                    f.write(f"\n`rs_lr_apply_kernel`: {a_us:.1f} us per real pass.\n")
+            else:
+                f.write(f"\n`rs3p_products_kernel`: {nreal} real passes of {nall} launches (the others find every item predicted and leave at once), "
+                        f"{avg_us:.1f} us per real pass -> {alg / avg_us / 1e6:.2f} TB/s of L as floats (algorithmic 4 n (n + 1) / 2 = {alg / 1e6:.0f} MB) = "
+                        f"{alg / avg_us / 1e6 / 8.0:.3f} of the 8 TB/s HBM peak; its 2 x 32 x n (n + 1) / 2 = {64 * n_ * (n_ + 1) / 2 / 1e9:.2f} GFLOP per pass = "
+                        f"{64 * n_ * (n_ + 1) / 2 / avg_us / 1e6:.1f} TFLOP/s = {64 * n_ * (n_ + 1) / 2 / avg_us / 1e6 / 157.3:.3f} of the 157.3 TFLOP/s f32-input MFMA peak.\n")
+            d_us, nd, ndall = real_avg("rs3p_decide_kernel")
+            if d_us:
+                f.write(f"\n`rs3p_decide_kernel`: {d_us:.1f} us per real pass ({nd} of {ndall} launches).\n")
         if fk:
             f.write(f"\nPMC passes of `tools/rstream_step.py 8192 128` (separate runs), averages over the {nf} real passes: FETCH_SIZE {fk:.0f} KB raw "
                     f"(x 2 = {2 * fk * 1024 / 1e6:.0f} MB: gfx950 tallies 128-B requests at 64 B), WRITE_SIZE {wk:.0f} KB ({wk * 1024 / 1e6:.1f} MB: the parts of the "
@@ -214,5 +239,9 @@ if rstats:
             if busy and gui:
                 f.write(f"; MFMA busy {busy / ((gui / 8) * 1024):.3f} of the chip's SIMDs")
             f.write(".\n")
-    print(open(f"profiles/{tag}_replay_summary.md").read()[:2500])
+    print(open(f"profiles/{tag}_{name}_summary.md").read()[:2500])
+
+
+replay_section("replay", True)
+replay_section("replay_dense", False)
 print(open(f"profiles/{tag}_summary.md").read()[:3000])
