@@ -180,7 +180,7 @@ struct RsVerifyArgs {
     const uint64_t* anchorP;         // [0] = first item the predictor has NOT reached
     int* kv; int* used; int* ierr;   // [m]: rejections, uniforms consumed behind the normals, error code of each verified item
 };
-int launch_rs32_tiles(hipStream_t stream, const double* L, int64_t n, int64_t ldl, float* Lt);
+int launch_rs32_tiles(hipStream_t stream, const double* L, int64_t n, int64_t ldl, float* Lt, bool diag_only = false);
 // rs_lr.hip: the structured form of the predictor's pass
 struct RsLrSetup {
     const double* theta; int64_t n;

@@ -38,7 +38,8 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 // columns) = 1 KiB, lane l = (row rg 32 + (l & 31), columns 8 ko + 4 (l >> 5) .. + 3) as one float4: a wave's step is one
 // contiguous kilobyte, its steps follow each other in memory.  Rows and columns past the matrix are zeros; the strict upper
 // triangle of L holds zeros (gpirt_sampler_create).  Only the tiles a product reads are written.
-__global__ __launch_bounds__(256) void rs32_tile_kernel(const double* __restrict__ L, int64_t n, int64_t ldl, int64_t nk8, float* __restrict__ Lt)
+// diag_only: just the octs of the 512-column part that holds the row group's diagonal (all the structured pass reads, rs_lr.hip)
+__global__ __launch_bounds__(256) void rs32_tile_kernel(const double* __restrict__ L, int64_t n, int64_t ldl, int64_t nk8, float* __restrict__ Lt, int diag_only)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t rg = blockIdx.y;
@@ -46,7 +47,8 @@ __global__ __launch_bounds__(256) void rs32_tile_kernel(const double* __restrict
     const int64_t kall = (r0 + RS_ROWS < n) ? r0 + RS_ROWS : n;
     const int64_t ko_end = (kall + 7) / 8;
     const int64_t row = r0 + (lane & 31);
-    for (int64_t ko = (int64_t)blockIdx.x * 4 + wave; ko < ko_end; ko += (int64_t)gridDim.x * 4) {
+    const int64_t ko_beg = diag_only ? (r0 / RS3P_KC) * (RS3P_KC / 8) : 0;
+    for (int64_t ko = ko_beg + (int64_t)blockIdx.x * 4 + wave; ko < ko_end; ko += (int64_t)gridDim.x * 4) {
         const int64_t k = 8 * ko + 4 * (lane >> 5);
         float4 v;
         v.x = (row < n && k + 0 < n) ? (float)L[row + (k + 0) * ldl] : 0.0f;
@@ -797,10 +799,10 @@ __global__ __launch_bounds__(256) void rs_commit_copy_kernel(RsVerifyArgs a, con
 
 }  // namespace
 
-int launch_rs32_tiles(hipStream_t stream, const double* L, int64_t n, int64_t ldl, float* Lt)
+int launch_rs32_tiles(hipStream_t stream, const double* L, int64_t n, int64_t ldl, float* Lt, bool diag_only)
 {
     const int64_t nrg = (n + RS_ROWS - 1) / RS_ROWS, nk8 = rs32_tile_octs(n);
-    hipLaunchKernelGGL(rs32_tile_kernel, dim3(8, (unsigned)nrg), dim3(256), 0, stream, L, n, ldl, nk8, Lt);
+    hipLaunchKernelGGL(rs32_tile_kernel, dim3(diag_only ? 2 : 8, (unsigned)nrg), dim3(256), 0, stream, L, n, ldl, nk8, Lt, diag_only ? 1 : 0);
     GP_HIP(hipGetLastError());
     return 0;
 }

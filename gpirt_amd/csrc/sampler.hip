@@ -459,11 +459,13 @@ int do_draw_f(gpirt_sampler_s* s)
     // the prediction did not break.  A round that commits nothing (the predictor stalled on its first item) hands the rest
     // of the draw to the one-phase replay, which always makes progress and reports genuine errors.
     bool predict = h->cfg.rs_predict != 2;
-    if (predict) GP_TRY(launch_rs32_tiles(st, s->L, n, s->ldl, s->Lt32));
     // The structured form of the pass (rs_lr.hip): the blocks of L below the diagonal parts as V C, built from theta alone.  It
     // serves the draw's rounds until one of them finds a misprediction (the dense pass takes the rest of the draw over); three
     // such draws in a row, or a coefficient block the construction itself flags, switch it off for this sampler.
     bool lr = predict && s->lr_on, lr_missed = false;
+    // (single-precision tiles of L: the structured pass reads the diagonal parts only; the whole triangle follows if the dense pass is needed)
+    bool tiles32_full = !lr;
+    if (predict) GP_TRY(launch_rs32_tiles(st, s->L, n, s->ldl, s->Lt32, lr));
     if (lr) {
         RsLrSetup q{};
         q.theta = s->theta; q.n = n; q.nodes = s->lr_nodes; q.wts = s->lr_wts; q.Mn = s->lr_M; q.eps = GPIRT_JITTER; q.L = s->L; q.ldl = s->ldl;
@@ -487,6 +489,7 @@ int do_draw_f(gpirt_sampler_s* s)
             Rs3Args ap = a;
             ap.anchor = s->anchorP; ap.pos = s->rs_posP; ap.k_out = s->rs_kpred; ap.err = s->rs_errP;
             ap.units = s->rs_unitsP; ap.nunits = s->rs_nunitsP; ap.nfull = s->rs_nfullP;
+            if (!lr && !tiles32_full) { GP_TRY(launch_rs32_tiles(st, s->L, n, s->ldl, s->Lt32)); tiles32_full = true; }
             ap.lr = lr ? 1 : 0;
             if (lr) {
                 ap.units = s->lr_units; ap.nunits = ap.nfull = s->lr_nunits;

@@ -67,17 +67,29 @@ __global__ __launch_bounds__(128) void lowrank_s_kernel(const double* __restrict
     if (k == 0) s[j] = 1.0 - sqrt(fmax(red[0], 0.0));
 }
 
-// exclusive count of RNG-consuming grid points (s_i > 0 and finite) -- R-stream replay only
-__global__ void fstar_offsets_kernel(const double* __restrict__ s, int N, int* __restrict__ off)
+// exclusive count of RNG-consuming grid points (s_i > 0 and finite) -- R-stream replay only.  One work-group: every thread
+// counts a contiguous chunk, the chunks' counts are scanned in LDS, every thread writes its chunk's offsets.
+__global__ __launch_bounds__(256) void fstar_offsets_kernel(const double* __restrict__ s, int N, int* __restrict__ off)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        int c = 0;
-        for (int i = 0; i < N; ++i) {
-            off[i] = c;
-            const double v = s[i];
-            if (isfinite(v) && v > 0.0) ++c;
-        }
-        off[N] = c;
+    __shared__ int cnt[256];
+    const int tid = threadIdx.x;
+    const int per = (N + 255) / 256;
+    const int i0 = tid * per, i1 = (i0 + per < N) ? i0 + per : N;
+    int c = 0;
+    for (int i = i0; i < i1; ++i) { const double v = s[i]; c += (isfinite(v) && v > 0.0) ? 1 : 0; }
+    cnt[tid] = c;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int q = 0; q < 256; ++q) { const int t = cnt[q]; cnt[q] = run; run += t; }
+        off[N] = run;
+    }
+    __syncthreads();
+    c = cnt[tid];
+    for (int i = i0; i < i1; ++i) {
+        off[i] = c;
+        const double v = s[i];
+        if (isfinite(v) && v > 0.0) ++c;
     }
 }
 
@@ -344,7 +356,7 @@ int launch_fstar_epilogue(hipStream_t stream, const FstarEpiArgs& a)
     const int* off = nullptr;
     if (a.U) {
         if (!a.off_scratch) { set_error("R-stream fstar replay needs the offset scratch (N + 1 ints)"); return GPIRT_E_ARG; }
-        hipLaunchKernelGGL(fstar_offsets_kernel, dim3(1), dim3(64), 0, stream, a.s, (int)a.N, a.off_scratch);
+        hipLaunchKernelGGL(fstar_offsets_kernel, dim3(1), dim3(256), 0, stream, a.s, (int)a.N, a.off_scratch);
         off = a.off_scratch;
     }
     dim3 grid((unsigned)((a.N + 255) / 256), (unsigned)a.m);
