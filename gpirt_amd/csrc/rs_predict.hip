@@ -92,7 +92,7 @@ constexpr int P32_LDS = (RS3P_KC + 3 * P32_WIN > 4 * 1024) ? RS3P_KC + 3 * P32_W
 #define P32_OCC 5
 #endif
 template <bool FULL>
-__device__ __forceinline__ void rs3p_product_unit(const Rs3Args& a, const uint64_t base, const uint64_t off, const uint64_t lo2, const uint64_t lo3, const int bx, const int by, const bool ext, float* lds, long long* tr)
+__device__ __forceinline__ void rs3p_product_unit(const Rs3Args& a, const uint64_t base, const uint64_t off, const uint64_t lo2, const uint64_t lo3, const int bx, const int by, float* lds, long long* tr)
 {
     const int tid = threadIdx.x, lane = tid & 63, kq = tid >> 6, c = lane & 31, hh = lane >> 5;
     const int64_t n = a.n;
@@ -111,8 +111,7 @@ __device__ __forceinline__ void rs3p_product_unit(const Rs3Args& a, const uint64
         if (o_end > o_all) o_end = o_all;
         steps = o_end > o_beg ? (int)(o_end - o_beg) : 0;
     }
-    // (ext: two row groups of C in place of L's, rs_lr.hip -- every column of the part counts, nothing is triangular)
-    const float* Lp = (ext ? a.Ct32 : a.Lt32) + ((int64_t)bx * a.nk8 + o_beg) * 256 + 4 * lane;
+    const float* Lp = a.Lt32 + ((int64_t)bx * a.nk8 + o_beg) * 256 + 4 * lane;
     float* W0 = lds; float* W1 = lds + RS3P_KC; float* W2 = W1 + P32_WIN; float* W3 = W2 + P32_WIN;
     static_assert(RS3P_KC + 3 * P32_WIN <= P32_LDS, "the windows must fit");
     static_assert(PD_W1 <= 32 && PD_W2 <= 32 && PD_W3 <= 32, "a window holds 2 RS3P_KC + 32 normals");
@@ -181,14 +180,12 @@ __device__ __forceinline__ void rs3p_product_unit(const Rs3Args& a, const uint64
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[kq * 1024 + (8 * q + 4 * hh + r) * 32 + c] = acc[4 * q + r];
     __syncthreads();
-    // (the structured form: the diagonal part's product is part 0; C's rows go to the part's record of RS_LR_RANK values)
-    float* out = ext ? a.lrY + ((int64_t)by * RS3_CAND) * RS_LR_RANK + r0 : a.part32 + (a.lr ? 0 : ((int64_t)by * RS3_CAND) * n) + r0;
-    const int64_t os = ext ? RS_LR_RANK : n, lim = os - r0;
+    float* out = a.part32 + ((int64_t)by * RS3_CAND) * n + r0;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int x = tid + 256 * p, cand = x >> 5, row = x & 31;
         const float v = ((red[x] + red[1024 + x]) + red[2048 + x]) + red[3072 + x];
-        if (row < lim) out[(int64_t)cand * os + row] = v;
+        if (r0 + row < n) out[(int64_t)cand * n + row] = v;
     }
     if (tr) { tr[4] = (long long)wall_clock64(); tr[6] = (long long)clock64(); }
 }
@@ -200,14 +197,96 @@ __global__ __launch_bounds__(256, P32_OCC) void rs3p_products_kernel(Rs3Args a)
     const uint64_t item0 = a.anchor[0], base = a.anchor[1], stalled = a.anchor[3], off = a.anchor[5], lo2 = a.anchor[6], lo3 = a.anchor[7];
     const uint32_t unit = a.units[blockIdx.x];
     if (item0 >= (uint64_t)a.m || stalled != 0) return;       // every item is predicted, or the predictor has stalled
-    const int bx = (int)(unit & 0xffffu), by = (int)((unit >> 16) & 0x7fffu);
-    const bool ext = (unit >> 31) != 0;
+    const int bx = (int)(unit & 0xffffu), by = (int)(unit >> 16);
     // debug stamps (gpirt_debug_rs_trace; tools/rs_trace.py): first / middle / last full unit, 8 words each from trace[64]
     long long* tr = (a.trace && threadIdx.x == 0 && (blockIdx.x == 0 || (int)blockIdx.x == a.nfull / 2 || (int)blockIdx.x == a.nfull - 1))
                         ? a.trace + 64 + 8 * (blockIdx.x == 0 ? 0 : (int)blockIdx.x == a.nfull / 2 ? 1 : 2) : nullptr;
     if (tr) { tr[0] = (long long)wall_clock64(); tr[5] = (long long)clock64(); }
-    if ((int)blockIdx.x < a.nfull) rs3p_product_unit<true>(a, base, off, lo2, lo3, bx, by, ext, lds, tr);
-    else                           rs3p_product_unit<false>(a, base, off, lo2, lo3, bx, by, false, lds, tr);
+    if ((int)blockIdx.x < a.nfull) rs3p_product_unit<true>(a, base, off, lo2, lo3, bx, by, lds, tr);
+    else                           rs3p_product_unit<false>(a, base, off, lo2, lo3, bx, by, lds, tr);
+}
+
+// The structured pass's products (rs_lr.hip: the diagonal parts of L and the coefficient rows C, every unit a whole part of
+// RS3P_KC columns): ~300 work-groups, one or two per compute unit, so nothing hides a wave's latencies but the wave itself --
+// NW = 8 waves take 64 columns each (8 steps: every kilobyte of the wave's tiles is requested up front) instead of four waves
+// 128: the MFMA phase of a unit 3.3 -> 1.8 us (in-kernel stamps), the windows staged by twice the threads.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void rs3p_products_lr_kernel(Rs3Args a)
+{
+    constexpr int NT = 64 * NW, STEPS = RS3P_KC / (8 * NW);
+    constexpr int LDSF = (RS3P_KC + 3 * P32_WIN > NW * 1024) ? RS3P_KC + 3 * P32_WIN : NW * 1024;
+    __shared__ __attribute__((aligned(16))) float lds[LDSF];
+    const uint64_t item0 = a.anchor[0], base = a.anchor[1], stalled = a.anchor[3], off = a.anchor[5], lo2 = a.anchor[6], lo3 = a.anchor[7];
+    const uint32_t unit = a.units[blockIdx.x];
+    if (item0 >= (uint64_t)a.m || stalled != 0) return;       // every item is predicted, or the predictor has stalled
+    const int bx = (int)(unit & 0xffffu), by = (int)((unit >> 16) & 0x7fffu);
+    const bool ext = (unit >> 31) != 0;
+    long long* tr = (a.trace && threadIdx.x == 0 && (blockIdx.x == 0 || (int)blockIdx.x == a.nfull / 2 || (int)blockIdx.x == a.nfull - 1))
+                        ? a.trace + 64 + 8 * (blockIdx.x == 0 ? 0 : (int)blockIdx.x == a.nfull / 2 ? 1 : 2) : nullptr;
+    if (tr) { tr[0] = (long long)wall_clock64(); tr[5] = (long long)clock64(); }
+    const int tid = threadIdx.x, lane = tid & 63, kq = tid >> 6, c = lane & 31, hh = lane >> 5;
+    const int64_t n = a.n;
+    const int64_t r0 = (int64_t)bx * RS_ROWS;
+    const int64_t k0 = (int64_t)by * RS3P_KC;
+    const int64_t o_beg = (k0 >> 3) + (int64_t)kq * STEPS;
+    const float* Lp = (ext ? a.Ct32 : a.Lt32) + ((int64_t)bx * a.nk8 + o_beg) * 256 + 4 * lane;
+    float* W0 = lds; float* W1 = lds + RS3P_KC; float* W2 = W1 + P32_WIN; float* W3 = W2 + P32_WIN;
+    const uint64_t item_step = 2ull * (uint64_t)n + 2ull;
+    const double* N0 = a.Nrm + base + 2ull * (uint64_t)k0;
+    const double* N1 = N0 + item_step + off;
+    const double* N2 = N1 + item_step + lo2;
+    const double* N3 = N1 + 2ull * item_step + lo3;
+    constexpr int C0 = (RS3P_KC + NT - 1) / NT, CW = (P32_WIN + NT - 1) / NT;
+    double w0[C0], w1[CW], w2[CW], w3[CW];
+    float4 lv[STEPS];
+#pragma unroll
+    for (int q = 0; q < C0; ++q) { const int x = tid + NT * q; w0[q] = N0[2 * (x < RS3P_KC ? x : 0)]; }
+#pragma unroll
+    for (int q = 0; q < CW; ++q) { const int x = tid + NT * q; const int xc = x < P32_WIN ? x : 0; w1[q] = N1[xc]; w2[q] = N2[xc]; w3[q] = N3[xc]; }
+#pragma unroll
+    for (int u = 0; u < STEPS; ++u) lv[u] = *reinterpret_cast<const float4*>(Lp + (int64_t)u * 256);
+#pragma unroll
+    for (int q = 0; q < C0; ++q) { const int x = tid + NT * q; if (x < RS3P_KC) W0[x] = (float)w0[q]; }
+#pragma unroll
+    for (int q = 0; q < CW; ++q) { const int x = tid + NT * q; if (x < P32_WIN) { W1[x] = (float)w1[q]; W2[x] = (float)w2[q]; W3[x] = (float)w3[q]; } }
+    __syncthreads();
+    if (tr) tr[1] = (long long)wall_clock64();                 // windows staged
+    const float* Zb = (c == 0) ? W0 : (c < PD_B2 ? W1 + (c - 1) : c < PD_B3 ? W2 + (c - PD_B2) : W3 + (c - PD_B3));
+    const int zs = (c == 0) ? 1 : 2;
+    const float* z = Zb + zs * ((int)((o_beg << 3) - k0) + 4 * hh);
+    f16v acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const float4 l = lv[s];
+        const float z0 = z[zs * (8 * s)], z1 = z[zs * (8 * s + 1)], z2 = z[zs * (8 * s + 2)], z3 = z[zs * (8 * s + 3)];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(z0, l.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(z1, l.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(z2, l.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(z3, l.w, acc, 0, 0, 0);
+    }
+    if (tr) tr[2] = (long long)wall_clock64();                 // this wave's MFMAs issued
+    __syncthreads();                                            // (the windows are no longer read)
+    if (tr) tr[3] = (long long)wall_clock64();
+    float* red = lds;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[kq * 1024 + (8 * q + 4 * hh + r) * 32 + c] = acc[4 * q + r];
+    __syncthreads();
+    // the diagonal part's product is part 0 of part32; C's rows go to the part's record of RS_LR_RANK values
+    float* out = ext ? a.lrY + ((int64_t)by * RS3_CAND) * RS_LR_RANK + r0 : a.part32 + r0;
+    const int64_t os = ext ? RS_LR_RANK : n, lim = os - r0;
+#pragma unroll
+    for (int p = 0; p < 1024 / NT; ++p) {
+        const int x = tid + NT * p, cand = x >> 5, row = x & 31;
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[w * 1024 + x];
+        if (row < lim) out[(int64_t)cand * os + row] = v;
+    }
+    if (tr) { tr[4] = (long long)wall_clock64(); tr[6] = (long long)clock64(); }
 }
 
 // ---- the predictor's slice loops: ONE meeting per pass -------------------------------------------------------------------
@@ -810,7 +889,8 @@ int launch_rs32_tiles(hipStream_t stream, const double* L, int64_t n, int64_t ld
 int launch_rs3p_products(hipStream_t stream, const Rs3Args& a)
 {
     if (a.nunits <= 0) return 0;
-    hipLaunchKernelGGL(rs3p_products_kernel, dim3((unsigned)a.nunits), dim3(256), 0, stream, a);
+    if (a.lr) hipLaunchKernelGGL(rs3p_products_lr_kernel<8>, dim3((unsigned)a.nunits), dim3(512), 0, stream, a);
+    else      hipLaunchKernelGGL(rs3p_products_kernel, dim3((unsigned)a.nunits), dim3(256), 0, stream, a);
     GP_HIP(hipGetLastError());
     return 0;
 }

@@ -13,7 +13,7 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=o
 # (mangled-name fragment, why it matters)
 NO_SCRATCH = {
     "rng_ess.hip": ["14ess_kernel_regILi8ELi256ELb1ELb0E", "14ess_kernel_regILi16ELi512ELb1ELb0E", "19rs3_products_kernel"],
-    "rs_predict.hip": ["20rs3p_products_kernel", "18rs3p_decide_kernel", "16rs_verify_kernel", "20rs_verify_reg_kernelILi16ELi512E", "20rs_verify_reg_kernelILi8ELi256E"],
+    "rs_predict.hip": ["20rs3p_products_kernel", "23rs3p_products_lr_kernel", "18rs3p_decide_kernel", "16rs_verify_kernel", "20rs_verify_reg_kernelILi16ELi512E", "20rs_verify_reg_kernelILi8ELi256E"],
     "rs_lr.hip": ["18rs_lr_apply_kernel", "14lr_coef_kernel"],
 }
 
