@@ -171,7 +171,7 @@ def replay_section(sub, structured):
         except ValueError:
             return (None, 0)
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
-                if "rs3p_products_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+                if "rs3p_products" in r["Kernel_Name"] and r["Counter_Name"] == counter]
         big = [v for v in vals if v > 0.5 * max(vals)] if vals else []       # (spare passes leave at once: not a pass)
         return (sum(big) / len(big), len(big)) if big else (None, 0)
 
@@ -214,7 +214,7 @@ def replay_section(sub, structured):
             real = [d for d in dur if d > 0.4 * sorted(dur)[(len(dur) * 3) // 4]] if dur else []
             return (sum(real) / len(real), len(real), len(dur)) if real else (None, 0, 0)
 
-        avg_us, nreal, nall = real_avg("rs3p_products_kernel")
+        avg_us, nreal, nall = real_avg("rs3p_products")
         if avg_us:
             if structured:
                 f.write(f"\n`rs3p_products_kernel` (structured): {nreal} real passes of {nall} launches (the others find every item predicted and leave at once), "
