@@ -705,6 +705,45 @@ def test_r_stream_structured_predictor_agrees_with_the_dense_predictor(handle, n
         assert q1[1] >= 5 * (m // every) - 5, q1
 
 
+@pytest.mark.parametrize("kind", ["sorted", "constant", "wide", "two_values"])
+def test_r_stream_structured_predictor_with_awkward_theta(handle, kind):
+    """The structured pass is built from theta alone (rs_lr.hip).  Starting values that stress the construction -- respondents
+    sorted by theta (every 64-row block sees a sliver of the axis), all respondents at one point or at two (a kernel matrix of
+    rank one or two), values beyond the nodes' interval [-5, 5] (clamped for the basis: those rows are predicted badly) -- may
+    cost mispredictions but never a wrong draw, a stall into the one-phase replay or a flagged coefficient block that goes
+    unnoticed: counts, theta, stream position and f equal the dense predictor's."""
+    from gpirt_amd import Sampler
+    from gpirt_amd.ops import RStream
+    from gpirt_amd.synthetic import make_responses
+    n, m = 4096, 12
+    y, th0 = make_responses(n, m, seed=99, snap_theta=False)
+    if kind == "sorted":
+        th0 = np.sort(th0)
+    elif kind == "constant":
+        th0 = np.full(n, 0.37)
+    elif kind == "two_values":
+        th0 = np.where(np.arange(n) % 3 == 0, -1.25, 2.5).astype(np.float64)
+    else:
+        th0 = 2.4 * th0                                    # a few hundred respondents beyond +-5
+    outs = []
+    for mode in (1, 2):
+        with handle.config("GPIRT_RS_LR", mode):
+            rs = RStream(5)
+            s = Sampler(handle, y, th0, rng="reference", rstream=rs, theta_stabilise=True)
+            s.init()
+            for _ in range(2):
+                s.step()
+            s.check()
+            outs.append((s.get("f"), s.get("ess_k"), s.get("theta"), rs.state(), s.get("rs_stats")))
+            s.close()
+    (f1, k1, t1, st1, q1), (f2, k2, t2, st2, q2) = outs
+    assert np.array_equal(k1, k2) and np.array_equal(t1, t2)
+    assert st1[1] == st2[1] and np.array_equal(st1[0], st2[0])
+    assert np.abs(f1 - f2).max() <= 1e-10
+    assert q1[2] == 0 and q2[2] == 0, (q1, q2)
+    print(f"[structured predictor, theta_init {kind}] mispredictions {int(q1[1])} (dense predictor: {int(q2[1])})")
+
+
 def test_r_stream_predicted_replay_long_slice_loops(handle):
     """Behind the burn-in of a chain with 8192 respondents the slice loops lengthen (mean count ~6, some above 16): a loop that
     rejects all sixteen points of a pass goes on in the next pass (round + 1), the candidate starts of the items behind it begin
