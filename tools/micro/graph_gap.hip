@@ -4,20 +4,24 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <chrono>
+#include <cstdlib>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
-struct Args { unsigned long long* anchor; float* buf; int n; };
+struct Args { unsigned long long* anchor; float* buf; int n; int spin; };
 // a stand-in for a pass kernel: reads the anchor, touches a little memory, work-group 0 bumps the anchor
 __global__ __launch_bounds__(256) void link_kernel(Args a)
 {
     const unsigned long long v = a.anchor[0];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < a.n) a.buf[i] = a.buf[i] * 0.5f + (float)(v & 7);
+    float x = (i < a.n) ? a.buf[i] : 0.0f;
+    for (int q = 0; q < a.spin; ++q) x = __builtin_fmaf(x, 0.999f, 1.0f);          // (a body of a few microseconds: the host gets ahead of the device)
+    if (i < a.n) a.buf[i] = x * 0.5f + (float)(v & 7);
     if (blockIdx.x == 0 && threadIdx.x == 0) a.anchor[0] = v + 1;
 }
-int main()
+int main(int argc, char** argv)
 {
     hipStream_t st; CK(hipStreamCreate(&st));
-    Args a; a.n = 288 * 256;
+    Args a; a.n = 288 * 256; a.spin = argc > 1 ? atoi(argv[1]) : 0;
+    printf("spin %d\n", a.spin);
     CK(hipMalloc(&a.anchor, 64)); CK(hipMemset(a.anchor, 0, 64)); CK(hipMalloc(&a.buf, a.n * 4)); CK(hipMemset(a.buf, 0, a.n * 4));
     const int CHAIN = 3000, GRID = 288;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
